@@ -1,0 +1,48 @@
+"""Shared test helpers: synthetic state_dicts shaped like the reference's
+modules (tests/golden/state_shapes.json, captured from the reference) and
+golden loaders.  Test-side only."""
+import json
+import os
+import numpy as np
+import torch
+
+from sincformer_metacog_speech_enhancement_amd import synthetic as syn
+from oracle import sfm_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLD, "state_shapes.json")) as _fh:
+    STATE_TABLES = json.load(_fh)
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+def synth_sd(table, seed, fs=16000, sinc_scale=None, as_torch=True):
+    """State dict for reference module `table` filled by synthetic.synth_state_dict."""
+    shapes = {k: tuple(v[0]) for k, v in STATE_TABLES[table]["state"].items()}
+    keep = None
+    sinc_keys = [k for k in shapes if k.split(".")[-1] in ("low_hz_", "band_hz_", "window", "n_")]
+    if sinc_keys:
+        init = orc.sinc_init(64, 251, fs)
+        keep = {k: init[k.split(".")[-1]].numpy() for k in sinc_keys}
+    sd = syn.synth_state_dict(shapes, seed, keep=keep, sinc_scale=sinc_scale)
+    if as_torch:
+        return {k: torch.from_numpy(v) for k, v in sd.items()}
+    return sd
+
+
+def arr(key, shape, seed, scale=1.0):
+    return torch.from_numpy(syn.synth_array(key, shape, seed, scale))
+
+
+def maxerr(a, b):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).abs().max())
+
+
+def rmse(a, b):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return float(((a - b) ** 2).mean().sqrt())
