@@ -1,0 +1,133 @@
+/* libsincformer_hip.so — C ABI of the MI355X (gfx950) hot path.
+ *
+ * The reference (pure Python / PyTorch) has no FFI layer: its operator boundary
+ * for this path is the set of aten dispatch sites listed in SURVEY.md §2b
+ * (K1..K17).  Each entry point below replaces the cited reference call site.
+ * Conventions:
+ *   - plain pointers to DEVICE memory + sizes; no torch types; `stream` is a
+ *     hipStream_t passed as void* (0 = default stream).
+ *   - enqueue-only: every call is asynchronous on `stream`, allocates nothing,
+ *     keeps no global state (thread-safe per stream), never throws.
+ *   - returns 0 (SFM_OK) or a negative error: -1 bad argument, -2 unsupported
+ *     shape, -3 launch failure.
+ *   - `dtype` selects the 16-bit MFMA operand / activation format:
+ *       0 = bf16, 1 = fp16 (accumulation is always fp32).
+ *   - "16-bit" tensors are raw uint16_t words of that format.
+ */
+#ifndef SINCFORMER_HIP_H
+#define SINCFORMER_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_OK 0
+#define SFM_ERR_ARG (-1)
+#define SFM_ERR_SHAPE (-2)
+#define SFM_ERR_LAUNCH (-3)
+#define SFM_DT_BF16 0
+#define SFM_DT_F16 1
+
+/* epilogues of sfm_gemm16 */
+#define SFM_EPI_NONE 0
+#define SFM_EPI_SWISH 1      /* x*sigmoid(x)           models/conformer.py:45          */
+#define SFM_EPI_GELU 2       /* erf GELU               agents/msa.py:45,64,69          */
+#define SFM_EPI_RESID 3      /* resid + alpha*v        models/conformer.py:49,71,128   */
+#define SFM_EPI_GLU 4        /* a*sigmoid(g)           models/conformer.py:114         */
+#define SFM_EPI_SIGMOID 5
+#define SFM_EPI_TANH_SCALE 6
+#define SFM_EPI_SIGMA 7      /* exp(.5*clamp(v,-10,10)) agents/perception.py:249       */
+#define SFM_EPI_CPEA 8       /* sigmoid | alpha*tanh   agents/cpea.py:102-105          */
+
+int sfm_abi_version(void);
+
+/* Dense layer / channels-last Conv1d as implicit GEMM on 16-bit MFMA.
+ * Replaces nn.Linear / nn.Conv1d call sites: models/conformer.py:44,47,113,122,
+ * 209,222; in_proj/out_proj of nn.MultiheadAttention (:69); agents/msa.py:143,
+ * 154-160; agents/perception.py:195,198,203 (conv_blocks), :168 (downsample),
+ * :175,179 (real/imag proj), :185,187 (uncertainty head); agents/cpea.py:56-76.
+ *   A   [B, Lin, Cin] 16-bit (position stride lda >= Cin, batch stride a_batch_stride; elements)
+ *   W   [Npad, Kpad] 16-bit, row n = output channel, K order = (tap, cin);
+ *       zero padded; Kpad % 32 == 0, Npad % 64 == 0
+ *   out row (b, l) = epi( sum_{tap,ci} A[b, l*stride-pad+tap, ci] W[n,(tap,ci)] + bias[n] )
+ *   gn_partial (optional): per (batch, row-half-tile, group) {sum, sumsq} of the
+ *       pre-activation outputs, [B][2*ceil(Lout/128)][N/gn_group][2] floats.
+ */
+int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const float* resid,
+               float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+               long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+               int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+               int nsplit, int dtype, void* stream);
+
+/* out[b,m,n] = bias[n] + sum_k sig[b, m*hop + k - padl] * Wt[k][n], exact fp32 on
+ * v_mfma_f32_32x32x2_f32.  Replaces F.conv1d of SincConv1d (agents/perception.py:117),
+ * torch.stft (training/conformer_pipeline.py:199), the irfft stage of torch.istft
+ * (:210) and fp32 matmuls.  mode 0: zero outside [0,Ls); 1: reflect.
+ * Columns >= nsplit go to out2 (when non-NULL) at column n - nsplit.
+ * gn_partial layout: [B][4*ceil(M/128)][N/gn_group][2]. */
+int sfm_framed_gemm_f32(const float* sig, const float* Wt, const float* bias, void* out, void* out2,
+                        float* gn_partial, int B, int M, int Ls, long long sig_batch_stride, int hop,
+                        int padl, int K, int Kpad, int N, int Npad, int nsplit, long long o_batch_stride,
+                        long long ldm, long long ldn, int mode, int out_f32, int gn_group, int dtype,
+                        void* stream);
+
+/* softmax(Q K^T * scale) V per (batch, head); replaces the attention core of
+ * nn.MultiheadAttention (models/conformer.py:69).  qkv [B,T,ldqkv] 16-bit with
+ * q at column h*hd, k at koff+h*hd, v at voff+h*hd; out [B,T,ldo] 16-bit at h*hd. */
+int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
+                      int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
+                      float scale, int dtype, void* stream);
+
+/* nn.LayerNorm (+ optional erf GELU when act==1): models/conformer.py:43,68,107,150;
+ * agents/msa.py:44-47; training/conformer_pipeline.py:274,282. */
+int sfm_layernorm(const float* x, const float* w, const float* b, void* out16, float* out32, int M, int D,
+                  int ldx, int ld16, int ld32, float eps, int act, int dtype, void* stream);
+
+/* nn.GroupNorm split in (stats from GEMM epilogue) -> finalize -> apply
+ * (agents/perception.py:157,169,176,180,196,199,204 and the residual add+GELU :129). */
+int sfm_gn_finalize(const float* partial, const float* w, const float* b, float* scale, float* shift, int B,
+                    int P, int G, int C, long long rows, float eps, void* stream);
+int sfm_gn_apply(const void* x1, const float* sc1, const float* sh1, const void* x2, const float* sc2,
+                 const float* sh2, void* out, int B, long long rows_per_batch, int C, int in_f32, int out_f32,
+                 int act, int dtype, void* stream);
+
+/* depthwise Conv1d + BatchNorm1d(eval) + Swish, channels-last: models/conformer.py:117-119 */
+int sfm_dwconv_bn_swish(const void* x, const float* wdw, const float* bdw, const float* bnw,
+                        const float* bnb, const float* bnm, const float* bnv, void* out, int B, int T,
+                        int C, int KS, float eps, int dtype, void* stream);
+
+/* layout / packing */
+int sfm_convert_rows(const float* src, void* dst, long long M, int C, int Cz, long long ld_src,
+                     long long ld_dst, int dtype, void* stream);
+int sfm_transpose(const void* src, void* dst, int B, int R, int C, long long src_batch, long long src_row,
+                  long long dst_batch, long long dst_row, int src_f32, int dst_f32, int dtype, void* stream);
+int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, int Tout, int C,
+                  long long ld_src, long long ld_dst, int dtype, void* stream);
+/* agents/msa.py:134-137 */
+int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst, long long M, int F, int zpad,
+                          long long ld_dst, int dtype, void* stream);
+/* agents/msa.py:166-172, training/conformer_pipeline.py:287-296 */
+int sfm_polar_mask(const float* lm, const float* lp, const float* mag_bias, const float* nr, const float* ni,
+                   float* mr, float* mi, float* er, float* ei, float* mmag, int B, long long rows_per_batch,
+                   int F, float phase_scale, long long ld_logits, long long ld_enh, void* stream);
+/* models/conformer.py:243-244 */
+int sfm_complex_mul(const float* sr, const float* si, const float* mr, const float* mi, float* er, float* ei,
+                    long long total, void* stream);
+/* overlap-add + envelope division of torch.istft: training/conformer_pipeline.py:210 */
+int sfm_istft_ola(const float* frames, const float* win2, float* out, int B, int T, int L, int n_fft, int hop,
+                  int win, long long ld_frames, void* stream);
+int sfm_pack_spec(const float* re, const float* im, float* dst, long long M, int F, int ld, long long ld_src,
+                  void* stream);
+/* agents/perception.py:88-112 */
+int sfm_sinc_filters(const float* low_hz, const float* band_hz, const float* window, const float* n_,
+                     float* filt, float* Wt, int C, int K, int Npad, float sample_rate, float min_low_hz,
+                     float min_band_hz, void* stream);
+/* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
+int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
+/* EpisodicMemory.forward eval (agents/memory.py:112-133) in one launch, see memory.hip */
+int sfm_memory_fwd(const float* emb, const float* params, float* bias_out, float* gate_out, int* top_idx,
+                   float* sim_out, int B, int key_dim, int value_dim, int slots, float temperature, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,4 @@
+from .perception import PerceptionAgent, SincConv1d
+from .cpea import CorrelationPhaseEstimationAgent
+from .msa import MaskSynthesisAgent
+from .memory import EpisodicMemory

@@ -1,0 +1,275 @@
+// Self-attention core softmax(Q K^T / sqrt(hd)) V  (models/conformer.py:69 ->
+// nn.MultiheadAttention, no mask, no positional term).
+//
+// attn_fwd_hd64: flash-style, never materialises [T, T].  Block = 4 waves =
+// 128 query rows of one (batch, head); each wave owns 32 query rows.  Per
+// 64-key tile (K, V staged in LDS, zero-filled past T):
+//   S^T = K Q^T   (32x32x16 MFMA; A = K rows from LDS, B = Q held in registers)
+//         -> each lane holds 16 keys of ONE query row (col = lane&31), so the
+//            row max / row sum are in-lane + one exchange with lane^32
+//   online softmax in fp32 (exp2 domain, scale folded in)
+//   O^T += V^T P^T: the S^T accumulator, converted to 16-bit, IS the B operand
+//            (k order 16s + 8(j>>2) + 4h + (j&3)); the matching A operand V^T
+//            comes from ds_read_b64_tr_b16 on the row-major V tile.
+// Epilogue: O^T / l -> LDS transpose -> 16-byte coalesced row stores.
+//
+// attn_fwd_generic: small-shape path (any head_dim <= 256, e.g. the reference
+// test config d_model 64 / 4 heads = 16), one wave per query row, fp32 VALU.
+#include "sfm_common.h"
+
+#define KS_ROW 72    // u16 elements: 144-byte K rows  (ds_read_b128 conflict-free)
+#define VS_ROW 96    // u16 elements: 192-byte V rows  (4 rows x 64 B tile the 256-B bank row for tr reads)
+#define OS_ROW 72
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
+                                                            int Tlen, int ldqkv, int ldo, int koff, int voff,
+                                                            long long qkv_batch_stride, long long o_batch_stride,
+                                                            float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) u16 smem[64 * KS_ROW + 64 * VS_ROW];
+  u16* Ks = smem;
+  u16* Vs = smem + 64 * KS_ROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int hl = lane >> 5, l31 = lane & 31;
+  const u16* base = qkv + (long long)b * qkv_batch_stride + h * 64;
+
+  // Q fragments: B operand, col = query (lane&31), k = d = ks*16 + 8*hl + j
+  u32x4 qf[4];
+  {
+    const int q = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < Tlen) v = *reinterpret_cast<const u32x4*>(base + (long long)q * ldqkv + ks * 16 + hl * 8);
+      qf[ks] = v;
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dj][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // staging coordinates: 64 rows x 8 chunks(16 B) for K and for V; 2 chunks each per thread
+  int srow[2], scol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int c = tid + 256 * i;
+    srow[i] = c >> 3;
+    scol[i] = (c & 7) * 8;
+  }
+  u32x4 rk[2], rv[2];
+  const int ntiles = (Tlen + 63) / 64;
+
+  auto load_kv = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kt * 64 + srow[i];
+      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+      if (key < Tlen) {
+        const u16* rowp = base + (long long)key * ldqkv + scol[i];
+        a = *reinterpret_cast<const u32x4*>(rowp + koff);
+        c = *reinterpret_cast<const u32x4*>(rowp + voff);
+      }
+      rk[i] = a;
+      rv[i] = c;
+    }
+  };
+
+  load_kv(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(&Ks[srow[i] * KS_ROW + scol[i]]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Vs[srow[i] * VS_ROW + scol[i]]) = rv[i];
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) load_kv(kt + 1);
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kj = 0; kj < 2; ++kj) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kj][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[(kj * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
+        s[kj] = T::mfma(kf, qf[ks], s[kj]);
+      }
+    }
+    // ---- online softmax (row = query = lane&31; keys spread over regs and lane halves) ----
+    const int kbase = kt * 64;
+    float mx = -1e30f;
+#pragma unroll
+    for (int kj = 0; kj < 2; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int key = kbase + kj * 32 + mfma_row(r, lane);
+        float v = s[kj][r] * scale_log2e;
+        v = (key < Tlen) ? v : -1e30f;
+        s[kj][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < 2; ++kj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = exp2f(s[kj][r] - m_new);
+        s[kj][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kj = 0; kj < 2; ++kj) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 pf;
+        pf[0] = pack2<T>(s[kj][8 * s2 + 0], s[kj][8 * s2 + 1]);
+        pf[1] = pack2<T>(s[kj][8 * s2 + 2], s[kj][8 * s2 + 3]);
+        pf[2] = pack2<T>(s[kj][8 * s2 + 4], s[kj][8 * s2 + 5]);
+        pf[3] = pack2<T>(s[kj][8 * s2 + 6], s[kj][8 * s2 + 7]);
+        // transposed V reads: 16-lane group g -> d block (g&1)*16, lane half = g>>1;
+        // lane 4q+p of the group addresses row q, cols 4p..4p+3 and receives column (lane&15)
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int qq = i16 >> 2, pp = i16 & 3;
+        const int keyrow = kj * 32 + s2 * 16 + 4 * (g16 >> 1) + qq;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+          const int dcol = dj * 32 + (g16 & 1) * 16 + 4 * pp;
+          s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(&Vs[keyrow * VS_ROW + dcol]));
+          s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(&Vs[(keyrow + 8) * VS_ROW + dcol]));
+          u32x2 a0 = __builtin_bit_cast(u32x2, v0);
+          u32x2 a1 = __builtin_bit_cast(u32x2, v1);
+          u32x4 vf = {a0[0], a0[1], a1[0], a1[1]};
+          o[dj] = T::mfma(vf, pf, o[dj]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, transpose through LDS, coalesced stores ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  u16* Os = smem + wave * (32 * OS_ROW);
+#pragma unroll
+  for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      int d0 = dj * 32 + 8 * rq + 4 * hl;
+      u32x2 w;
+      w[0] = pack2<T>(o[dj][4 * rq + 0] * inv, o[dj][4 * rq + 1] * inv);
+      w[1] = pack2<T>(o[dj][4 * rq + 2] * inv, o[dj][4 * rq + 3] * inv);
+      *reinterpret_cast<u32x2*>(&Os[l31 * OS_ROW + d0]) = w;
+    }
+  __syncthreads();
+  u16* ob = out + (long long)b * o_batch_stride + h * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = lane + 64 * i;
+    int row = c >> 3, ch = (c & 7) * 8;
+    int q = q0 + row;
+    if (q < Tlen) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(&Os[row * OS_ROW + ch]);
+      *reinterpret_cast<u32x4*>(ob + (long long)q * ldo + ch) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// generic small-shape attention: one wave per query row, lanes over head_dim
+// (<= 256 => up to 4 elements per lane), two passes over the keys in fp32.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
+                                                               int Tlen, int hd, int ldqkv, int ldo, int koff,
+                                                               int voff, long long qkv_batch_stride,
+                                                               long long o_batch_stride, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (q >= Tlen) return;
+  const u16* base = qkv + (long long)b * qkv_batch_stride + h * hd;
+  float qv[4], acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int d = lane + 64 * i;
+    qv[i] = (d < hd) ? T::to_f32(base[(long long)q * ldqkv + d]) * scale : 0.f;
+    acc[i] = 0.f;
+  }
+  float m = -1e30f, l = 0.f;
+  for (int key = 0; key < Tlen; ++key) {
+    const u16* kr = base + (long long)key * ldqkv;
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int d = lane + 64 * i;
+      if (d < hd) part += qv[i] * T::to_f32(kr[koff + d]);
+    }
+    float sc = wave_sum(part);
+    float mn = fmaxf(m, sc);
+    float al = expf(m - mn), pv = expf(sc - mn);
+    l = l * al + pv;
+    m = mn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int d = lane + 64 * i;
+      if (d < hd) acc[i] = acc[i] * al + pv * T::to_f32(kr[voff + d]);
+    }
+  }
+  u16* ob = out + (long long)b * o_batch_stride + h * hd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int d = lane + 64 * i;
+    if (d < hd) ob[(long long)q * ldo + d] = T::from_f32(acc[i] / l);
+  }
+}
+
+// qkv: [B, T, ldqkv] 16-bit with q at column h*hd, k at koff + h*hd, v at voff + h*hd.
+extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
+                                 int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
+                                 float scale, int dtype, void* stream) {
+  if (!qkv || !out) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 256) return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 64 && (ldqkv % 8) == 0 && (ldo % 8) == 0 && (koff % 8) == 0 && (voff % 8) == 0 &&
+      (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
+    dim3 grid((T + 127) / 128, H, B), block(256);
+    float sl2 = scale * 1.44269504088896340736f;
+    if (dtype == SFM_DT_F16)
+      hipLaunchKernelGGL((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
+                         koff, voff, qkv_batch_stride, o_batch_stride, sl2);
+    else
+      hipLaunchKernelGGL((attn_fwd_hd64_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
+                         koff, voff, qkv_batch_stride, o_batch_stride, sl2);
+  } else {
+    dim3 grid((T + 3) / 4, H, B), block(256);
+    if (dtype == SFM_DT_F16)
+      hipLaunchKernelGGL((attn_fwd_generic_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd, ldqkv,
+                         ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);
+    else
+      hipLaunchKernelGGL((attn_fwd_generic_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd,
+                         ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);
+  }
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}

@@ -1,0 +1,159 @@
+// framed_gemm_f32: out[b, m, n] = bias[n] + sum_k sig[b, m*hop + k - padl] * Wt[k][n]
+// with exact-fp32 arithmetic on the matrix cores (v_mfma_f32_32x32x2_f32, which is
+// bit-for-bit an fmaf chain; there is no TF32 on gfx950, so this is full fp32).
+// One kernel serves every fp32 "frames x matrix" product on the path:
+//   * SincConv1d FIR filterbank  (hop 1, K 251, zero edges)   agents/perception.py:115-118
+//   * torch.stft as a windowed DFT (hop 80, K 160, reflect)   training/conformer_pipeline.py:196-202
+//   * the irfft x window stage of torch.istft (hop = row stride) conformer_pipeline.py:205-211
+//   * generic row-major fp32 GEMM (hop = lda, padl 0)
+// Tile 128 rows x 64 cols, k-chunks of 32; 4 waves each own 32 rows x 64 cols.
+// A-tile is gathered from the signal with edge handling while staged into LDS
+// (row stride 33 floats: conflict-free ds_read_b32 fragment reads).
+#include "sfm_common.h"
+
+struct FramedParams {
+  const float* sig;
+  const float* Wt;
+  const float* bias;
+  void* out;
+  void* out2;
+  float* gn_partial;
+  long long sig_batch_stride, o_batch_stride, ldm, ldn;
+  int B, M, Ls, hop, padl, K, Kpad, N, Npad, nsplit;
+  int mode, out_f32, gn_group;
+};
+
+#define FBM 128
+#define FBN 64
+#define FKC 32
+#define FAS 33
+
+template <class T>
+__global__ __launch_bounds__(256) void framed_gemm_kernel(FramedParams p) {
+  __shared__ float As[FBM * FAS];
+  __shared__ float Bs[FKC * FBN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * FBN;
+  const int m0 = blockIdx.y * FBM;
+  const int b = blockIdx.z;
+  const float* sg = p.sig + (long long)b * p.sig_batch_stride;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float ra[16], rb[8];
+  const int nkc = p.Kpad / FKC;
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int idx = tid + 256 * i;
+      int row = idx >> 5, kk = idx & 31;
+      int m = m0 + row;
+      int k = kc * FKC + kk;
+      float v = 0.f;
+      if (m < p.M && k < p.K) {
+        long long s = (long long)m * p.hop + k - p.padl;
+        if (p.mode == 1) {
+          if (s < 0) s = -s;
+          if (s >= p.Ls) s = 2LL * (p.Ls - 1) - s;
+          if (s >= 0 && s < p.Ls) v = sg[s];
+        } else {
+          if (s >= 0 && s < p.Ls) v = sg[s];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int idx = tid + 256 * i;
+      int kk = idx >> 6, n = idx & 63;
+      rb[i] = p.Wt[(long long)(kc * FKC + kk) * p.Npad + n0 + n];
+    }
+  };
+
+  load_chunk(0);
+  for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int idx = tid + 256 * i;
+      As[(idx >> 5) * FAS + (idx & 31)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Bs[tid + 256 * i] = rb[i];
+    __syncthreads();
+    if (kc + 1 < nkc) load_chunk(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < FKC / 2; ++ks) {
+      float a = As[(wave * 32 + (lane & 31)) * FAS + 2 * ks + (lane >> 5)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float bv = Bs[(2 * ks + (lane >> 5)) * FBN + j * 32 + (lane & 31)];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + j * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+    float gsum = 0.f, gsq = 0.f;
+    void* dst = p.out;
+    int nn = n;
+    if (p.out2 && n >= p.nsplit) { dst = p.out2; nn = n - p.nsplit; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int m = m0 + wave * 32 + mfma_row(r, lane);
+      if (nok && m < p.M) {
+        float v = acc[j][r] + bv;
+        gsum += v;
+        gsq += v * v;
+        long long off = (long long)b * p.o_batch_stride + (long long)m * p.ldm + (long long)nn * p.ldn;
+        if (p.out_f32) reinterpret_cast<float*>(dst)[off] = v;
+        else reinterpret_cast<u16*>(dst)[off] = T::from_f32(v);
+      }
+    }
+    if (p.gn_partial) {
+      for (int o = 1; o < p.gn_group; o <<= 1) {
+        gsum += __shfl_xor(gsum, o, 64);
+        gsq += __shfl_xor(gsq, o, 64);
+      }
+      gsum += __shfl_xor(gsum, 32, 64);
+      gsq += __shfl_xor(gsq, 32, 64);
+      if (lane < 32 && (lane & (p.gn_group - 1)) == 0 && nok) {
+        int ngroups = p.N / p.gn_group;
+        long long slot = ((long long)b * (gridDim.y * 4) + blockIdx.y * 4 + wave) * ngroups + n / p.gn_group;
+        p.gn_partial[slot * 2 + 0] = gsum;
+        p.gn_partial[slot * 2 + 1] = gsq;
+      }
+    }
+  }
+}
+
+extern "C" int sfm_framed_gemm_f32(const float* sig, const float* Wt, const float* bias, void* out, void* out2,
+                                   float* gn_partial, int B, int M, int Ls, long long sig_batch_stride, int hop,
+                                   int padl, int K, int Kpad, int N, int Npad, int nsplit, long long o_batch_stride,
+                                   long long ldm, long long ldn, int mode, int out_f32, int gn_group, int dtype,
+                                   void* stream) {
+  if (!sig || !Wt || !out) return SFM_ERR_ARG;
+  if (B <= 0 || M <= 0 || N <= 0 || K <= 0) return SFM_ERR_SHAPE;
+  if (Kpad % FKC != 0 || Npad % FBN != 0 || K > Kpad || N > Npad) return SFM_ERR_SHAPE;
+  if (mode == 1 && (padl >= Ls || Ls < 2)) return SFM_ERR_SHAPE;
+  if (gn_partial && (gn_group <= 0 || gn_group > 32 || (32 % gn_group) != 0 || (N % gn_group) != 0)) return SFM_ERR_SHAPE;
+  FramedParams p;
+  p.sig = sig; p.Wt = Wt; p.bias = bias; p.out = out; p.out2 = out2; p.gn_partial = gn_partial;
+  p.sig_batch_stride = sig_batch_stride; p.o_batch_stride = o_batch_stride; p.ldm = ldm; p.ldn = ldn;
+  p.B = B; p.M = M; p.Ls = Ls; p.hop = hop; p.padl = padl; p.K = K; p.Kpad = Kpad; p.N = N; p.Npad = Npad;
+  p.nsplit = nsplit; p.mode = mode; p.out_f32 = out_f32; p.gn_group = gn_group;
+  dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM, B), block(256);
+  if (dtype == SFM_DT_F16) hipLaunchKernelGGL((framed_gemm_kernel<F16>), grid, block, 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((framed_gemm_kernel<BF16>), grid, block, 0, (hipStream_t)stream, p);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}

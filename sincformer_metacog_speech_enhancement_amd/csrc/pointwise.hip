@@ -1,0 +1,637 @@
+// HBM-bound kernels of the path: normalisations, depthwise conv, layout packs,
+// mask epilogue, overlap-add, sinc filter synthesis.  All are coalesced
+// streaming kernels (wave = 64 lanes, shuffles for row statistics, LDS halos).
+#include "sfm_common.h"
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dim (nn.LayerNorm; models/conformer.py:43,68,107,150,
+// agents/msa.py:44,47).  One wave per row, two-pass statistics in registers.
+// Writes a 16-bit copy (GEMM operand) and/or an fp32 copy; optional erf-GELU.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bsh, u16* out16, float* out32,
+                                                        int M, int D, int ldx, int ld16, int ld32, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long long)row * ldx;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int d = lane + 64 * i;
+    v[i] = (d < D) ? xr[d] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int d = lane + 64 * i;
+    float c = (d < D) ? (v[i] - mean) : 0.f;
+    q += c * c;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int d = lane + 64 * i;
+    if (d < D) {
+      float y = (v[i] - mean) * rstd * w[d] + bsh[d];
+      if (act == 1) y = gelu_erf(y);
+      if (out16) out16[(long long)row * ld16 + d] = T::from_f32(y);
+      if (out32) out32[(long long)row * ld32 + d] = y;
+    }
+  }
+}
+
+extern "C" int sfm_layernorm(const float* x, const float* w, const float* b, void* out16, float* out32, int M, int D,
+                             int ldx, int ld16, int ld32, float eps, int act, int dtype, void* stream) {
+  if (!x || !w || !b || (!out16 && !out32)) return SFM_ERR_ARG;
+  if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
+  dim3 grid((M + 3) / 4), block(256);
+  if (dtype == SFM_DT_F16)
+    hipLaunchKernelGGL((layernorm_kernel<F16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M, D,
+                       ldx, ld16, ld32, eps, act);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<BF16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M,
+                       D, ldx, ld16, ld32, eps, act);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm (agents/perception.py:157,169,176,180,196,199,204).  Statistics
+// arrive as per-tile partial (sum, sumsq) written by the producing GEMM's
+// epilogue; gn_finalize reduces them (fp64) into per-(batch, channel)
+// scale/shift; gn_apply normalises (+ optional second branch, + GELU).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ w,
+                                                         const float* __restrict__ bsh, float* scale, float* shift,
+                                                         int P, int G, int C, double count, float eps) {
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int i = lane; i < P; i += 64) {
+    const float* pp = partial + (((long long)b * P + i) * G + g) * 2;
+    s += (double)pp[0];
+    q += (double)pp[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const int cpg = C / G;
+  for (int i = lane; i < cpg; i += 64) {
+    int c = g * cpg + i;
+    float sc = w[c] * rstd;
+    scale[(long long)b * C + c] = sc;
+    shift[(long long)b * C + c] = bsh[c] - (float)mean * sc;
+  }
+}
+
+extern "C" int sfm_gn_finalize(const float* partial, const float* w, const float* b, float* scale, float* shift, int B,
+                               int P, int G, int C, long long rows, float eps, void* stream) {
+  if (!partial || !w || !b || !scale || !shift) return SFM_ERR_ARG;
+  if (B <= 0 || P <= 0 || G <= 0 || C % G != 0) return SFM_ERR_SHAPE;
+  double count = (double)rows * (double)(C / G);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, (hipStream_t)stream, partial, w, b, scale, shift, P,
+                     G, C, count, eps);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+template <class T>
+__device__ __forceinline__ void load8(const void* p, int is_f32, long long idx, float* v) {
+  if (is_f32) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
+    f32x4 a = q[0], c = q[1];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
+  } else {
+    u32x4 a = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(p) + idx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = T::to_f32((u16)(a[i] & 0xffffu));
+      v[2 * i + 1] = T::to_f32((u16)(a[i] >> 16));
+    }
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void store8(void* p, int is_f32, long long idx, const float* v) {
+  if (is_f32) {
+    f32x4* q = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + idx);
+    f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
+    q[0] = a;
+    q[1] = c;
+  } else {
+    u32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p) + idx) = a;
+  }
+}
+
+// y[b,l,c] = act( x1*sc1+sh1 (+ x2*sc2+sh2) ), channels-last, 8 channels per thread
+template <class T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, const float* __restrict__ sc1,
+                                                       const float* __restrict__ sh1, const void* x2,
+                                                       const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                       void* out, long long rows_per_batch, int C, long long total8,
+                                                       int in_f32, int out_f32, int act) {
+  const int cpr = C >> 3;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
+    long long row = e / cpr;
+    int c0 = (int)(e - row * cpr) * 8;
+    long long b = row / rows_per_batch;
+    float v[8], u[8];
+    load8<T>(x1, in_f32, e * 8, v);
+    const float* s1 = sc1 + b * C + c0;
+    const float* h1 = sh1 + b * C + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * s1[i] + h1[i];
+    if (x2) {
+      load8<T>(x2, in_f32, e * 8, u);
+      const float* s2 = sc2 + b * C + c0;
+      const float* h2 = sh2 + b * C + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += u[i] * s2[i] + h2[i];
+    }
+    if (act == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+    }
+    store8<T>(out, out_f32, e * 8, v);
+  }
+}
+
+extern "C" int sfm_gn_apply(const void* x1, const float* sc1, const float* sh1, const void* x2, const float* sc2,
+                            const float* sh2, void* out, int B, long long rows_per_batch, int C, int in_f32, int out_f32,
+                            int act, int dtype, void* stream) {
+  if (!x1 || !sc1 || !sh1 || !out) return SFM_ERR_ARG;
+  if (C % 8 != 0 || B <= 0 || rows_per_batch <= 0) return SFM_ERR_SHAPE;
+  long long total8 = (long long)B * rows_per_batch * (C / 8);
+  long long nb = (total8 + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (dtype == SFM_DT_F16)
+    hipLaunchKernelGGL((gn_apply_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x1, sc1, sh1, x2,
+                       sc2, sh2, out, rows_per_batch, C, total8, in_f32, out_f32, act);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x1, sc1, sh1,
+                       x2, sc2, sh2, out, rows_per_batch, C, total8, in_f32, out_f32, act);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Depthwise Conv1d(k, pad (k-1)/2, groups=C) + BatchNorm1d(eval) + Swish on a
+// channels-last [B, T, C] 16-bit tensor (models/conformer.py:117-119).
+// Tile = 64 frames (+ k-1 halo) x C channels in LDS; each work item computes
+// 4 consecutive frames of one channel pair with a sliding weight window.
+// ---------------------------------------------------------------------------
+#define DW_TT 64
+template <class T>
+__global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(const u16* __restrict__ x, const float* __restrict__ wdw,
+                                                              const float* __restrict__ bdw, const float* __restrict__ bnw,
+                                                              const float* __restrict__ bnb, const float* __restrict__ bnm,
+                                                              const float* __restrict__ bnv, u16* __restrict__ out,
+                                                              int Tlen, int C, int KS, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int halo = KS - 1, padl = (KS - 1) / 2;
+  const int rows = DW_TT + halo;
+  u16* xs = reinterpret_cast<u16*>(dsm);                                 // [rows][C]
+  float* ws = reinterpret_cast<float*>(dsm + (((size_t)rows * C * 2 + 15) & ~(size_t)15));  // [KS][C]
+  float* scs = ws + (size_t)KS * C;                                      // [C] scale
+  float* shs = scs + C;                                                  // [C] shift (conv bias folded)
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * DW_TT;
+  const int b = blockIdx.y;
+  const u16* xb = x + (long long)b * Tlen * C;
+  const int cpr = C >> 3;
+  for (int e = tid; e < rows * cpr; e += 256) {
+    int r = e / cpr, c8 = (e - r * cpr) * 8;
+    int t = t0 - padl + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t >= 0 && t < Tlen) v = *reinterpret_cast<const u32x4*>(xb + (long long)t * C + c8);
+    *reinterpret_cast<u32x4*>(&xs[r * C + c8]) = v;
+  }
+  for (int e = tid; e < KS * C; e += 256) {
+    int k = e / C, c = e - k * C;
+    ws[e] = wdw[c * KS + k];
+  }
+  for (int c = tid; c < C; c += 256) {
+    float sc = bnw[c] * rsqrtf(bnv[c] + eps);
+    scs[c] = sc;
+    shs[c] = bnb[c] - bnm[c] * sc + bdw[c] * sc;
+  }
+  __syncthreads();
+  const int npair = C >> 1;
+  const int items = (DW_TT / 4) * npair;
+  u16* ob = out + (long long)b * Tlen * C;
+  for (int it = tid; it < items; it += 256) {
+    int pair = it % npair, tq = it / npair;
+    int c = pair * 2, tl = tq * 4;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KS + 3; ++k) {
+      // shift the weight window: w[o] = W[k - o]
+      w0[3] = w0[2]; w0[2] = w0[1]; w0[1] = w0[0];
+      w1[3] = w1[2]; w1[2] = w1[1]; w1[1] = w1[0];
+      if (k < KS) {
+        w0[0] = ws[k * C + c];
+        w1[0] = ws[k * C + c + 1];
+      } else {
+        w0[0] = 0.f;
+        w1[0] = 0.f;
+      }
+      uint32_t pk = *reinterpret_cast<const uint32_t*>(&xs[(tl + k) * C + c]);
+      float x0 = T::to_f32((u16)(pk & 0xffffu)), x1 = T::to_f32((u16)(pk >> 16));
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        a0[o] += w0[o] * x0;
+        a1[o] += w1[o] * x1;
+      }
+    }
+    float s0 = scs[c], s1 = scs[c + 1], h0 = shs[c], h1 = shs[c + 1];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      int t = t0 + tl + o;
+      if (t < Tlen) {
+        float y0 = swish_f(a0[o] * s0 + h0), y1 = swish_f(a1[o] * s1 + h1);
+        *reinterpret_cast<uint32_t*>(&ob[(long long)t * C + c]) = pack2<T>(y0, y1);
+      }
+    }
+  }
+}
+
+extern "C" int sfm_dwconv_bn_swish(const void* x, const float* wdw, const float* bdw, const float* bnw,
+                                   const float* bnb, const float* bnm, const float* bnv, void* out, int B, int T,
+                                   int C, int KS, float eps, int dtype, void* stream) {
+  if (!x || !wdw || !bdw || !bnw || !bnb || !bnm || !bnv || !out) return SFM_ERR_ARG;
+  if (C % 8 != 0 || KS < 1 || (KS & 1) == 0 || B <= 0 || T <= 0) return SFM_ERR_SHAPE;
+  size_t rows = DW_TT + KS - 1;
+  size_t lds = ((rows * C * 2 + 15) & ~(size_t)15) + ((size_t)KS * C + 2 * (size_t)C) * 4;
+  if (lds > 160 * 1024) return SFM_ERR_SHAPE;
+  dim3 grid((T + DW_TT - 1) / DW_TT, B), block(256);
+  hipError_t e;
+  if (dtype == SFM_DT_F16) {
+    e = hipFuncSetAttribute((const void*)dwconv_bn_swish_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return SFM_ERR_LAUNCH;
+    hipLaunchKernelGGL((dwconv_bn_swish_kernel<F16>), grid, block, lds, (hipStream_t)stream, (const u16*)x, wdw, bdw,
+                       bnw, bnb, bnm, bnv, (u16*)out, T, C, KS, eps);
+  } else {
+    e = hipFuncSetAttribute((const void*)dwconv_bn_swish_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return SFM_ERR_LAUNCH;
+    hipLaunchKernelGGL((dwconv_bn_swish_kernel<BF16>), grid, block, lds, (hipStream_t)stream, (const u16*)x, wdw, bdw,
+                       bnw, bnb, bnm, bnv, (u16*)out, T, C, KS, eps);
+  }
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Layout / packing kernels
+// ---------------------------------------------------------------------------
+// fp32 [M, C] (row stride lds_) -> 16-bit [M, ldd] at column offset; cols [C, Cz) zero-filled
+template <class T>
+__global__ __launch_bounds__(256) void convert_rows_kernel(const float* __restrict__ src, u16* __restrict__ dst,
+                                                           long long M, int C, int Cz, long long lds_, long long ldd) {
+  long long total = M * Cz;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long m = e / Cz;
+    int c = (int)(e - m * Cz);
+    float v = (c < C) ? src[m * lds_ + c] : 0.f;
+    dst[m * ldd + c] = T::from_f32(v);
+  }
+}
+
+extern "C" int sfm_convert_rows(const float* src, void* dst, long long M, int C, int Cz, long long ld_src,
+                                long long ld_dst, int dtype, void* stream) {
+  if (!src || !dst) return SFM_ERR_ARG;
+  if (M <= 0 || C <= 0 || Cz < C) return SFM_ERR_SHAPE;
+  long long nb = (M * Cz + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (dtype == SFM_DT_F16)
+    hipLaunchKernelGGL((convert_rows_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src,
+                       (u16*)dst, M, C, Cz, ld_src, ld_dst);
+  else
+    hipLaunchKernelGGL((convert_rows_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src,
+                       (u16*)dst, M, C, Cz, ld_src, ld_dst);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// transpose [B, R, Ccols] <-> [B, Ccols, R] through a 32x33 LDS tile.
+// src element (b, r, c) at src[b*sb + r*sr + c]; dst element at dst[b*db + c*dc + r].
+// src fp32 or 16-bit; dst fp32 or 16-bit.
+template <class T>
+__global__ __launch_bounds__(256) void transpose_kernel(const void* src, void* dst, int R, int Cc, long long sb,
+                                                        long long sr, long long db, long long dc, int src_f32,
+                                                        int dst_f32) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < Cc) {
+      long long idx = (long long)b * sb + (long long)r * sr + c;
+      v = src_f32 ? reinterpret_cast<const float*>(src)[idx] : T::to_f32(reinterpret_cast<const u16*>(src)[idx]);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < R && c < Cc) {
+      long long idx = (long long)b * db + (long long)c * dc + r;
+      float v = tile[tx][i];
+      if (dst_f32) reinterpret_cast<float*>(dst)[idx] = v;
+      else reinterpret_cast<u16*>(dst)[idx] = T::from_f32(v);
+    }
+  }
+}
+
+extern "C" int sfm_transpose(const void* src, void* dst, int B, int R, int C, long long src_batch, long long src_row,
+                             long long dst_batch, long long dst_row, int src_f32, int dst_f32, int dtype, void* stream) {
+  if (!src || !dst) return SFM_ERR_ARG;
+  if (B <= 0 || R <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  dim3 grid((C + 31) / 32, (R + 31) / 32, B), block(256);
+  if (dtype == SFM_DT_F16)
+    hipLaunchKernelGGL((transpose_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, dst, R, C, src_batch, src_row,
+                       dst_batch, dst_row, src_f32, dst_f32);
+  else
+    hipLaunchKernelGGL((transpose_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, dst, R, C, src_batch,
+                       src_row, dst_batch, dst_row, src_f32, dst_f32);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// adaptive average pool along time (glue G1): src fp32 [B, Tin, ld_src] cols [0,C)
+// -> dst 16-bit [B, Tout, ld_dst] cols [0, C).  window i = [floor(i*Tin/Tout), ceil((i+1)*Tin/Tout))
+template <class T>
+__global__ __launch_bounds__(256) void pool_time_kernel(const float* __restrict__ src, u16* dst16, float* dst32,
+                                                        int Tin, int Tout, int C, long long ld_src, long long ld_dst) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  long long s = ((long long)i * Tin) / Tout;
+  long long e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
+  float acc = 0.f;
+  for (long long t = s; t < e; ++t) acc += src[((long long)b * Tin + t) * ld_src + c];
+  acc /= (float)(e - s);
+  long long o = ((long long)b * Tout + i) * ld_dst + c;
+  if (dst16) dst16[o] = T::from_f32(acc);
+  if (dst32) dst32[o] = acc;
+}
+
+extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, int Tout, int C,
+                             long long ld_src, long long ld_dst, int dtype, void* stream) {
+  if (!src || (!dst16 && !dst32)) return SFM_ERR_ARG;
+  if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  dim3 grid((C + 255) / 256, Tout, B), block(256);
+  if (dtype == SFM_DT_F16)
+    hipLaunchKernelGGL((pool_time_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin, Tout,
+                       C, ld_src, ld_dst);
+  else
+    hipLaunchKernelGGL((pool_time_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin,
+                       Tout, C, ld_src, ld_dst);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// log1p-magnitude normalisation of the noisy STFT (agents/msa.py:134-137) written as
+// 16-bit into the fusion operand: cols [0,F) real, [F,2F) imag, [2F, 2F+zpad) zero.
+template <class T>
+__global__ __launch_bounds__(256) void stft_lognorm_pack_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                                u16* __restrict__ dst, long long M, int F, int zpad,
+                                                                long long ld_dst) {
+  const int W = 2 * F + zpad;
+  long long total = M * W;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long m = e / W;
+    int c = (int)(e - m * W);
+    float v = 0.f;
+    if (c < 2 * F) {
+      int f = (c < F) ? c : c - F;
+      float r = re[m * F + f], i = im[m * F + f];
+      float mag = sqrtf(r * r + i * i + 1e-8f);
+      float nf = log1pf(mag) / mag;
+      v = ((c < F) ? r : i) * nf;
+    }
+    dst[m * ld_dst + c] = T::from_f32(v);
+  }
+}
+
+extern "C" int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst, long long M, int F, int zpad,
+                                     long long ld_dst, int dtype, void* stream) {
+  if (!re || !im || !dst) return SFM_ERR_ARG;
+  if (M <= 0 || F <= 0 || zpad < 0) return SFM_ERR_SHAPE;
+  long long nb = (M * (2 * F + zpad) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (dtype == SFM_DT_F16)
+    hipLaunchKernelGGL((stft_lognorm_pack_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
+                       (u16*)dst, M, F, zpad, ld_dst);
+  else
+    hipLaunchKernelGGL((stft_lognorm_pack_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
+                       (u16*)dst, M, F, zpad, ld_dst);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Bounded polar mask + complex application (agents/msa.py:166-172,
+// models/conformer.py:243-244, training/conformer_pipeline.py:287-296).
+//   mag = sigmoid(lm (+ bias[b])) ; ph = tanh(lp) * phase_scale
+//   mask = mag * (cos ph, sin ph) ; enh = mask (x) noisy   (optional)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void polar_mask_kernel(const float* __restrict__ lm, const float* __restrict__ lp,
+                                                         const float* __restrict__ mag_bias, const float* __restrict__ nr,
+                                                         const float* __restrict__ ni, float* mr, float* mi, float* er,
+                                                         float* ei, float* mmag, long long rows_per_batch, int F,
+                                                         long long total, float phase_scale, long long ld_l,
+                                                         long long ld_enh) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long m = e / F;
+    int f = (int)(e - m * F);
+    float a = lm[m * ld_l + f];
+    if (mag_bias) a += mag_bias[(m / rows_per_batch) * F + f];
+    float mg = 1.0f / (1.0f + expf(-a));
+    float ph = tanhf(lp[m * ld_l + f]) * phase_scale;
+    float c = cosf(ph), s = sinf(ph);
+    float xr = mg * c, xi = mg * s;
+    if (mr) mr[e] = xr;
+    if (mi) mi[e] = xi;
+    if (mmag) mmag[e] = mg;
+    if (er) {
+      float r = nr[e], i = ni[e];
+      er[m * ld_enh + f] = xr * r - xi * i;
+      ei[m * ld_enh + f] = xr * i + xi * r;
+    }
+  }
+}
+
+extern "C" int sfm_polar_mask(const float* lm, const float* lp, const float* mag_bias, const float* nr, const float* ni,
+                              float* mr, float* mi, float* er, float* ei, float* mmag, int B, long long rows_per_batch,
+                              int F, float phase_scale, long long ld_logits, long long ld_enh, void* stream) {
+  if (!lm || !lp) return SFM_ERR_ARG;
+  if (er && (!ei || !nr || !ni)) return SFM_ERR_ARG;
+  long long total = (long long)B * rows_per_batch * F;
+  if (total <= 0) return SFM_ERR_SHAPE;
+  long long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(polar_mask_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lm, lp, mag_bias, nr, ni,
+                     mr, mi, er, ei, mmag, rows_per_batch, F, total, phase_scale, ld_logits, ld_enh);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// complex multiply (ComplexConformer.apply_mask, models/conformer.py:243-244)
+__global__ __launch_bounds__(256) void complex_mul_kernel(const float* __restrict__ sr, const float* __restrict__ si,
+                                                          const float* __restrict__ mr, const float* __restrict__ mi,
+                                                          float* er, float* ei, long long total) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    float a = sr[e], b = si[e], c = mr[e], d = mi[e];
+    er[e] = c * a - d * b;
+    ei[e] = c * b + d * a;
+  }
+}
+
+extern "C" int sfm_complex_mul(const float* sr, const float* si, const float* mr, const float* mi, float* er, float* ei,
+                               long long total, void* stream) {
+  if (!sr || !si || !mr || !mi || !er || !ei) return SFM_ERR_ARG;
+  if (total <= 0) return SFM_ERR_SHAPE;
+  long long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(complex_mul_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sr, si, mr, mi, er, ei,
+                     total);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// iSTFT overlap-add (gather form, no atomics) of windowed irfft frames
+// frames [B, T, win] (already x window, restricted to the window support):
+//   out[b, s] = sum_t frames[b, t, p - t*hop - woff] / sum_t w^2[p - t*hop - woff],
+//   p = s + n_fft/2, woff = (n_fft - win)/2   (torch.istft, center=True)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win2,
+                                                        float* __restrict__ out, int Tn, int L, int n_fft, int hop,
+                                                        int win, long long ld_frames) {
+  const int b = blockIdx.y;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= L) return;
+  const int p = s + n_fft / 2 - (n_fft - win) / 2;     // position relative to window support start
+  int t = p / hop;
+  if (t > Tn - 1) t = Tn - 1;
+  float acc = 0.f, env = 0.f;
+  for (; t >= 0; --t) {
+    int n = p - t * hop;
+    if (n >= win) break;
+    if (n >= 0) {
+      acc += frames[((long long)b * Tn + t) * ld_frames + n];
+      env += win2[n];
+    }
+  }
+  out[(long long)b * L + s] = (env > 1e-11f) ? acc / env : 0.f;
+}
+
+extern "C" int sfm_istft_ola(const float* frames, const float* win2, float* out, int B, int T, int L, int n_fft, int hop,
+                             int win, long long ld_frames, void* stream) {
+  if (!frames || !win2 || !out) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || L <= 0 || hop <= 0 || win <= 0 || win > n_fft) return SFM_ERR_SHAPE;
+  hipLaunchKernelGGL(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, frames, win2, out,
+                     T, L, n_fft, hop, win, ld_frames);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// pack [real | imag] fp32 rows into one [M, ld] fp32 operand (zero tail) for the irfft GEMM
+__global__ __launch_bounds__(256) void pack_spec_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                        float* __restrict__ dst, long long M, int F, int ld,
+                                                        long long ld_src) {
+  long long total = M * ld;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long m = e / ld;
+    int c = (int)(e - m * ld);
+    float v = 0.f;
+    if (c < F) v = re[m * ld_src + c];
+    else if (c < 2 * F) v = im[m * ld_src + c - F];
+    dst[e] = v;
+  }
+}
+
+extern "C" int sfm_pack_spec(const float* re, const float* im, float* dst, long long M, int F, int ld, long long ld_src,
+                             void* stream) {
+  if (!re || !im || !dst) return SFM_ERR_ARG;
+  if (M <= 0 || F <= 0 || ld < 2 * F) return SFM_ERR_SHAPE;
+  long long nb = (M * ld + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(pack_spec_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im, dst, M, F, ld,
+                     ld_src);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// SincConv1d filter synthesis (agents/perception.py:88-112), one block per
+// channel.  Writes filt[c][k] (row-major, for inspection) and Wt[k][c] (k-major,
+// zero padded to [Kpad][Npad]: the framed-GEMM operand).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sinc_filters_kernel(const float* __restrict__ low_hz, const float* __restrict__ band_hz,
+                                                           const float* __restrict__ window, const float* __restrict__ n_,
+                                                           float* filt, float* Wt, int C, int K, int Npad,
+                                                           float sample_rate, float min_low, float min_band) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int half = (K - 1) / 2;
+  float low = min_low + fabsf(low_hz[c]);
+  float high = fminf(low + min_band + fabsf(band_hz[c]), sample_rate / 2.0f);
+  float fl = low / sample_rate, fh = high / sample_rate;
+  float total = 0.f;
+  float vals[2] = {0.f, 0.f};
+  for (int i = 0; i < 2; ++i) {
+    int k = tid + 256 * i;
+    float v = 0.f;
+    if (k < K) {
+      if (k == half) v = 2.0f * (fh - fl);
+      else {
+        int kk = (k < half) ? k : (K - 1 - k);
+        float n = n_[kk];
+        v = (sinf(fh * n) - sinf(fl * n)) / (n / 2.0f + 1e-8f);
+      }
+      v *= window[k];
+    }
+    vals[i] = v;
+    total += fabsf(v);
+  }
+  total = wave_sum(total);
+  if ((tid & 63) == 0) red[tid >> 6] = total;
+  __syncthreads();
+  float norm = red[0] + red[1] + red[2] + red[3] + 1e-8f;
+  for (int i = 0; i < 2; ++i) {
+    int k = tid + 256 * i;
+    if (k < K) {
+      float v = vals[i] / norm;
+      if (filt) filt[(long long)c * K + k] = v;
+      if (Wt) Wt[(long long)k * Npad + c] = v;
+    }
+  }
+}
+
+extern "C" int sfm_sinc_filters(const float* low_hz, const float* band_hz, const float* window, const float* n_,
+                                float* filt, float* Wt, int C, int K, int Npad, float sample_rate, float min_low_hz,
+                                float min_band_hz, void* stream) {
+  if (!low_hz || !band_hz || !window || !n_ || (!filt && !Wt)) return SFM_ERR_ARG;
+  if (C <= 0 || K <= 0 || K > 512 || (K & 1) == 0 || (Wt && Npad < C)) return SFM_ERR_SHAPE;
+  hipLaunchKernelGGL(sinc_filters_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, low_hz, band_hz, window, n_, filt,
+                     Wt, C, K, Npad, sample_rate, min_low_hz, min_band_hz);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}

@@ -1,0 +1,85 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// wave = 64 lanes everywhere; MFMA fragment maps follow the CDNA4 ISA:
+//   v_mfma_f32_32x32x16_{bf16,f16}: A lane l -> row l&31, k = 8*(l>>5)+j (j<8)
+//                                   B lane l -> col l&31, k = 8*(l>>5)+j
+//   C/D (16 regs): col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+//   v_mfma_f32_32x32x2_f32: A lane l -> A[l&31][l>>5], B lane l -> B[l>>5][l&31]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SFM_OK 0
+#define SFM_ERR_ARG -1
+#define SFM_ERR_SHAPE -2
+#define SFM_ERR_LAUNCH -3
+
+#define SFM_DT_BF16 0
+#define SFM_DT_F16 1
+
+typedef uint16_t u16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // 8 x 16-bit packed
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct BF16 {
+  static constexpr int id = SFM_DT_BF16;
+  static __device__ __forceinline__ u16 from_f32(float f) {
+    __bf16 h = (__bf16)f;                         // v_cvt_pk_bf16_f32, RNE, NaN-preserving
+    return __builtin_bit_cast(u16, h);
+  }
+  static __device__ __forceinline__ float to_f32(u16 b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+struct F16 {
+  static constexpr int id = SFM_DT_F16;
+  static __device__ __forceinline__ u16 from_f32(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(u16, h);
+  }
+  static __device__ __forceinline__ float to_f32(u16 b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <class T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+}
+
+// row of C/D register r for lane l (32x32 tiles)
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish_f(float x) { return x * sigmoid_f(x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define SFM_CHECK_LAUNCH()                                 \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return SFM_ERR_LAUNCH;          \
+  } while (0)

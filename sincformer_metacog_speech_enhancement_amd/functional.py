@@ -1,0 +1,468 @@
+"""Forward compositions of the HIP kernels for every module on the path.
+
+Internal layouts (DESIGN.md "Data layout in HBM"):
+  * time-major / channels-last everywhere: [B, T, C] (never [B, C, T]),
+  * fp32 residual stream, 16-bit (bf16|f16) GEMM operands and wide activations,
+  * weights packed once per (parameter version, dtype) into MFMA-friendly
+    [Npad, Kpad] 16-bit tiles (`pack_*`), cached by the nn.Module mirrors.
+All functions take/return device tensors and only enqueue kernels on the
+current stream; there is no CPU code path.
+"""
+import math
+import torch
+
+from . import ops
+
+N_FFT, HOP, WIN = 256, 80, 160
+N_FREQ = N_FFT // 2 + 1
+FUSE_LD = 1056           # 2*256 + 4*64 + 2*129 = 1026 -> padded to 33*32
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def sub(sd, prefix):
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+
+
+def add_to16(x32, y32, C):
+    """(x + y) -> 16-bit, via the two-branch scale/shift kernel with unit scales."""
+    M = x32.numel() // C
+    dev = x32.device
+    one = _const(dev, C, 1.0)
+    zero = _const(dev, C, 0.0)
+    out = torch.empty(M, C, device=dev, dtype=ops.compute_dtype())
+    ops.gn_apply(x32, one, zero, out, 1, M, C, act=0, x2=y32, sc2=one, sh2=zero)
+    return out
+
+
+_const_cache = {}
+
+
+def _const(dev, C, val):
+    key = (str(dev), C, val)
+    t = _const_cache.get(key)
+    if t is None:
+        t = torch.full((1, C), val, device=dev, dtype=torch.float32)
+        _const_cache[key] = t
+    return t
+
+
+# ---------------------------------------------------------------------------
+# STFT / iSTFT  (training/conformer_pipeline.py:196-211)
+# ---------------------------------------------------------------------------
+_stft_cache = {}
+
+
+def _stft_consts(n_fft, win, dev):
+    key = (n_fft, win, str(dev))
+    c = _stft_cache.get(key)
+    if c is None:
+        wi, win2 = ops.istft_matrix(n_fft, win, dev)
+        c = {"fwd": ops.stft_matrix(n_fft, win, dev), "inv": wi, "win2": win2}
+        _stft_cache[key] = c
+    return c
+
+
+def stft(wave, n_fft=N_FFT, hop=HOP, win=WIN):
+    """wave [B, L] fp32 -> real, imag [B, T, n_fft/2+1] fp32 (contiguous), T = 1 + L//hop."""
+    wave = wave.contiguous()
+    B, L = wave.shape
+    if L <= n_fft // 2:
+        raise RuntimeError("stft: signal shorter than the reflect padding (L=%d)" % L)
+    T = 1 + L // hop
+    F = n_fft // 2 + 1
+    c = _stft_consts(n_fft, win, wave.device)
+    re = torch.empty(B, T, F, device=wave.device, dtype=torch.float32)
+    im = torch.empty(B, T, F, device=wave.device, dtype=torch.float32)
+    # frame t covers xpad[t*hop + woff + k], k in [0, win): sample index t*hop + k - win/2  (reflected)
+    ops.framed_gemm(wave, c["fwd"], re, B=B, M=T, Ls=L, sig_batch_stride=L, hop=hop, padl=n_fft // 2 - (n_fft - win) // 2,
+                    K=win, N=2 * F, o_batch_stride=T * F, ldm=F, ldn=1, mode=1, out2=im, nsplit=F)
+    return re, im
+
+
+def istft_from_packed(spec, B, T, length, n_fft=N_FFT, hop=HOP, win=WIN):
+    """spec [B*T, ld>=2F] fp32 rows (real | imag | zero pad) -> waveform [B, length]."""
+    F = n_fft // 2 + 1
+    c = _stft_consts(n_fft, win, spec.device)
+    ld = spec.stride(0)
+    M = B * T
+    frames = torch.empty(M, win, device=spec.device, dtype=torch.float32)
+    ops.framed_gemm(spec, c["inv"], frames, B=1, M=M, Ls=M * ld, sig_batch_stride=0, hop=ld, padl=0, K=2 * F, N=win,
+                    o_batch_stride=0, ldm=win, ldn=1, mode=0)
+    out = torch.empty(B, length, device=spec.device, dtype=torch.float32)
+    ops.istft_ola(frames, c["win2"], out, B, T, length, n_fft, hop, win, win)
+    return out
+
+
+def istft(real, imag, length, n_fft=N_FFT, hop=HOP, win=WIN):
+    real, imag = real.contiguous(), imag.contiguous()
+    B, T, F = real.shape
+    ld = ops.round_up(2 * F, 8)
+    spec = torch.empty(B * T, ld, device=real.device, dtype=torch.float32)
+    ops.pack_spec(real, imag, spec, B * T, F, ld, F)
+    return istft_from_packed(spec, B, T, length, n_fft, hop, win)
+
+
+# ---------------------------------------------------------------------------
+# Conformer (models/conformer.py)
+# ---------------------------------------------------------------------------
+def pack_ffn(sd):
+    return {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
+            "w1": ops.pack_linear(sd["linear1.weight"], sd["linear1.bias"]),
+            "w2": ops.pack_linear(sd["linear2.weight"], sd["linear2.bias"])}
+
+
+def pack_mhsa(sd):
+    return {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
+            "win": ops.pack_linear(sd["attention.in_proj_weight"], sd["attention.in_proj_bias"]),
+            "wout": ops.pack_linear(sd["attention.out_proj.weight"], sd["attention.out_proj.bias"])}
+
+
+def pack_convmod(sd):
+    D = sd["pointwise2.weight"].shape[0]
+    return {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
+            "pw1": ops.pack_linear(sd["pointwise1.weight"].reshape(2 * D, D), sd["pointwise1.bias"], glu=True),
+            "dw_w": _f32(sd["depthwise.weight"].reshape(D, -1)), "dw_b": _f32(sd["depthwise.bias"]),
+            "bn_w": _f32(sd["batch_norm.weight"]), "bn_b": _f32(sd["batch_norm.bias"]),
+            "bn_m": _f32(sd["batch_norm.running_mean"]), "bn_v": _f32(sd["batch_norm.running_var"]),
+            "pw2": ops.pack_linear(sd["pointwise2.weight"].reshape(D, D), sd["pointwise2.bias"])}
+
+
+def pack_block(sd):
+    return {"ff1": pack_ffn(sub(sd, "ff1")), "mhsa": pack_mhsa(sub(sd, "mhsa")), "conv": pack_convmod(sub(sd, "conv")),
+            "ff2": pack_ffn(sub(sd, "ff2")), "fn_w": _f32(sd["final_norm.weight"]), "fn_b": _f32(sd["final_norm.bias"])}
+
+
+def _ln16(x32, w, b, act=0):
+    out = torch.empty(x32.shape, device=x32.device, dtype=ops.compute_dtype())
+    ops.layernorm(x32, w, b, out16=out, act=act)
+    return out
+
+
+def ffn_forward(x32, pk):
+    """FeedForwardModule.forward (eval): x + 0.5 * W2 swish(W1 LN(x))   [M, D] fp32 -> fp32"""
+    h = _ln16(x32, pk["ln_w"], pk["ln_b"])
+    u = ops.linear16(h, pk["w1"], epi=ops.EPI_SWISH)
+    return ops.linear16(u, pk["w2"], epi=ops.EPI_RESID, resid=x32, alpha=0.5)
+
+
+def mhsa_forward(x32, pk, B, T, H):
+    D = x32.shape[1]
+    h = _ln16(x32, pk["ln_w"], pk["ln_b"])
+    qkv = ops.linear16(h, pk["win"])
+    o = ops.attention(qkv, B, T, H, D // H)
+    return ops.linear16(o, pk["wout"], epi=ops.EPI_RESID, resid=x32, alpha=1.0)
+
+
+def convmod_forward(x32, pk, B, T):
+    D = x32.shape[1]
+    h = _ln16(x32, pk["ln_w"], pk["ln_b"])
+    g = ops.linear16(h, pk["pw1"], epi=ops.EPI_GLU)
+    d = ops.dwconv_bn_swish(g, pk["dw_w"], pk["dw_b"], pk["bn_w"], pk["bn_b"], pk["bn_m"], pk["bn_v"], B, T, D)
+    return ops.linear16(d, pk["pw2"], epi=ops.EPI_RESID, resid=x32, alpha=1.0)
+
+
+def block_forward(x32, pk, B, T, H, want16=False):
+    """ConformerBlock.forward (eval) on the flattened [B*T, D] fp32 stream."""
+    x = ffn_forward(x32, pk["ff1"])
+    x = mhsa_forward(x, pk["mhsa"], B, T, H)
+    x = convmod_forward(x, pk["conv"], B, T)
+    x = ffn_forward(x, pk["ff2"])
+    out = torch.empty_like(x)
+    out16 = torch.empty(x.shape, device=x.device, dtype=ops.compute_dtype()) if want16 else None
+    ops.layernorm(x, pk["fn_w"], pk["fn_b"], out16=out16, out32=out)
+    return (out, out16) if want16 else out
+
+
+def pack_complex_conformer(sd, num_blocks):
+    nf2 = sd["input_proj.weight"].shape[1]
+    return {"in": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"],
+                                  k_pad_to=ops.round_up(nf2, 32)),
+            "out": ops.pack_linear(sd["output_proj.weight"], sd["output_proj.bias"]),
+            "blocks": [pack_block(sub(sd, "blocks.%d" % i)) for i in range(num_blocks)], "nf2": nf2}
+
+
+def complex_conformer_core(x16, pk, B, T, H, out_dtype=torch.float32):
+    """x16: [M, ld>=round32(2*n_freq)] 16-bit operand of input_proj -> output_proj result [M, 2*n_freq]."""
+    x = ops.linear16(x16, pk["in"], out_dtype=torch.float32)
+    skip = x
+    for bp in pk["blocks"]:
+        x = block_forward(x, bp, B, T, H)
+    y16 = add_to16(x, skip, x.shape[1])
+    return ops.linear16(y16, pk["out"], out_dtype=out_dtype)
+
+
+def complex_conformer_forward(stft_real, stft_imag, pk, H):
+    """ComplexConformer.forward: ([B,T,nf], [B,T,nf]) fp32 -> (mask_real, mask_imag) fp32 views."""
+    B, T, nf = stft_real.shape
+    M = B * T
+    sr, si = stft_real.contiguous(), stft_imag.contiguous()
+    ld = pk["in"].Kpad
+    x16 = torch.empty(M, ld, device=sr.device, dtype=ops.compute_dtype())
+    ops.convert_rows(sr, x16, M, nf, nf, nf, ld)
+    ops.convert_rows(si, x16[:, nf:], M, nf, ld - nf, nf, ld)
+    y = complex_conformer_core(x16, pk, B, T, H).reshape(B, T, 2 * nf)
+    return y[..., :nf], y[..., nf:]
+
+
+# ---------------------------------------------------------------------------
+# PerceptionAgent (agents/perception.py:216-251)
+# ---------------------------------------------------------------------------
+def pack_perception(sd, sample_rate):
+    pk = {"fs": float(sample_rate)}
+    for k in ("low_hz_", "band_hz_", "window", "n_"):
+        pk[k] = _f32(sd["sinc_conv." + k]).reshape(-1)
+    pk["K"] = pk["window"].numel()
+    pk["C0"] = pk["low_hz_"].numel()
+    pk["sn_w"], pk["sn_b"] = _f32(sd["sinc_norm.weight"]), _f32(sd["sinc_norm.bias"])
+    pk["blocks"] = []
+    for i in range(3):
+        s = sub(sd, "conv_blocks.%d" % i)
+        cout = s["main.0.weight"].shape[0]
+        pk["blocks"].append({
+            "c1": ops.pack_linear(s["main.0.weight"], s["main.0.bias"]), "g1w": _f32(s["main.1.weight"]), "g1b": _f32(s["main.1.bias"]),
+            "c2": ops.pack_linear(s["main.3.weight"], s["main.3.bias"]), "g2w": _f32(s["main.4.weight"]), "g2b": _f32(s["main.4.bias"]),
+            "cs": ops.pack_linear(s["skip.0.weight"], s["skip.0.bias"]), "gsw": _f32(s["skip.1.weight"]), "gsb": _f32(s["skip.1.bias"]),
+            "cout": cout, "groups": min(16, cout)})
+    pk["down"] = ops.pack_linear(sd["downsample.0.weight"], sd["downsample.0.bias"])
+    pk["dn_w"], pk["dn_b"] = _f32(sd["downsample.1.weight"]), _f32(sd["downsample.1.bias"])
+    D = sd["real_proj.0.weight"].shape[0]
+    pk["D"] = D
+    wz = torch.cat([sd["real_proj.0.weight"], sd["imag_proj.0.weight"]], dim=0)
+    bz = torch.cat([sd["real_proj.0.bias"], sd["imag_proj.0.bias"]], dim=0)
+    pk["zproj"] = ops.pack_linear(wz, bz)
+    pk["z_w"] = torch.cat([_f32(sd["real_proj.1.weight"]), _f32(sd["imag_proj.1.weight"])])
+    pk["z_b"] = torch.cat([_f32(sd["real_proj.1.bias"]), _f32(sd["imag_proj.1.bias"])])
+    pk["u0"] = ops.pack_linear(sd["uncertainty_head.0.weight"], sd["uncertainty_head.0.bias"])
+    pk["u2"] = ops.pack_linear(sd["uncertainty_head.2.weight"], sd["uncertainty_head.2.bias"])
+    return pk
+
+
+def _conv_gn(x16, pw, B, Lin, stride, pad, groups, raw_dtype):
+    """conv (implicit GEMM) + GroupNorm partial statistics; returns raw [B, Lout, C], partial, P, Lout."""
+    cin, k = pw.cin, pw.ksize
+    Lout = (Lin + 2 * pad - k) // stride + 1
+    C = pw.N
+    raw = torch.empty(B, Lout, C, device=x16.device, dtype=raw_dtype)
+    P = 2 * ((Lout + 127) // 128)
+    part = torch.empty(B, P, groups, 2, device=x16.device, dtype=torch.float32)
+    ops.gemm16(x16, pw, raw, B=B, Lout=Lout, Lin=Lin, a_batch_stride=Lin * cin, ldo=C, o_batch_stride=Lout * C,
+               stride=stride, pad=pad, gn_partial=part, gn_group=C // groups)
+    return raw, part, P, Lout
+
+
+def perception_forward(wave, pk, keep_sinc=False):
+    """wave [B, L] fp32 -> zcat [B, T_pa, 2D] fp32 (z_real | z_imag, channels-last), sigma [B, T_pa] fp32."""
+    dt = ops.compute_dtype()
+    wave = wave.contiguous()
+    B, L = wave.shape
+    C0, K = pk["C0"], pk["K"]
+    dev = wave.device
+    _, Wt = ops.sinc_filters(pk["low_hz_"], pk["band_hz_"], pk["window"], pk["n_"], C0, K, pk["fs"], 50.0, 50.0,
+                             want_filt=False)
+    raw = torch.empty(B, L, C0, device=dev, dtype=dt)
+    P0 = 4 * ((L + 127) // 128)
+    part = torch.empty(B, P0, 8, 2, device=dev, dtype=torch.float32)
+    ops.framed_gemm(wave, Wt, raw, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=K // 2, K=K, N=C0,
+                    o_batch_stride=L * C0, ldm=C0, ldn=1, mode=0, gn_partial=part, gn_group=C0 // 8)
+    sc, sh = ops.gn_finalize(part, pk["sn_w"], pk["sn_b"], B, P0, 8, C0, L)
+    x = torch.empty(B, L, C0, device=dev, dtype=dt)
+    ops.gn_apply(raw, sc, sh, x, B, L, C0, act=1)
+    del raw
+    Lc = L
+    for bp in pk["blocks"]:
+        G, C = bp["groups"], bp["cout"]
+        r1, p1, P1, L1 = _conv_gn(x, bp["c1"], B, Lc, 2, 3, G, dt)
+        s1, h1 = ops.gn_finalize(p1, bp["g1w"], bp["g1b"], B, P1, G, C, L1)
+        a1 = torch.empty(B, L1, C, device=dev, dtype=dt)
+        ops.gn_apply(r1, s1, h1, a1, B, L1, C, act=1)
+        r2, p2, P2, _ = _conv_gn(a1, bp["c2"], B, L1, 1, 1, G, dt)
+        rs, ps, Ps, _ = _conv_gn(x, bp["cs"], B, Lc, 2, 0, G, dt)
+        s2, h2 = ops.gn_finalize(p2, bp["g2w"], bp["g2b"], B, P2, G, C, L1)
+        ss, hs = ops.gn_finalize(ps, bp["gsw"], bp["gsb"], B, Ps, G, C, L1)
+        x = torch.empty(B, L1, C, device=dev, dtype=dt)
+        ops.gn_apply(r2, s2, h2, x, B, L1, C, act=1, x2=rs, sc2=ss, sh2=hs)
+        Lc = L1
+    D = pk["D"]
+    rd, pd, Pd, Tpa = _conv_gn(x, pk["down"], B, Lc, 2, 2, 16, dt)
+    sd_, hd_ = ops.gn_finalize(pd, pk["dn_w"], pk["dn_b"], B, Pd, 16, D, Tpa)
+    xd = torch.empty(B, Tpa, D, device=dev, dtype=dt)
+    ops.gn_apply(rd, sd_, hd_, xd, B, Tpa, D, act=1)
+    # complex latent heads: one GEMM for (real | imag), GroupNorm(16) per half = 32 groups over 2D channels
+    rz, pz, Pz, _ = _conv_gn(xd, pk["zproj"], B, Tpa, 1, 0, 32, torch.float32)
+    sz, hz = ops.gn_finalize(pz, pk["z_w"], pk["z_b"], B, Pz, 32, 2 * D, Tpa)
+    zcat = torch.empty(B, Tpa, 2 * D, device=dev, dtype=torch.float32)
+    ops.gn_apply(rz, sz, hz, zcat, B, Tpa, 2 * D, act=0)
+    # uncertainty head
+    u = torch.empty(B, Tpa, pk["u0"].N, device=dev, dtype=dt)
+    ops.gemm16(xd, pk["u0"], u, B=B, Lout=Tpa, Lin=Tpa, a_batch_stride=Tpa * D, ldo=pk["u0"].N,
+               o_batch_stride=Tpa * pk["u0"].N, stride=1, pad=1, epi=ops.EPI_GELU)
+    sigma = torch.empty(B * Tpa, 1, device=dev, dtype=torch.float32)
+    ops.linear16(u.reshape(B * Tpa, -1), pk["u2"], epi=ops.EPI_SIGMA, out=sigma)
+    return zcat, sigma.reshape(B, Tpa)
+
+
+# ---------------------------------------------------------------------------
+# CPEA (agents/cpea.py:79-112)
+# ---------------------------------------------------------------------------
+def pack_cpea(sd, num_layers=2):
+    pk = {"layers": [], "H": sd["lstm.weight_hh_l0"].shape[1]}
+    for l in range(num_layers):
+        wih = torch.cat([sd["lstm.weight_ih_l%d" % l], sd["lstm.weight_ih_l%d_reverse" % l]], dim=0)
+        bias = torch.cat([sd["lstm.bias_ih_l%d" % l] + sd["lstm.bias_hh_l%d" % l],
+                          sd["lstm.bias_ih_l%d_reverse" % l] + sd["lstm.bias_hh_l%d_reverse" % l]], dim=0)
+        whh = torch.stack([_f32(sd["lstm.weight_hh_l%d" % l]), _f32(sd["lstm.weight_hh_l%d_reverse" % l])], dim=0)
+        pk["layers"].append({"wih": ops.pack_linear(wih, bias), "whh": whh.contiguous()})
+    wh = torch.cat([sd["rho_s_head.0.weight"], sd["rho_n_head.0.weight"], sd["phi1_head.0.weight"],
+                    sd["phi2_head.0.weight"]], dim=0)
+    bh = torch.cat([sd["rho_s_head.0.bias"], sd["rho_n_head.0.bias"], sd["phi1_head.0.bias"], sd["phi2_head.0.bias"]], dim=0)
+    pk["heads"] = ops.pack_linear(wh, bh)
+    pk["oc"] = sd["rho_s_head.0.weight"].shape[0]
+    return pk
+
+
+def cpea_forward(z16, pk, B, T, out=None):
+    """z16: [B*T, ld] 16-bit rows whose first input_dim columns are the latent ->
+    [B*T, 4*oc] (rho_s | rho_n | phi1 | phi2); `out` may be a strided 16-bit/fp32 view."""
+    H = pk["H"]
+    M = B * T
+    dt = ops.compute_dtype()
+    x16 = z16
+    for lp in pk["layers"]:
+        xg = ops.linear16(x16, lp["wih"], out_dtype=torch.float32)                  # [M, 8H] = [B,T,2,4H]
+        h = ops.bilstm_layer(xg, lp["whh"], B, T, H)                                # [B, T, 2H] fp32
+        x16 = torch.empty(M, 2 * H, device=h.device, dtype=dt)
+        ops.convert_rows(h, x16, M, 2 * H, 2 * H, 2 * H, 2 * H)
+    oc = pk["oc"]
+    if out is None:
+        out = torch.empty(M, 4 * oc, device=x16.device, dtype=torch.float32)
+    ops.linear16(x16, pk["heads"], epi=ops.EPI_CPEA, alpha=math.pi, nsplit=2 * oc, out=out)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# EpisodicMemory (agents/memory.py:95-148)
+# ---------------------------------------------------------------------------
+def pack_memory_params(sd):
+    order = ["key_proj.0.weight", "key_proj.0.bias", "key_proj.1.weight", "key_proj.1.bias", "key_proj.3.weight",
+             "key_proj.3.bias", "keys", "values", "value_proj.0.weight", "value_proj.0.bias", "gate.0.weight",
+             "gate.0.bias"]
+    return torch.cat([_f32(sd[k]).reshape(-1) for k in order]).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# MaskSynthesisAgent (agents/msa.py:106-174)
+# ---------------------------------------------------------------------------
+def pack_msa(sd, num_blocks):
+    return {"f0": ops.pack_linear(sd["fusion.0.weight"], sd["fusion.0.bias"], k_pad_to=FUSE_LD),
+            "f1w": _f32(sd["fusion.1.weight"]), "f1b": _f32(sd["fusion.1.bias"]),
+            "f3": ops.pack_linear(sd["fusion.3.weight"], sd["fusion.3.bias"]),
+            "f4w": _f32(sd["fusion.4.weight"]), "f4b": _f32(sd["fusion.4.bias"]),
+            "conf": pack_complex_conformer(sub(sd, "conformer"), num_blocks),
+            "r0": ops.pack_linear(sd["mask_proj_real.0.weight"], sd["mask_proj_real.0.bias"]),
+            "r2": ops.pack_linear(sd["mask_proj_real.2.weight"], sd["mask_proj_real.2.bias"]),
+            "i0": ops.pack_linear(sd["mask_proj_imag.0.weight"], sd["mask_proj_imag.0.bias"]),
+            "i2": ops.pack_linear(sd["mask_proj_imag.2.weight"], sd["mask_proj_imag.2.bias"]),
+            "d_model": sd["fusion.3.weight"].shape[0]}
+
+
+def msa_logits(fused16, pk, B, T, H):
+    """fused16 [M, FUSE_LD] 16-bit (the 8-way concat of agents/msa.py:140, zero padded)
+    -> magnitude / phase logits [M, 129] fp32 each."""
+    D = pk["d_model"]
+    h = ops.linear16(fused16, pk["f0"], out_dtype=torch.float32)
+    h16 = _ln16(h, pk["f1w"], pk["f1b"], act=1)
+    h = ops.linear16(h16, pk["f3"], out_dtype=torch.float32)
+    hf16 = _ln16(h, pk["f4w"], pk["f4b"])
+    y16 = complex_conformer_core(hf16, pk["conf"], B, T, H, out_dtype=ops.compute_dtype())   # [M, D]: mask_r | mask_i
+    half = D // 2
+    gr = ops.linear16(y16[:, :half], pk["r0"], epi=ops.EPI_GELU)
+    lm = ops.linear16(gr, pk["r2"], out_dtype=torch.float32)
+    gi = ops.linear16(y16[:, half:], pk["i0"], epi=ops.EPI_GELU)
+    lp = ops.linear16(gi, pk["i2"], out_dtype=torch.float32)
+    return lm, lp
+
+
+def msa_pack_inputs(z_real, z_imag, cpea, noisy_real, noisy_imag):
+    """Module-API inputs (reference layouts) -> fused 16-bit operand [B*T, FUSE_LD]."""
+    B, D, T = z_real.shape
+    M = B * T
+    dev = z_real.device
+    fused = torch.empty(M, FUSE_LD, device=dev, dtype=ops.compute_dtype())
+    zr, zi = z_real.float().contiguous(), z_imag.float().contiguous()
+    ops.transpose(zr, fused, B, D, T, D * T, T, T * FUSE_LD, FUSE_LD)
+    ops.transpose(zi, fused[:, D:], B, D, T, D * T, T, T * FUSE_LD, FUSE_LD)
+    col = 2 * D
+    for k in ("rho_s", "rho_n", "phi1", "phi2"):
+        c = cpea[k].float().contiguous()
+        oc = c.shape[-1]
+        ops.convert_rows(c, fused[:, col:], M, oc, oc, oc, FUSE_LD)
+        col += oc
+    nr, ni = noisy_real.float().contiguous(), noisy_imag.float().contiguous()
+    F = nr.shape[-1]
+    ops.stft_lognorm_pack(nr, ni, fused[:, col:], M, F, FUSE_LD - col - 2 * F, FUSE_LD)
+    return fused, nr, ni
+
+
+PHASE_SCALE_MSA = 3.14159 / 8.0     # literal of agents/msa.py:168
+
+
+def msa_forward(z_real, z_imag, cpea, noisy_real, noisy_imag, pk, H, mag_bias=None):
+    B, D, T = z_real.shape
+    fused, nr, ni = msa_pack_inputs(z_real, z_imag, cpea, noisy_real, noisy_imag)
+    lm, lp = msa_logits(fused, pk, B, T, H)
+    F = nr.shape[-1]
+    mr = torch.empty(B, T, F, device=lm.device, dtype=torch.float32)
+    mi = torch.empty(B, T, F, device=lm.device, dtype=torch.float32)
+    ops.polar_mask(lm, lp, B, T, F, PHASE_SCALE_MSA, lm.stride(0), mag_bias=mag_bias, mr=mr, mi=mi)
+    return mr, mi
+
+
+# ---------------------------------------------------------------------------
+# North-star composition with the build-defined glue
+# ---------------------------------------------------------------------------
+def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
+    """wave [B, L] fp32 -> dict(mask_real, mask_imag [B,T,129], enhanced [B,L], ...).
+    packs: dict(pa=, cpea=, msa=[, memory=(params, kd, vd, slots, temp)])."""
+    dt = ops.compute_dtype()
+    wave = wave.contiguous()
+    B, L = wave.shape
+    dev = wave.device
+    T = 1 + L // HOP
+    M = B * T
+    pa = packs["pa"]
+    D = pa["D"]
+    zcat, sigma = perception_forward(wave, pa)                         # [B, Tpa, 2D] fp32
+    Tpa = zcat.shape[1]
+    fused = torch.empty(M, FUSE_LD, device=dev, dtype=dt)
+    zpool = torch.empty(B, T, 2 * D, device=dev, dtype=torch.float32) if use_memory else None
+    ops.pool_time(zcat, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD)  # G1 -> fused[:, :2D]
+    oc4 = 4 * packs["cpea"]["oc"]
+    cpea_forward(fused, packs["cpea"], B, T, out=fused[:, 2 * D:2 * D + oc4])   # CPEA(z_real pooled) -> fused cols
+    nr, ni = stft(wave)
+    col = 2 * D + oc4
+    ops.stft_lognorm_pack(nr, ni, fused[:, col:], M, N_FREQ, FUSE_LD - col - 2 * N_FREQ, FUSE_LD)
+    bias = None
+    out = {}
+    if use_memory:
+        ops.pool_time(zcat, None, zpool, B, Tpa, T, 2 * D, 2 * D, 2 * D)
+        emb = torch.empty(B, 1, 2 * D, device=dev, dtype=torch.float32)
+        ops.pool_time(zpool, None, emb, B, T, 1, 2 * D, 2 * D, 2 * D)   # G2: key = mean over frames
+        params, kd, vd, slots, temp = packs["memory"]
+        emb_r = emb.reshape(B, 2 * D)[:, :kd].contiguous()
+        bias, gate, top, sim = ops.memory_fwd(emb_r, params, kd, vd, slots, temp)
+        out.update(mem_bias=bias, mem_gate=gate, mem_top=top, mem_sim=sim)
+    lm, lp = msa_logits(fused, packs["msa"], B, T, H)
+    mr = torch.empty(B, T, N_FREQ, device=dev, dtype=torch.float32)
+    mi = torch.empty(B, T, N_FREQ, device=dev, dtype=torch.float32)
+    ld = ops.round_up(2 * N_FREQ, 8)
+    spec = torch.zeros(M, ld, device=dev, dtype=torch.float32)
+    ops.polar_mask(lm, lp, B, T, N_FREQ, PHASE_SCALE_MSA, lm.stride(0), mag_bias=bias, nr=nr, ni=ni, mr=mr, mi=mi,
+                   er=spec, ei=spec[:, N_FREQ:], ld_enh=ld)            # G3 bias; enhanced spectrum packed for iSTFT
+    out.update(mask_real=mr, mask_imag=mi, sigma=sigma, zcat=zcat, noisy_real=nr, noisy_imag=ni, spec=spec)
+    if "wave" in want:
+        out["enhanced"] = istft_from_packed(spec, B, T, L)
+    return out

@@ -1,0 +1,77 @@
+"""ctypes binding of libsincformer_hip.so (C ABI: include/sincformer_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+is absent, importing/using the ops raises.  (The oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsincformer_hip.so")
+
+c_vp = ctypes.c_void_p
+c_i = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_f = ctypes.c_float
+
+# name -> argtypes, in the order of include/sincformer_hip.h
+SIGNATURES = {
+    "sfm_abi_version": [],
+    "sfm_gemm16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i,
+                   c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_framed_gemm_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i,
+                            c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_attention_fwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_vp],
+    "sfm_layernorm": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_vp],
+    "sfm_gn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_f, c_vp],
+    "sfm_gn_apply": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_dwconv_bn_swish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp],
+    "sfm_convert_rows": [c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_i, c_vp],
+    "sfm_transpose": [c_vp, c_vp, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_vp],
+    "sfm_pool_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
+    "sfm_stft_lognorm_pack": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_i, c_vp],
+    "sfm_polar_mask": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_f, c_ll, c_ll,
+                       c_vp],
+    "sfm_complex_mul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
+    "sfm_istft_ola": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_vp],
+    "sfm_pack_spec": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_vp],
+    "sfm_sinc_filters": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_f, c_vp],
+    "sfm_bilstm_layer": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_memory_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
+}
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises HipExtensionMissing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            "libsincformer_hip.so not built (%s). Run `python -m sincformer_metacog_speech_enhancement_amd.build` "
+            "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipExtensionMissing("symbol %s missing from %s" % (name, LIB_PATH)) from e
+        fn.argtypes = args
+        fn.restype = c_i
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "bad argument", -2: "unsupported shape", -3: "kernel launch failed"}
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (name, _ERR.get(rc, "error"), rc))

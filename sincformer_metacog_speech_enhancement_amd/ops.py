@@ -1,0 +1,332 @@
+"""Thin Python wrappers over the C ABI (one function per entry point) plus the
+host-side weight packing the kernels expect.  Tensors must live on the HIP
+device; there is no CPU fallback (lib.load() raises if the .so is missing)."""
+import ctypes
+import math
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+EPI_NONE, EPI_SWISH, EPI_GELU, EPI_RESID, EPI_GLU, EPI_SIGMOID, EPI_TANH_SCALE, EPI_SIGMA, EPI_CPEA = range(9)
+
+_DT_ID = {torch.bfloat16: 0, torch.float16: 1}
+_state = {"dtype": torch.bfloat16}
+
+
+def set_compute_dtype(dt):
+    """16-bit MFMA operand/activation format: torch.bfloat16 (default) or torch.float16."""
+    if isinstance(dt, str):
+        dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16,
+              "float16": torch.float16}[dt]
+    if dt not in _DT_ID:
+        raise ValueError("compute dtype must be bfloat16 or float16")
+    _state["dtype"] = dt
+
+
+def compute_dtype():
+    return _state["dtype"]
+
+
+def dtype_name():
+    return "bf16" if _state["dtype"] is torch.bfloat16 else "f16"
+
+
+def _dt():
+    return _DT_ID[_state["dtype"]]
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sincformer HIP ops need device tensors (no CPU fallback); got a CPU tensor")
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------
+# weight packing
+# ---------------------------------------------------------------------------
+class PackedWeight:
+    """W [Npad, Kpad] 16-bit (+ fp32 bias [Npad]) for sfm_gemm16."""
+    __slots__ = ("w", "bias", "N", "K", "Npad", "Kpad", "ksize", "cin", "glu")
+
+    def __init__(self, w, bias, N, K, ksize, cin, glu=False):
+        self.w, self.bias, self.N, self.K = w, bias, N, K
+        self.Npad, self.Kpad = w.shape
+        self.ksize, self.cin, self.glu = ksize, cin, glu
+
+
+def pack_linear(weight, bias=None, glu=False, k_pad_to=None, dtype=None):
+    """weight [N, K] (nn.Linear) or [N, Cin, k] (nn.Conv1d; repacked to tap-major K).
+    glu=True interleaves the two halves in 32-row groups for the GLU epilogue."""
+    dtype = dtype or _state["dtype"]
+    w = weight.detach().float()
+    ksize, cin = 1, w.shape[1]
+    if w.dim() == 3:
+        ksize = w.shape[2]
+        w = w.permute(0, 2, 1).reshape(w.shape[0], -1)       # [N, k*Cin], tap-major
+    N, K = w.shape
+    b = bias.detach().float() if bias is not None else torch.zeros(N, device=w.device)
+    if glu:
+        C = N // 2
+        idx = torch.arange(N, device=w.device)
+        blk, t = idx // 64, idx % 64
+        src = torch.where(t < 32, blk * 32 + t, C + blk * 32 + (t - 32))
+        w, b = w[src], b[src]
+    Kpad = round_up(k_pad_to or K, 32)
+    if glu or (N > 64 and round_up(N, 128) - N < 64):
+        Npad = round_up(N, 128)          # 128-column tiles
+    else:
+        Npad = round_up(N, 64)           # 64-column tiles (kernel picks BN from Npad % 128)
+    W = torch.zeros(Npad, Kpad, device=w.device, dtype=dtype)
+    W[:N, :K] = w.to(dtype)
+    Bp = torch.zeros(Npad, device=w.device, dtype=torch.float32)
+    Bp[:N] = b
+    if ksize == 1:
+        cin = Kpad if k_pad_to else K    # operand rows must be zero padded up to cin
+        if cin % 8 != 0:
+            raise ValueError("K=%d is not a multiple of 8: pass k_pad_to and zero-pad the operand" % K)
+    return PackedWeight(W.contiguous(), Bp, (N // 2) if glu else N, K, ksize, cin, glu)
+
+
+def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda=None, stride=1, pad=0,
+           epi=EPI_NONE, resid=None, ldr=0, r_batch_stride=0, alpha=1.0, gn_partial=None, gn_group=0, nsplit=0):
+    """A: [B, Lin, cin] 16-bit with position stride lda (default cin) -> out rows (b, l)."""
+    _need_dev(A, out)
+    L = _lib.load()
+    cin = pw.cin
+    lda = cin if lda is None else lda
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    rc = L.sfm_gemm16(_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin, lda,
+                      pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo, o_batch_stride, ldr, r_batch_stride,
+                      float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _stream())
+    _lib.check(rc, "sfm_gemm16")
+    return out
+
+
+def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=None, nsplit=0):
+    """x16 [M, K(>=pw.K)] 16-bit contiguous rows -> [M, N]."""
+    M, ld = x16.shape[0], x16.stride(0)
+    if out is None:
+        odt = out_dtype or (torch.float32 if epi == EPI_RESID else _state["dtype"])
+        out = torch.empty(M, pw.N, device=x16.device, dtype=odt)
+    gemm16(x16, pw, out, B=1, Lout=M, Lin=M, a_batch_stride=0, lda=ld, ldo=out.stride(0), o_batch_stride=0, epi=epi,
+           resid=resid, ldr=(resid.stride(0) if resid is not None else 0), alpha=alpha, nsplit=nsplit)
+    return out
+
+
+def framed_gemm(sig, Wt, out, *, B, M, Ls, sig_batch_stride, hop, padl, K, N, o_batch_stride, ldm, ldn, mode=0,
+                bias=None, out2=None, nsplit=0, gn_partial=None, gn_group=0):
+    _need_dev(sig, Wt, out)
+    L = _lib.load()
+    Kpad, Npad = Wt.shape
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    rc = L.sfm_framed_gemm_f32(_p(sig), _p(Wt), _p(bias), _p(out), _p(out2), _p(gn_partial), B, M, Ls,
+                               sig_batch_stride, hop, padl, K, Kpad, N, Npad, nsplit, o_batch_stride, ldm, ldn, mode,
+                               out_f32, gn_group, _dt(), _stream())
+    _lib.check(rc, "sfm_framed_gemm_f32")
+    return out
+
+
+def pack_f32_matrix(wt_kn):
+    """[K, N] fp32 -> zero padded [round32(K), round64(N)] operand of framed_gemm."""
+    K, N = wt_kn.shape
+    W = torch.zeros(round_up(K, 32), round_up(N, 64), device=wt_kn.device, dtype=torch.float32)
+    W[:K, :N] = wt_kn
+    return W
+
+
+def attention(qkv16, B, T, H, hd, out=None):
+    """qkv16 [B*T, 3*H*hd] (q | k | v) -> [B*T, H*hd]."""
+    _need_dev(qkv16)
+    L = _lib.load()
+    D = H * hd
+    ld = qkv16.stride(0)
+    if out is None:
+        out = torch.empty(B * T, D, device=qkv16.device, dtype=qkv16.dtype)
+    rc = L.sfm_attention_fwd(_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld, T * out.stride(0),
+                             1.0 / math.sqrt(hd), _dt(), _stream())
+    _lib.check(rc, "sfm_attention_fwd")
+    return out
+
+
+def layernorm(x32, w, b, out16=None, out32=None, act=0, eps=1e-5):
+    _need_dev(x32)
+    L = _lib.load()
+    M, D = x32.shape
+    rc = L.sfm_layernorm(_p(x32), _p(w), _p(b), _p(out16), _p(out32), M, D, x32.stride(0),
+                         out16.stride(0) if out16 is not None else 0, out32.stride(0) if out32 is not None else 0,
+                         eps, act, _dt(), _stream())
+    _lib.check(rc, "sfm_layernorm")
+
+
+def gn_finalize(partial, w, b, Bn, P, G, C, rows, eps=1e-5):
+    L = _lib.load()
+    scale = torch.empty(Bn, C, device=w.device, dtype=torch.float32)
+    shift = torch.empty(Bn, C, device=w.device, dtype=torch.float32)
+    rc = L.sfm_gn_finalize(_p(partial), _p(w), _p(b), _p(scale), _p(shift), Bn, P, G, C, rows, eps, _stream())
+    _lib.check(rc, "sfm_gn_finalize")
+    return scale, shift
+
+
+def gn_apply(x1, sc1, sh1, out, Bn, rows, C, act=0, x2=None, sc2=None, sh2=None):
+    L = _lib.load()
+    in_f32 = 1 if x1.dtype == torch.float32 else 0
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    rc = L.sfm_gn_apply(_p(x1), _p(sc1), _p(sh1), _p(x2), _p(sc2), _p(sh2), _p(out), Bn, rows, C, in_f32, out_f32, act,
+                        _dt(), _stream())
+    _lib.check(rc, "sfm_gn_apply")
+    return out
+
+
+def dwconv_bn_swish(x16, wdw, bdw, bnw, bnb, bnm, bnv, B, T, C, out=None, eps=1e-5):
+    L = _lib.load()
+    KS = wdw.shape[-1]
+    if out is None:
+        out = torch.empty_like(x16)
+    rc = L.sfm_dwconv_bn_swish(_p(x16), _p(wdw), _p(bdw), _p(bnw), _p(bnb), _p(bnm), _p(bnv), _p(out), B, T, C, KS,
+                               eps, _dt(), _stream())
+    _lib.check(rc, "sfm_dwconv_bn_swish")
+    return out
+
+
+def convert_rows(src32, dst16, M, C, Cz, ld_src, ld_dst):
+    L = _lib.load()
+    rc = L.sfm_convert_rows(_p(src32), _p(dst16), M, C, Cz, ld_src, ld_dst, _dt(), _stream())
+    _lib.check(rc, "sfm_convert_rows")
+
+
+def transpose(src, dst, B, R, C, src_batch, src_row, dst_batch, dst_row):
+    L = _lib.load()
+    rc = L.sfm_transpose(_p(src), _p(dst), B, R, C, src_batch, src_row, dst_batch, dst_row,
+                         1 if src.dtype == torch.float32 else 0, 1 if dst.dtype == torch.float32 else 0, _dt(),
+                         _stream())
+    _lib.check(rc, "sfm_transpose")
+
+
+def pool_time(src32, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst):
+    L = _lib.load()
+    rc = L.sfm_pool_time(_p(src32), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src, ld_dst, _dt(), _stream())
+    _lib.check(rc, "sfm_pool_time")
+
+
+def stft_lognorm_pack(re, im, dst16, M, F, zpad, ld_dst):
+    L = _lib.load()
+    rc = L.sfm_stft_lognorm_pack(_p(re), _p(im), _p(dst16), M, F, zpad, ld_dst, _dt(), _stream())
+    _lib.check(rc, "sfm_stft_lognorm_pack")
+
+
+def polar_mask(lm, lp, B, rows, F, phase_scale, ld_logits, mag_bias=None, nr=None, ni=None, mr=None, mi=None, er=None,
+               ei=None, mmag=None, ld_enh=0):
+    L = _lib.load()
+    rc = L.sfm_polar_mask(_p(lm), _p(lp), _p(mag_bias), _p(nr), _p(ni), _p(mr), _p(mi), _p(er), _p(ei), _p(mmag), B,
+                          rows, F, float(phase_scale), ld_logits, ld_enh, _stream())
+    _lib.check(rc, "sfm_polar_mask")
+
+
+def complex_mul(sr, si, mr, mi):
+    L = _lib.load()
+    er, ei = torch.empty_like(sr), torch.empty_like(sr)
+    rc = L.sfm_complex_mul(_p(sr), _p(si), _p(mr), _p(mi), _p(er), _p(ei), sr.numel(), _stream())
+    _lib.check(rc, "sfm_complex_mul")
+    return er, ei
+
+
+def istft_ola(frames, win2, out, B, T, Ln, n_fft, hop, win, ld_frames):
+    L = _lib.load()
+    rc = L.sfm_istft_ola(_p(frames), _p(win2), _p(out), B, T, Ln, n_fft, hop, win, ld_frames, _stream())
+    _lib.check(rc, "sfm_istft_ola")
+
+
+def pack_spec(re, im, dst, M, F, ld, ld_src):
+    L = _lib.load()
+    rc = L.sfm_pack_spec(_p(re), _p(im), _p(dst), M, F, ld, ld_src, _stream())
+    _lib.check(rc, "sfm_pack_spec")
+
+
+def sinc_filters(low_hz, band_hz, window, n_, C, K, sample_rate, min_low_hz, min_band_hz, want_filt=True):
+    L = _lib.load()
+    dev = low_hz.device
+    Npad = round_up(C, 64)
+    Wt = torch.zeros(round_up(K, 32), Npad, device=dev, dtype=torch.float32)
+    filt = torch.empty(C, K, device=dev, dtype=torch.float32) if want_filt else None
+    rc = L.sfm_sinc_filters(_p(low_hz), _p(band_hz), _p(window), _p(n_), _p(filt), _p(Wt), C, K, Npad,
+                            float(sample_rate), float(min_low_hz), float(min_band_hz), _stream())
+    _lib.check(rc, "sfm_sinc_filters")
+    return filt, Wt
+
+
+def bilstm_layer(xg, whh, B, T, H):
+    L = _lib.load()
+    out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)
+    rc = L.sfm_bilstm_layer(_p(xg), _p(whh), _p(out), B, T, H, _dt(), _stream())
+    _lib.check(rc, "sfm_bilstm_layer")
+    return out
+
+
+def memory_fwd(emb, params, key_dim, value_dim, slots, temperature):
+    L = _lib.load()
+    Bn = emb.shape[0]
+    dev = emb.device
+    bias = torch.empty(Bn, value_dim, device=dev, dtype=torch.float32)
+    gate = torch.empty(Bn, 1, device=dev, dtype=torch.float32)
+    top = torch.empty(Bn, device=dev, dtype=torch.int32)
+    sim = torch.empty(Bn, device=dev, dtype=torch.float32)
+    rc = L.sfm_memory_fwd(_p(emb), _p(params), _p(bias), _p(gate), _p(top), _p(sim), Bn, key_dim, value_dim, slots,
+                          float(temperature), _stream())
+    _lib.check(rc, "sfm_memory_fwd")
+    return bias, gate, top, sim
+
+
+# ---------------------------------------------------------------------------
+# constant operands for STFT / iSTFT as fp32 matrix products (host, float64 twiddles)
+# ---------------------------------------------------------------------------
+def _hann(n):
+    k = np.arange(n, dtype=np.float64)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+
+
+def stft_matrix(n_fft, win, device):
+    """[win, 2F] : columns [0,F) real part, [F,2F) imag part, restricted to the
+    window support (torch.stft zero-pads the window to n_fft centred)."""
+    F = n_fft // 2 + 1
+    woff = (n_fft - win) // 2
+    w = _hann(win)
+    n = (np.arange(win, dtype=np.float64) + woff)[:, None]
+    f = np.arange(F, dtype=np.float64)[None, :]
+    ang = 2.0 * np.pi * ((n * f) % n_fft) / n_fft
+    M = np.concatenate([w[:, None] * np.cos(ang), -w[:, None] * np.sin(ang)], axis=1)
+    return pack_f32_matrix(torch.from_numpy(M.astype(np.float32)).to(device))
+
+
+def istft_matrix(n_fft, win, device):
+    """[2F(+pad), win]: irfft restricted to the window support, times the window."""
+    F = n_fft // 2 + 1
+    woff = (n_fft - win) // 2
+    w = _hann(win)
+    n = (np.arange(win, dtype=np.float64) + woff)[None, :]
+    f = np.arange(F, dtype=np.float64)[:, None]
+    ang = 2.0 * np.pi * ((f * n) % n_fft) / n_fft
+    coef = np.full((F, 1), 2.0)
+    coef[0, 0] = 1.0
+    if n_fft % 2 == 0:
+        coef[F - 1, 0] = 1.0
+    br = coef * np.cos(ang) / n_fft * w[None, :]
+    bi = -coef * np.sin(ang) / n_fft * w[None, :]
+    bi[0, :] = 0.0
+    if n_fft % 2 == 0:
+        bi[F - 1, :] = 0.0
+    M = np.concatenate([br, bi], axis=0)
+    win2 = torch.from_numpy((w * w).astype(np.float32)).to(device)
+    return pack_f32_matrix(torch.from_numpy(M.astype(np.float32)).to(device)), win2

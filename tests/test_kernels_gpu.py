@@ -1,0 +1,337 @@
+"""Kernel-level parity: every C-ABI entry point against an fp32 CPU evaluation
+of the same operation (oracle primitives / plain torch) on seeded inputs.
+Needs a real MI355X: `pytest -m gpu`."""
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import arr, maxerr, rmse, synth_sd
+from oracle import sfm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+# relative tolerance of one 16-bit rounding of an O(1) value
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from sincformer_metacog_speech_enhancement_amd import ops as _ops
+    return _ops
+
+
+def dev(x):
+    return x.cuda()
+
+
+def q16(x, dt):
+    """round to the 16-bit format and back (CPU)"""
+    return x.to(dt).float()
+
+
+def report(name, got, ref, tol):
+    e = maxerr(got, ref)
+    r = rmse(got, ref)
+    print("%-40s max|err| %.3e  rmse %.3e  tol %.1e  ref_rms %.3e" % (name, e, r, tol, float(ref.double().pow(2).mean().sqrt())))
+    assert math.isfinite(e) and e <= tol, "%s: max err %.3e > %.1e" % (name, e, tol)
+
+
+# ---------------------------------------------------------------------------
+def test_mfma_layout_identity(ops):
+    """A = I with an asymmetric B catches transposed fragment maps."""
+    ops.set_compute_dtype(torch.float16)
+    K = 64
+    A = torch.eye(128, K)
+    W = (torch.arange(128 * K, dtype=torch.float32).reshape(128, K) % 61) / 8.0 - 3.0
+    pw = ops.pack_linear(dev(W))
+    out = ops.linear16(dev(A).half().contiguous(), pw, out_dtype=torch.float32)
+    ref = A @ q16(W, torch.float16).t()
+    report("mfma identity", out.cpu(), ref, 1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,K,N", [(300, 256, 256), (129, 1024, 256), (77, 64, 129), (513, 256, 1024), (40, 128, 64), (5, 64, 1)])
+def test_gemm16_plain(ops, dt, M, K, N):
+    ops.set_compute_dtype(dt)
+    x = arr("gx", (M, K), 1)
+    w = arr("gw", (N, K), 2) / math.sqrt(K)
+    b = arr("gb", (N,), 3)
+    pw = ops.pack_linear(dev(w), dev(b))
+    out = ops.linear16(dev(x).to(dt).contiguous(), pw, out_dtype=torch.float32)
+    ref = q16(x, dt) @ q16(w, dt).t() + b
+    report("gemm16 %s %dx%dx%d" % (dt, M, K, N), out.cpu(), ref, 2e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm16_epilogues(ops, dt):
+    ops.set_compute_dtype(dt)
+    M, K, N = 200, 256, 256
+    x, w, b = arr("ex", (M, K), 4), arr("ew", (N, K), 5) / 16.0, arr("eb", (N,), 6)
+    xq, wq = q16(x, dt), q16(w, dt)
+    base = xq @ wq.t() + b
+    pw = ops.pack_linear(dev(w), dev(b))
+    xd = dev(x).to(dt).contiguous()
+    tol16 = 4 * EPS[dt]
+    report("epi swish", ops.linear16(xd, pw, epi=ops.EPI_SWISH, out_dtype=torch.float32).cpu(), base * torch.sigmoid(base), 5e-4)
+    report("epi gelu", ops.linear16(xd, pw, epi=ops.EPI_GELU, out_dtype=torch.float32).cpu(), orc.gelu(base), 5e-4)
+    report("epi gelu 16-bit out", ops.linear16(xd, pw, epi=ops.EPI_GELU).float().cpu(), orc.gelu(base), tol16 * 4)
+    res = arr("er", (M, N), 7)
+    report("epi resid", ops.linear16(xd, pw, epi=ops.EPI_RESID, resid=dev(res), alpha=0.5).cpu(), res + 0.5 * base, 5e-4)
+    report("epi sigmoid", ops.linear16(xd, pw, epi=ops.EPI_SIGMOID, out_dtype=torch.float32).cpu(), torch.sigmoid(base), 2e-4)
+    report("epi sigma", ops.linear16(xd, pw, epi=ops.EPI_SIGMA, out_dtype=torch.float32).cpu(),
+           torch.exp(0.5 * torch.clamp(base, -10, 10)), 2e-3)
+    ref = torch.cat([torch.sigmoid(base[:, :128]), math.pi * torch.tanh(base[:, 128:])], dim=1)
+    report("epi cpea", ops.linear16(xd, pw, epi=ops.EPI_CPEA, out_dtype=torch.float32, alpha=math.pi, nsplit=128).cpu(), ref, 1e-3)
+    # GLU: weight [2C, K]
+    w2, b2 = arr("ew2", (512, K), 8) / 16.0, arr("eb2", (512,), 9)
+    pg = ops.pack_linear(dev(w2), dev(b2), glu=True)
+    h = xq @ q16(w2, dt).t() + b2
+    report("epi glu", ops.linear16(xd, pg, epi=ops.EPI_GLU, out_dtype=torch.float32).cpu(), h[:, :256] * torch.sigmoid(h[:, 256:]), 5e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,s,p,L", [(64, 128, 7, 2, 3, 301), (128, 128, 3, 1, 1, 150), (64, 128, 1, 2, 0, 301),
+                                              (256, 256, 5, 2, 2, 77), (256, 64, 3, 1, 1, 40)])
+def test_gemm16_conv_and_groupnorm(ops, dt, cin, cout, k, s, p, L):
+    ops.set_compute_dtype(dt)
+    B = 2
+    x = arr("cx", (B, cin, L), 10)
+    w = arr("cw", (cout, cin, k), 11) / math.sqrt(cin * k)
+    b = arr("cb", (cout,), 12)
+    Lout = (L + 2 * p - k) // s + 1
+    ref = F.conv1d(q16(x, dt), q16(w, dt), b, stride=s, padding=p)              # [B, cout, Lout]
+    xcl = dev(x).transpose(1, 2).contiguous().to(dt)                            # [B, L, cin]
+    pw = ops.pack_linear(dev(w), dev(b))
+    out = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32)
+    G = 16 if cout >= 16 else cout
+    gs = cout // G
+    P = 2 * ((Lout + 127) // 128)
+    part = torch.zeros(B, P, G, 2, device="cuda", dtype=torch.float32)
+    ops.gemm16(xcl, pw, out, B=B, Lout=Lout, Lin=L, a_batch_stride=L * cin, ldo=cout, o_batch_stride=Lout * cout,
+               stride=s, pad=p, gn_partial=part, gn_group=gs)
+    report("conv k%d s%d %d->%d" % (k, s, cin, cout), out.cpu().transpose(1, 2), ref, 3e-4)
+    gw, gb = arr("gnw", (cout,), 13) * 0.1 + 1.0, arr("gnb", (cout,), 14) * 0.1
+    sc, sh = ops.gn_finalize(part, dev(gw), dev(gb), B, P, G, cout, Lout)
+    y = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32)
+    ops.gn_apply(out, sc, sh, y, B, Lout, cout, act=1)
+    refn = orc.gelu(orc.group_norm(ref, G, gw, gb))
+    report("groupnorm+gelu", y.cpu().transpose(1, 2), refn, 5e-4)
+    # two-branch residual form with 16-bit storage
+    o16 = out.to(dt)
+    y16 = torch.empty(B, Lout, cout, device="cuda", dtype=dt)
+    ops.gn_apply(o16, sc, sh, y16, B, Lout, cout, act=1, x2=o16, sc2=sc, sh2=sh)
+    ref2 = orc.gelu(2.0 * orc.group_norm(ref, G, gw, gb))
+    report("groupnorm two-branch 16-bit", y16.float().cpu().transpose(1, 2), ref2, 16 * EPS[dt])
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fs,scaled", [(16000, False), (16000, True), (8000, True)])
+def test_sinc_filters_and_fir(ops, fs, scaled):
+    ops.set_compute_dtype(torch.bfloat16)
+    p = orc.sinc_init(64, 251, fs)
+    if scaled:
+        p["low_hz_"], p["band_hz_"] = p["low_hz_"] * (fs / 8.0), p["band_hz_"] * (fs / 8.0)
+    ref_f = orc.sinc_filters(p["low_hz_"], p["band_hz_"], p["window"], p["n_"], fs)
+    filt, Wt = ops.sinc_filters(dev(p["low_hz_"].reshape(-1)), dev(p["band_hz_"].reshape(-1)), dev(p["window"]),
+                                dev(p["n_"].reshape(-1)), 64, 251, fs, 50.0, 50.0)
+    report("sinc filters fs%d scaled=%s" % (fs, scaled), filt.cpu(), ref_f, 2e-6)
+    B, L = 3, 1000
+    x = arr("sx", (B, L), 20, 0.3)
+    out = torch.empty(B, L, 64, device="cuda", dtype=torch.float32)
+    part = torch.zeros(B, 4 * ((L + 127) // 128), 8, 2, device="cuda")
+    ops.framed_gemm(dev(x), Wt, out, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=125, K=251, N=64,
+                    o_batch_stride=L * 64, ldm=64, ldn=1, mode=0, gn_partial=part, gn_group=8)
+    ref = orc.sinc_conv(x, ref_f)
+    report("sinc FIR (f32 mfma)", out.cpu().transpose(1, 2), ref, 2e-6)
+    gw, gb = arr("sgw", (64,), 21) * 0.1 + 1.0, arr("sgb", (64,), 22) * 0.1
+    sc, sh = ops.gn_finalize(part, dev(gw), dev(gb), B, part.shape[1], 8, 64, L)
+    y = torch.empty(B, L, 64, device="cuda", dtype=torch.float32)
+    ops.gn_apply(out, sc, sh, y, B, L, 64, act=1)
+    report("sinc GN(8)+GELU", y.cpu().transpose(1, 2), orc.gelu(orc.group_norm(ref, 8, gw, gb)), 2e-4)
+    # channels-first fp32 output (module API layout)
+    out_cf = torch.empty(B, 64, L, device="cuda", dtype=torch.float32)
+    ops.framed_gemm(dev(x), Wt, out_cf, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=125, K=251, N=64,
+                    o_batch_stride=L * 64, ldm=1, ldn=L, mode=0)
+    report("sinc FIR channels-first", out_cf.cpu(), ref, 2e-6)
+
+
+@pytest.mark.parametrize("L", [1600, 1637, 479, 200])
+def test_stft_istft(ops, L):
+    ops.set_compute_dtype(torch.bfloat16)
+    B = 2
+    x = arr("stx", (B, L), 30, 0.3)
+    T = 1 + L // 80
+    Wst = ops.stft_matrix(256, 160, "cuda")
+    re = torch.empty(B, T, 129, device="cuda")
+    im = torch.empty(B, T, 129, device="cuda")
+    ops.framed_gemm(dev(x), Wst, re, B=B, M=T, Ls=L, sig_batch_stride=L, hop=80, padl=80, K=160, N=258,
+                    o_batch_stride=T * 129, ldm=129, ldn=1, mode=1, out2=im, nsplit=129)
+    rr, ri = orc.stft(x)
+    report("stft real L%d" % L, re.cpu(), rr, 2e-5)
+    report("stft imag L%d" % L, im.cpu(), ri, 2e-5)
+    # istft of a modified spectrum
+    pr, pi = rr * 0.7 - ri * 0.2, ri * 0.9 + rr * 0.1
+    Wi, win2 = ops.istft_matrix(256, 160, "cuda")
+    spec = torch.zeros(B * T, 264, device="cuda")
+    ops.pack_spec(dev(pr), dev(pi), spec, B * T, 129, 264, 129)
+    frames = torch.empty(B * T, 160, device="cuda")
+    ops.framed_gemm(spec, Wi, frames, B=1, M=B * T, Ls=B * T * 264, sig_batch_stride=0, hop=264, padl=0, K=258,
+                    N=160, o_batch_stride=0, ldm=160, ldn=1, mode=0)
+    y = torch.empty(B, L, device="cuda")
+    ops.istft_ola(frames, win2, y, B, T, L, 256, 80, 160, 160)
+    report("istft L%d" % L, y.cpu(), orc.istft(pr, pi, L), 2e-5)
+
+
+# ---------------------------------------------------------------------------
+def _attn_ref(qkv, B, T, H, hd):
+    D = H * hd
+    q, k, v = qkv.reshape(B, T, 3 * D).split(D, dim=-1)
+    q = q.reshape(B, T, H, hd).transpose(1, 2)
+    k = k.reshape(B, T, H, hd).transpose(1, 2)
+    v = v.reshape(B, T, H, hd).transpose(1, 2)
+    p = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    return (p @ v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,H,hd", [(2, 200, 4, 64), (1, 64, 4, 64), (3, 1, 2, 64), (1, 801, 4, 64), (2, 129, 1, 64),
+                                      (2, 20, 4, 16), (1, 37, 2, 32)])
+def test_attention(ops, dt, B, T, H, hd):
+    ops.set_compute_dtype(dt)
+    qkv = arr("aq", (B * T, 3 * H * hd), 40 + T, 1.5)
+    out = ops.attention(dev(qkv).to(dt).contiguous(), B, T, H, hd)
+    ref = _attn_ref(q16(qkv, dt), B, T, H, hd)
+    report("attention %s B%d T%d H%d hd%d" % (dt, B, T, H, hd), out.float().cpu(), ref, 6 * EPS[dt])
+
+
+def test_attention_online_softmax_rescale(ops):
+    """a spiked key late in the sequence forces the running-max rescale branch"""
+    ops.set_compute_dtype(torch.float16)
+    B, T, H, hd = 1, 300, 1, 64
+    qkv = arr("aq2", (B * T, 3 * hd), 77, 0.5)
+    qkv[5, :hd] = 3.0
+    qkv[250, hd:2 * hd] = 3.0          # key 250 aligned with query 5: score jumps in the 4th tile
+    out = ops.attention(dev(qkv).half().contiguous(), B, T, H, hd)
+    ref = _attn_ref(q16(qkv, torch.float16), B, T, H, hd)
+    report("attention rescale", out.float().cpu(), ref, 3e-3)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,D", [(100, 256), (33, 64), (17, 258)])
+def test_layernorm(ops, dt, M, D):
+    ops.set_compute_dtype(dt)
+    x, w, b = arr("lx", (M, D), 50, 2.0) + 0.3, arr("lw", (D,), 51) * 0.1 + 1, arr("lb", (D,), 52) * 0.1
+    o16 = torch.empty(M, D, device="cuda", dtype=dt)
+    o32 = torch.empty(M, D, device="cuda")
+    ops.layernorm(dev(x), dev(w), dev(b), out16=o16, out32=o32)
+    ref = orc.layer_norm(x, w, b)
+    report("layernorm fp32 D%d" % D, o32.cpu(), ref, 2e-5)
+    report("layernorm 16b D%d" % D, o16.float().cpu(), ref, 8 * EPS[dt])
+    ops.layernorm(dev(x), dev(w), dev(b), out32=o32, act=1)
+    report("layernorm+gelu", o32.cpu(), orc.gelu(ref), 2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,KS,T", [(256, 31, 200), (64, 7, 20), (256, 31, 64), (256, 31, 7)])
+def test_dwconv_bn_swish(ops, dt, C, KS, T):
+    ops.set_compute_dtype(dt)
+    B = 2
+    x = arr("dx", (B, T, C), 60)
+    w, b = arr("dw", (C, 1, KS), 61) / math.sqrt(KS), arr("db", (C,), 62) * 0.1
+    bw, bb = arr("dbw", (C,), 63) * 0.1 + 1, arr("dbb", (C,), 64) * 0.1
+    rm, rv = arr("drm", (C,), 65) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5
+    out = ops.dwconv_bn_swish(dev(x).to(dt).contiguous(), dev(w.reshape(C, KS).contiguous()), dev(b), dev(bw), dev(bb),
+                              dev(rm), dev(rv), B, T, C)
+    h = F.conv1d(q16(x, dt).transpose(1, 2), w, b, padding=(KS - 1) // 2, groups=C)
+    ref = orc.swish(orc.batch_norm_eval(h, bw, bb, rm, rv)).transpose(1, 2)
+    report("dwconv C%d k%d T%d" % (C, KS, T), out.float().cpu(), ref, 8 * EPS[dt])
+
+
+def test_layout_kernels(ops):
+    ops.set_compute_dtype(torch.float16)
+    B, C, T = 2, 256, 37
+    z = arr("tz", (B, C, T), 70)
+    dst = torch.zeros(B * T, 1056, device="cuda", dtype=torch.float16)
+    ops.transpose(dev(z), dst[:, 256:], B, C, T, C * T, T, T * 1056, 1056)      # [B,C,T] -> cols 256.. of [B*T, 1056]
+    report("transpose cf->cl16", dst.float().cpu()[:, 256:512].reshape(B, T, C), z.transpose(1, 2), 2e-3)
+    assert float(dst[:, :256].abs().max()) == 0.0 and float(dst[:, 512:].abs().max()) == 0.0
+    back = torch.empty(B, C, T, device="cuda")
+    ops.transpose(dst[:, 256:], back, B, T, C, T * 1056, 1056, C * T, T)
+    report("transpose cl16->cf32", back.cpu(), z.half().float(), 1e-6)
+    src = arr("cs", (50, 64), 71)
+    d2 = torch.full((50, 100), 7.0, device="cuda", dtype=torch.float16)
+    ops.convert_rows(dev(src), d2, 50, 64, 80, 64, 100)
+    assert maxerr(d2[:, :64].float().cpu(), src) < 2e-3 and float(d2[:, 64:80].abs().max()) == 0 and float(d2[0, 80]) == 7.0
+    zz = arr("pz", (B, 100, 512), 72)
+    p16 = torch.empty(B, 21, 512, device="cuda", dtype=torch.float16)
+    p32 = torch.empty(B, 21, 512, device="cuda")
+    ops.pool_time(dev(zz), p16, p32, B, 100, 21, 512, 512, 512)
+    refp = orc.pool_latents(zz.transpose(1, 2), 21).transpose(1, 2)
+    report("pool_time", p32.cpu(), refp, 1e-6)
+    report("pool_time 16", p16.float().cpu(), refp, 2e-3)
+    re, im = arr("nr", (40, 129), 73, 0.5), arr("ni", (40, 129), 74, 0.5)
+    pk = torch.full((40, 300), 3.0, device="cuda", dtype=torch.float16)
+    ops.stft_lognorm_pack(dev(re), dev(im), pk, 40, 129, 30, 300)
+    mag = torch.sqrt(re ** 2 + im ** 2 + 1e-8)
+    nf = torch.log1p(mag) / mag
+    report("stft lognorm pack", pk.float().cpu()[:, :258], torch.cat([re * nf, im * nf], dim=1), 2e-3)
+    assert float(pk[:, 258:288].abs().max()) == 0 and float(pk[0, 288]) == 3.0
+
+
+def test_polar_mask_and_complex_mul(ops):
+    B, T, Fq = 2, 21, 129
+    lm, lp = arr("plm", (B * T, Fq), 80), arr("plp", (B * T, Fq), 81)
+    nr, ni = arr("pnr", (B * T, Fq), 82), arr("pni", (B * T, Fq), 83)
+    bias = arr("pb", (B, Fq), 84) * 0.3
+    mr, mi, er, ei, mm = (torch.empty(B * T, Fq, device="cuda") for _ in range(5))
+    ops.polar_mask(dev(lm), dev(lp), B, T, Fq, 3.14159 / 8.0, Fq, mag_bias=dev(bias), nr=dev(nr), ni=dev(ni), mr=mr,
+                   mi=mi, er=er, ei=ei, mmag=mm, ld_enh=Fq)
+    mag = torch.sigmoid(lm + bias.repeat_interleave(T, dim=0))
+    ph = torch.tanh(lp) * (3.14159 / 8.0)
+    rmr, rmi = mag * torch.cos(ph), mag * torch.sin(ph)
+    report("polar mask real", mr.cpu(), rmr, 2e-6)
+    report("polar mask imag", mi.cpu(), rmi, 2e-6)
+    report("polar enh real", er.cpu(), rmr * nr - rmi * ni, 5e-6)
+    report("polar enh imag", ei.cpu(), rmr * ni + rmi * nr, 5e-6)
+    report("polar mag", mm.cpu(), mag, 2e-6)
+    cr, ci = ops.complex_mul(dev(nr), dev(ni), dev(rmr), dev(rmi))
+    report("complex mul", cr.cpu(), rmr * nr - rmi * ni, 2e-6)
+    report("complex mul i", ci.cpu(), rmr * ni + rmi * nr, 2e-6)
+
+
+@pytest.mark.parametrize("B,T", [(2, 21), (3, 130)])
+def test_bilstm_layer(ops, B, T):
+    H, I = 128, 256
+    sd = synth_sd("CorrelationPhaseEstimationAgent", 61)
+    x = arr("lsx", (B, T, I), 90)
+    lsd = orc.sub(sd, "lstm")
+    xg = []
+    whh = []
+    for sfx in ("", "_reverse"):
+        xg.append(x @ lsd["weight_ih_l0" + sfx].t() + lsd["bias_ih_l0" + sfx] + lsd["bias_hh_l0" + sfx])
+        whh.append(lsd["weight_hh_l0" + sfx])
+    xg = torch.stack(xg, dim=2).contiguous()            # [B, T, 2, 4H]
+    whh = torch.stack(whh, dim=0).contiguous()          # [2, 4H, H]
+    out = ops.bilstm_layer(dev(xg), dev(whh), B, T, H)
+    f = orc._lstm_dir(x, lsd["weight_ih_l0"], lsd["weight_hh_l0"], lsd["bias_ih_l0"], lsd["bias_hh_l0"], False)
+    r = orc._lstm_dir(x, lsd["weight_ih_l0_reverse"], lsd["weight_hh_l0_reverse"], lsd["bias_ih_l0_reverse"],
+                      lsd["bias_hh_l0_reverse"], True)
+    report("bilstm layer T%d" % T, out.cpu(), torch.cat([f, r], dim=-1), 2e-5)
+
+
+def test_memory(ops):
+    from sincformer_metacog_speech_enhancement_amd.functional import pack_memory_params
+    sd = synth_sd("EpisodicMemory", 71)
+    e = arr("g7_e", (3, 256), 72)
+    params = pack_memory_params({k: dev(v) for k, v in sd.items()})
+    bias, gate, top, sim = ops.memory_fwd(dev(e), params, 256, 129, 64, 1.0)
+    ref = orc.memory_forward(sd, e)
+    report("memory bias", bias.cpu(), ref["bias"], 2e-5)
+    report("memory gate", gate.cpu(), ref["gate"], 2e-5)
+    report("memory sim", sim.cpu(), ref["similarity"], 2e-5)
+    assert np.array_equal(top.cpu().numpy().astype(np.int64), ref["top_indices"].numpy())
