@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X (contract: see the round prompt / DESIGN.md §Measurement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3p|c1] [--dtype bf16|f16]
+
+A step = one forward pass of the north-star path (PerceptionAgent -> pool -> CPEA -> STFT ->
+MaskSynthesisAgent -> apply_mask -> iSTFT) over one batch of synthetic 16 kHz utterances that is
+already resident in HBM.  Default workload = BASELINE.json configs[1]: batch 64 x 4 s (L = 64 000,
+T = 801 STFT frames/utterance), forward only, bf16 MFMA operands with fp32 accumulation.
+value = STFT frames/s over all ranks (utterances shard over ranks: no data-path collective).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the timed
+region) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (batch per GPU, samples, description)
+    "c1": (1, 16000, "B1 x 1 s (L16000, T201) forward"),
+    "c2": (64, 64000, "B64 x 4 s (L64000, T801) SincNet+Conformer forward (BASELINE configs[1])"),
+    "c3p": (256, 40880, "B256 x 512-frame utterances (L40880, T512) forward"),
+}
+PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "hbm": 8000.0}      # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
+FAMILY_BOUND = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32"}
+
+
+def build_path(dtype, seed=1234):
+    import torch
+    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    ops.set_compute_dtype(dtype)
+    path = EnhancementPath(sample_rate=16000, use_memory=False)
+    sd = path.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    keep = {k: v.numpy() for k, v in sd.items() if k.split(".")[-1] in ("low_hz_", "band_hz_", "window", "n_")}
+    new = syn.synth_state_dict(shapes, seed, keep=keep, sinc_scale=2000.0)
+    path.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+    return path, new
+
+
+def host_cores():
+    """threads this process may really use: affinity mask, cgroup cpu quota, capped at the
+    16-core share a 1-GPU box gets (oversubscribing a quota makes the CPU leg crawl)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(weights, L, batch=2, iters=3):
+    """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample."""
+    import torch
+    from oracle import sfm_oracle as orc
+    from sincformer_metacog_speech_enhancement_amd import synthetic as syn
+    cores = host_cores()
+    torch.set_num_threads(cores)
+
+    def subd(prefix):
+        p = prefix + "."
+        return {k[len(p):]: torch.from_numpy(v) for k, v in weights.items() if k.startswith(p)}
+    sds = {"pa": subd("perception"), "cpea": subd("cpea"), "msa": subd("msa")}
+    noisy, _ = syn.synth_wave(batch, L, 1234)
+    orc.enhance_path(sds, noisy, 16000)           # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        orc.enhance_path(sds, noisy, 16000)
+    dt = (time.perf_counter() - t0) / iters
+    T = 1 + L // 80
+    return {"value": batch * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle enhance_path, batch %d x L%d, %d iterations after 1 warm-up, fp32, torch %d threads"
+                      % (batch, L, iters, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write the per-kernel-family breakdown JSON here")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    B, L, desc = WORKLOADS[args.workload]
+    T = 1 + L // 80
+    path, weights = build_path(args.dtype)
+    path = path.cuda().eval()
+    noisy, _ = syn.synth_wave(B, L, 1234 + rank)          # each rank enhances its own utterance shard
+    wave = torch.from_numpy(noisy).cuda()
+
+    def step():
+        return path(wave)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        print("[bench] %s, dtype %s, world %d" % (desc, args.dtype, world), file=sys.stderr, flush=True)
+    with torch.no_grad():
+        # warm-up; the last warm-up step is instrumented per kernel family to find the dominant one
+        for i in range(max(args.warmup, 1)):
+            if i == max(args.warmup, 1) - 1:
+                ops.profiler.enable(None)
+            step()
+        breakdown = ops.profiler.summary()
+        ops.profiler.disable()
+        dominant = max(breakdown, key=lambda k: breakdown[k]["ms_total"])
+        ops.profiler.enable({dominant})
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        dom = ops.profiler.summary()[dominant]
+        ops.profiler.disable()
+
+    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    frames = world * B * T * args.steps
+    if rank == 0:
+        kind = FAMILY_BOUND.get(dominant, "hbm")
+        secs = dom["ms_avg"] * 1e-3
+        if kind == "hbm":
+            ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
+        else:
+            ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
+        att = breakdown.get("attention_fwd")
+        line = {
+            "metric": "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref",
+            "value": frames / elapsed, "unit": "STFT frames/s (whole job)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
+                       "sharding": "utterances over ranks, no data-path collective"},
+            "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit,
+                         "frac": ach / peak, "traffic": None, "launches": dom["n"], "avg_ms": dom["ms_avg"]},
+            "frames_per_s_per_gpu": frames / elapsed / world,
+        }
+        if att:
+            tf = att["flops"] / att["n"] / (att["ms_avg"] * 1e-3) / 1e12
+            line["attention"] = {"tflops": tf, "frac_bf16_mfma_peak": tf / PEAKS["mfma16"], "avg_ms": att["ms_avg"]}
+        line["breakdown_ms_per_step"] = {k: round(v["ms_total"], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])}
+        print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
+              (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, L)
+        if args.breakdown:
+            with open(args.breakdown, "w") as fh:
+                json.dump(breakdown, fh, indent=1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -256,18 +256,18 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
     dim3 grid((T + 127) / 128, H, B), block(256);
     float sl2 = scale * 1.44269504088896340736f;
     if (dtype == SFM_DT_F16)
-      hipLaunchKernelGGL((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
+      SFM_LAUNCH((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
                          koff, voff, qkv_batch_stride, o_batch_stride, sl2);
     else
-      hipLaunchKernelGGL((attn_fwd_hd64_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
+      SFM_LAUNCH((attn_fwd_hd64_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
                          koff, voff, qkv_batch_stride, o_batch_stride, sl2);
   } else {
     dim3 grid((T + 3) / 4, H, B), block(256);
     if (dtype == SFM_DT_F16)
-      hipLaunchKernelGGL((attn_fwd_generic_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd, ldqkv,
+      SFM_LAUNCH((attn_fwd_generic_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd, ldqkv,
                          ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);
     else
-      hipLaunchKernelGGL((attn_fwd_generic_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd,
+      SFM_LAUNCH((attn_fwd_generic_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd,
                          ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);
   }
   SFM_CHECK_LAUNCH();

@@ -152,8 +152,8 @@ extern "C" int sfm_framed_gemm_f32(const float* sig, const float* Wt, const floa
   p.B = B; p.M = M; p.Ls = Ls; p.hop = hop; p.padl = padl; p.K = K; p.Kpad = Kpad; p.N = N; p.Npad = Npad;
   p.nsplit = nsplit; p.mode = mode; p.out_f32 = out_f32; p.gn_group = gn_group;
   dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM, B), block(256);
-  if (dtype == SFM_DT_F16) hipLaunchKernelGGL((framed_gemm_kernel<F16>), grid, block, 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((framed_gemm_kernel<BF16>), grid, block, 0, (hipStream_t)stream, p);
+  if (dtype == SFM_DT_F16) SFM_LAUNCH((framed_gemm_kernel<F16>), grid, block, 0, (hipStream_t)stream, p);
+  else SFM_LAUNCH((framed_gemm_kernel<BF16>), grid, block, 0, (hipStream_t)stream, p);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
 }

@@ -222,10 +222,10 @@ static int launch_gemm16(const GemmParams& p, int bn, hipStream_t stream) {
   dim3 block(256);
   if (bn == 128) {
     dim3 grid((p.epi == EPI_GLU ? 2 * p.N + 127 : p.N + 127) / 128, (p.Lout + BM - 1) / BM, p.B);
-    hipLaunchKernelGGL((gemm16_kernel<T, 128>), grid, block, 0, stream, p);
+    SFM_LAUNCH((gemm16_kernel<T, 128>), grid, block, 0, stream, p);
   } else {
     dim3 grid((p.N + 63) / 64, (p.Lout + BM - 1) / BM, p.B);
-    hipLaunchKernelGGL((gemm16_kernel<T, 64>), grid, block, 0, stream, p);
+    SFM_LAUNCH((gemm16_kernel<T, 64>), grid, block, 0, stream, p);
   }
   SFM_CHECK_LAUNCH();
   return SFM_OK;

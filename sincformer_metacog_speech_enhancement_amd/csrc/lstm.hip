@@ -74,11 +74,11 @@ extern "C" int sfm_bilstm_layer(const float* xg, const float* whh, float* out, i
   if (!xg || !whh || !out) return SFM_ERR_ARG;
   if (B <= 0 || T <= 0) return SFM_ERR_SHAPE;
   if (H == 128) {
-    hipLaunchKernelGGL((bilstm_layer_kernel<128>), dim3(2, B), dim3(1024), 0, (hipStream_t)stream, xg, whh, out, T);
+    SFM_LAUNCH((bilstm_layer_kernel<128>), dim3(2, B), dim3(1024), 0, (hipStream_t)stream, xg, whh, out, T);
   } else if (H == 64) {
-    hipLaunchKernelGGL((bilstm_layer_kernel<64>), dim3(2, B), dim3(512), 0, (hipStream_t)stream, xg, whh, out, T);
+    SFM_LAUNCH((bilstm_layer_kernel<64>), dim3(2, B), dim3(512), 0, (hipStream_t)stream, xg, whh, out, T);
   } else if (H == 32) {
-    hipLaunchKernelGGL((bilstm_layer_kernel<32>), dim3(2, B), dim3(256), 0, (hipStream_t)stream, xg, whh, out, T);
+    SFM_LAUNCH((bilstm_layer_kernel<32>), dim3(2, B), dim3(256), 0, (hipStream_t)stream, xg, whh, out, T);
   } else {
     return SFM_ERR_SHAPE;
   }

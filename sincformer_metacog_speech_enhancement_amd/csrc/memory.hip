@@ -124,7 +124,7 @@ extern "C" int sfm_memory_fwd(const float* emb, const float* params, float* bias
   if (B <= 0 || key_dim <= 0 || key_dim > MEM_MAXD || value_dim <= 0 || value_dim > MEM_MAXD || slots <= 0 ||
       slots > MEM_MAXD)
     return SFM_ERR_SHAPE;
-  hipLaunchKernelGGL(memory_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, params, bias_out, gate_out,
+  SFM_LAUNCH(memory_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, params, bias_out, gate_out,
                      top_idx, sim_out, key_dim, value_dim, slots, temperature);
   SFM_CHECK_LAUNCH();
   return SFM_OK;

@@ -51,10 +51,10 @@ extern "C" int sfm_layernorm(const float* x, const float* w, const float* b, voi
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
   dim3 grid((M + 3) / 4), block(256);
   if (dtype == SFM_DT_F16)
-    hipLaunchKernelGGL((layernorm_kernel<F16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M, D,
+    SFM_LAUNCH((layernorm_kernel<F16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M, D,
                        ldx, ld16, ld32, eps, act);
   else
-    hipLaunchKernelGGL((layernorm_kernel<BF16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M,
+    SFM_LAUNCH((layernorm_kernel<BF16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M,
                        D, ldx, ld16, ld32, eps, act);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -99,7 +99,7 @@ extern "C" int sfm_gn_finalize(const float* partial, const float* w, const float
   if (!partial || !w || !b || !scale || !shift) return SFM_ERR_ARG;
   if (B <= 0 || P <= 0 || G <= 0 || C % G != 0) return SFM_ERR_SHAPE;
   double count = (double)rows * (double)(C / G);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, (hipStream_t)stream, partial, w, b, scale, shift, P,
+  SFM_LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(64), 0, (hipStream_t)stream, partial, w, b, scale, shift, P,
                      G, C, count, eps);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -179,10 +179,10 @@ extern "C" int sfm_gn_apply(const void* x1, const float* sc1, const float* sh1, 
   long long nb = (total8 + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (dtype == SFM_DT_F16)
-    hipLaunchKernelGGL((gn_apply_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x1, sc1, sh1, x2,
+    SFM_LAUNCH((gn_apply_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x1, sc1, sh1, x2,
                        sc2, sh2, out, rows_per_batch, C, total8, in_f32, out_f32, act);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x1, sc1, sh1,
+    SFM_LAUNCH((gn_apply_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x1, sc1, sh1,
                        x2, sc2, sh2, out, rows_per_batch, C, total8, in_f32, out_f32, act);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -282,12 +282,12 @@ extern "C" int sfm_dwconv_bn_swish(const void* x, const float* wdw, const float*
   if (dtype == SFM_DT_F16) {
     e = hipFuncSetAttribute((const void*)dwconv_bn_swish_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return SFM_ERR_LAUNCH;
-    hipLaunchKernelGGL((dwconv_bn_swish_kernel<F16>), grid, block, lds, (hipStream_t)stream, (const u16*)x, wdw, bdw,
+    SFM_LAUNCH((dwconv_bn_swish_kernel<F16>), grid, block, lds, (hipStream_t)stream, (const u16*)x, wdw, bdw,
                        bnw, bnb, bnm, bnv, (u16*)out, T, C, KS, eps);
   } else {
     e = hipFuncSetAttribute((const void*)dwconv_bn_swish_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return SFM_ERR_LAUNCH;
-    hipLaunchKernelGGL((dwconv_bn_swish_kernel<BF16>), grid, block, lds, (hipStream_t)stream, (const u16*)x, wdw, bdw,
+    SFM_LAUNCH((dwconv_bn_swish_kernel<BF16>), grid, block, lds, (hipStream_t)stream, (const u16*)x, wdw, bdw,
                        bnw, bnb, bnm, bnv, (u16*)out, T, C, KS, eps);
   }
   SFM_CHECK_LAUNCH();
@@ -317,10 +317,10 @@ extern "C" int sfm_convert_rows(const float* src, void* dst, long long M, int C,
   long long nb = (M * Cz + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (dtype == SFM_DT_F16)
-    hipLaunchKernelGGL((convert_rows_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src,
+    SFM_LAUNCH((convert_rows_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src,
                        (u16*)dst, M, C, Cz, ld_src, ld_dst);
   else
-    hipLaunchKernelGGL((convert_rows_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src,
+    SFM_LAUNCH((convert_rows_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src,
                        (u16*)dst, M, C, Cz, ld_src, ld_dst);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -364,10 +364,10 @@ extern "C" int sfm_transpose(const void* src, void* dst, int B, int R, int C, lo
   if (B <= 0 || R <= 0 || C <= 0) return SFM_ERR_SHAPE;
   dim3 grid((C + 31) / 32, (R + 31) / 32, B), block(256);
   if (dtype == SFM_DT_F16)
-    hipLaunchKernelGGL((transpose_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, dst, R, C, src_batch, src_row,
+    SFM_LAUNCH((transpose_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, dst, R, C, src_batch, src_row,
                        dst_batch, dst_row, src_f32, dst_f32);
   else
-    hipLaunchKernelGGL((transpose_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, dst, R, C, src_batch,
+    SFM_LAUNCH((transpose_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, dst, R, C, src_batch,
                        src_row, dst_batch, dst_row, src_f32, dst_f32);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -397,10 +397,10 @@ extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B,
   if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return SFM_ERR_SHAPE;
   dim3 grid((C + 255) / 256, Tout, B), block(256);
   if (dtype == SFM_DT_F16)
-    hipLaunchKernelGGL((pool_time_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin, Tout,
+    SFM_LAUNCH((pool_time_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin, Tout,
                        C, ld_src, ld_dst);
   else
-    hipLaunchKernelGGL((pool_time_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin,
+    SFM_LAUNCH((pool_time_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin,
                        Tout, C, ld_src, ld_dst);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -436,10 +436,10 @@ extern "C" int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst
   long long nb = (M * (2 * F + zpad) + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (dtype == SFM_DT_F16)
-    hipLaunchKernelGGL((stft_lognorm_pack_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
+    SFM_LAUNCH((stft_lognorm_pack_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
                        (u16*)dst, M, F, zpad, ld_dst);
   else
-    hipLaunchKernelGGL((stft_lognorm_pack_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
+    SFM_LAUNCH((stft_lognorm_pack_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
                        (u16*)dst, M, F, zpad, ld_dst);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -486,7 +486,7 @@ extern "C" int sfm_polar_mask(const float* lm, const float* lp, const float* mag
   if (total <= 0) return SFM_ERR_SHAPE;
   long long nb = (total + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(polar_mask_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lm, lp, mag_bias, nr, ni,
+  SFM_LAUNCH(polar_mask_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lm, lp, mag_bias, nr, ni,
                      mr, mi, er, ei, mmag, rows_per_batch, F, total, phase_scale, ld_logits, ld_enh);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -509,7 +509,7 @@ extern "C" int sfm_complex_mul(const float* sr, const float* si, const float* mr
   if (total <= 0) return SFM_ERR_SHAPE;
   long long nb = (total + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(complex_mul_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sr, si, mr, mi, er, ei,
+  SFM_LAUNCH(complex_mul_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sr, si, mr, mi, er, ei,
                      total);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -546,7 +546,7 @@ extern "C" int sfm_istft_ola(const float* frames, const float* win2, float* out,
                              int win, long long ld_frames, void* stream) {
   if (!frames || !win2 || !out) return SFM_ERR_ARG;
   if (B <= 0 || T <= 0 || L <= 0 || hop <= 0 || win <= 0 || win > n_fft) return SFM_ERR_SHAPE;
-  hipLaunchKernelGGL(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, frames, win2, out,
+  SFM_LAUNCH(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, frames, win2, out,
                      T, L, n_fft, hop, win, ld_frames);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -573,7 +573,7 @@ extern "C" int sfm_pack_spec(const float* re, const float* im, float* dst, long 
   if (M <= 0 || F <= 0 || ld < 2 * F) return SFM_ERR_SHAPE;
   long long nb = (M * ld + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(pack_spec_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im, dst, M, F, ld,
+  SFM_LAUNCH(pack_spec_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im, dst, M, F, ld,
                      ld_src);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
@@ -630,7 +630,7 @@ extern "C" int sfm_sinc_filters(const float* low_hz, const float* band_hz, const
                                 float min_band_hz, void* stream) {
   if (!low_hz || !band_hz || !window || !n_ || (!filt && !Wt)) return SFM_ERR_ARG;
   if (C <= 0 || K <= 0 || K > 512 || (K & 1) == 0 || (Wt && Npad < C)) return SFM_ERR_SHAPE;
-  hipLaunchKernelGGL(sinc_filters_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, low_hz, band_hz, window, n_, filt,
+  SFM_LAUNCH(sinc_filters_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, low_hz, band_hz, window, n_, filt,
                      Wt, C, K, Npad, sample_rate, min_low_hz, min_band_hz);
   SFM_CHECK_LAUNCH();
   return SFM_OK;

@@ -78,8 +78,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-#define SFM_CHECK_LAUNCH()                                 \
-  do {                                                     \
-    hipError_t e__ = hipGetLastError();                    \
-    if (e__ != hipSuccess) return SFM_ERR_LAUNCH;          \
+// hipGetLastError() is sticky on ROCm 7 (it reports the last *error* of any earlier runtime call
+// in this thread, e.g. a benign hipErrorNotReady from an event query made by the caller's
+// framework), so the state is cleared right before the launch and read right after it.
+#define SFM_LAUNCH(kernel, grid, block, shmem, stream, ...)                    \
+  do {                                                                         \
+    (void)hipGetLastError();                                                   \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);       \
+    if (hipGetLastError() != hipSuccess) return SFM_ERR_LAUNCH;                \
   } while (0)
+#define SFM_CHECK_LAUNCH() do { } while (0)

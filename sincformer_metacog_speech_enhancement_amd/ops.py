@@ -54,6 +54,109 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class KernelProfiler:
+    """Optional HIP-event timing of individual launches (bench.py / profiling only).
+    Events are recorded on the current torch stream, i.e. the stream the kernels are
+    enqueued on.  enable(None) instruments every family, enable({"attention"}) one."""
+
+    def __init__(self):
+        self.families = set()
+        self.all = False
+        self.records = []
+
+    def enable(self, families=None):
+        self.all = families is None
+        self.families = set(families or ())
+        self.records = []
+
+    def disable(self):
+        self.all = False
+        self.families = set()
+
+    def active(self, name):
+        return self.all or name in self.families
+
+    def summary(self):
+        """{family: dict(n, ms_total, ms_avg, flops, bytes)} — synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, fl, by in self.records:
+            d = out.setdefault(name, {"n": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["n"] += 1
+            d["ms_total"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        for d in out.values():
+            d["ms_avg"] = d["ms_total"] / max(d["n"], 1)
+        return out
+
+
+profiler = KernelProfiler()
+
+
+def _call(name, fn, args, flops=0.0, nbytes=0.0):
+    if profiler.active(name):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        profiler.records.append((name, e0, e1, float(flops), float(nbytes)))
+    else:
+        rc = fn(*args)
+    _lib.check(rc, name)
+
+
+
+def _cost_of(name, v):
+    """algorithmic (flops, bytes) of one launch, from the wrapper's local variables
+    (bytes = each operand read once + each result written once)."""
+    try:
+        if name == "gemm16":
+            pw = v["pw"]
+            ncols = pw.Npad if pw.glu else pw.N
+            rows = v["B"] * v["Lout"]
+            fl = 2.0 * rows * ncols * pw.K
+            osz = 4 if v["out"].dtype == torch.float32 else 2
+            by = v["B"] * v["Lin"] * pw.cin * 2 + pw.Npad * pw.Kpad * 2 + rows * pw.N * osz
+            if v.get("resid") is not None:
+                by += rows * pw.N * 4
+            return fl, by
+        if name == "framed_gemm_f32":
+            rows = v["B"] * v["M"]
+            osz = 4 if v["out"].dtype == torch.float32 else 2
+            return 2.0 * rows * v["N"] * v["K"], v["B"] * v["Ls"] * 4 + rows * v["N"] * osz
+        if name == "attention_fwd":
+            B, T, H, hd = v["B"], v["T"], v["H"], v["hd"]
+            return 4.0 * B * H * T * T * hd, 4.0 * B * T * H * hd * 2
+        if name == "layernorm":
+            M, D = v["M"], v["D"]
+            return 8.0 * M * D, M * D * (4 + (2 if v["out16"] is not None else 0) + (4 if v["out32"] is not None else 0))
+        if name == "gn_apply":
+            n = v["Bn"] * v["rows"] * v["C"]
+            isz = 4 if v["in_f32"] else 2
+            osz = 4 if v["out_f32"] else 2
+            return 10.0 * n, n * (isz * (2 if v["x2"] is not None else 1) + osz)
+        if name == "dwconv_bn_swish":
+            n = v["B"] * v["T"] * v["C"]
+            return 2.0 * n * v["KS"], n * 4
+        if name == "bilstm_layer":
+            B, T, H = v["B"], v["T"], v["H"]
+            return 2.0 * B * T * 2 * 4 * H * H, B * T * (8 * H + 2 * H) * 4
+        if name == "pool_time":
+            return 0.0, v["B"] * (v["Tin"] + v["Tout"]) * v["C"] * 4
+        if name == "polar_mask":
+            n = v["B"] * v["rows"] * v["F"]
+            return 20.0 * n, n * 4 * 8
+        if name == "stft_lognorm_pack":
+            return 0.0, v["M"] * v["F"] * (8 + 4)
+        if name == "istft_ola":
+            return 0.0, v["B"] * v["Ln"] * 12
+    except Exception:
+        pass
+    return 0.0, 0.0
+
+
 # ---------------------------------------------------------------------------
 # weight packing
 # ---------------------------------------------------------------------------
@@ -108,10 +211,10 @@ def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda
     cin = pw.cin
     lda = cin if lda is None else lda
     out_f32 = 1 if out.dtype == torch.float32 else 0
-    rc = L.sfm_gemm16(_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin, lda,
+    _call("gemm16", L.sfm_gemm16, (_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin, lda,
                       pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo, o_batch_stride, ldr, r_batch_stride,
-                      float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _stream())
-    _lib.check(rc, "sfm_gemm16")
+                      float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _stream()),
+          *_cost_of("gemm16", locals()))
     return out
 
 
@@ -132,10 +235,10 @@ def framed_gemm(sig, Wt, out, *, B, M, Ls, sig_batch_stride, hop, padl, K, N, o_
     L = _lib.load()
     Kpad, Npad = Wt.shape
     out_f32 = 1 if out.dtype == torch.float32 else 0
-    rc = L.sfm_framed_gemm_f32(_p(sig), _p(Wt), _p(bias), _p(out), _p(out2), _p(gn_partial), B, M, Ls,
+    _call("framed_gemm_f32", L.sfm_framed_gemm_f32, (_p(sig), _p(Wt), _p(bias), _p(out), _p(out2), _p(gn_partial), B, M, Ls,
                                sig_batch_stride, hop, padl, K, Kpad, N, Npad, nsplit, o_batch_stride, ldm, ldn, mode,
-                               out_f32, gn_group, _dt(), _stream())
-    _lib.check(rc, "sfm_framed_gemm_f32")
+                               out_f32, gn_group, _dt(), _stream()),
+          *_cost_of("framed_gemm_f32", locals()))
     return out
 
 
@@ -155,28 +258,29 @@ def attention(qkv16, B, T, H, hd, out=None):
     ld = qkv16.stride(0)
     if out is None:
         out = torch.empty(B * T, D, device=qkv16.device, dtype=qkv16.dtype)
-    rc = L.sfm_attention_fwd(_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld, T * out.stride(0),
-                             1.0 / math.sqrt(hd), _dt(), _stream())
-    _lib.check(rc, "sfm_attention_fwd")
+    _call("attention_fwd", L.sfm_attention_fwd, (_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld, T * out.stride(0),
+                             1.0 / math.sqrt(hd), _dt(), _stream()),
+          *_cost_of("attention_fwd", locals()))
     return out
 
 
 def layernorm(x32, w, b, out16=None, out32=None, act=0, eps=1e-5):
+    """rows of x32 [M, >=D] are normalised over their first D = w.numel() columns."""
     _need_dev(x32)
     L = _lib.load()
-    M, D = x32.shape
-    rc = L.sfm_layernorm(_p(x32), _p(w), _p(b), _p(out16), _p(out32), M, D, x32.stride(0),
+    M, D = x32.shape[0], w.numel()
+    _call("layernorm", L.sfm_layernorm, (_p(x32), _p(w), _p(b), _p(out16), _p(out32), M, D, x32.stride(0),
                          out16.stride(0) if out16 is not None else 0, out32.stride(0) if out32 is not None else 0,
-                         eps, act, _dt(), _stream())
-    _lib.check(rc, "sfm_layernorm")
+                         eps, act, _dt(), _stream()),
+          *_cost_of("layernorm", locals()))
 
 
 def gn_finalize(partial, w, b, Bn, P, G, C, rows, eps=1e-5):
     L = _lib.load()
     scale = torch.empty(Bn, C, device=w.device, dtype=torch.float32)
     shift = torch.empty(Bn, C, device=w.device, dtype=torch.float32)
-    rc = L.sfm_gn_finalize(_p(partial), _p(w), _p(b), _p(scale), _p(shift), Bn, P, G, C, rows, eps, _stream())
-    _lib.check(rc, "sfm_gn_finalize")
+    _call("gn_finalize", L.sfm_gn_finalize, (_p(partial), _p(w), _p(b), _p(scale), _p(shift), Bn, P, G, C, rows, eps, _stream()),
+          *_cost_of("gn_finalize", locals()))
     return scale, shift
 
 
@@ -184,9 +288,9 @@ def gn_apply(x1, sc1, sh1, out, Bn, rows, C, act=0, x2=None, sc2=None, sh2=None)
     L = _lib.load()
     in_f32 = 1 if x1.dtype == torch.float32 else 0
     out_f32 = 1 if out.dtype == torch.float32 else 0
-    rc = L.sfm_gn_apply(_p(x1), _p(sc1), _p(sh1), _p(x2), _p(sc2), _p(sh2), _p(out), Bn, rows, C, in_f32, out_f32, act,
-                        _dt(), _stream())
-    _lib.check(rc, "sfm_gn_apply")
+    _call("gn_apply", L.sfm_gn_apply, (_p(x1), _p(sc1), _p(sh1), _p(x2), _p(sc2), _p(sh2), _p(out), Bn, rows, C, in_f32, out_f32, act,
+                        _dt(), _stream()),
+          *_cost_of("gn_apply", locals()))
     return out
 
 
@@ -195,64 +299,64 @@ def dwconv_bn_swish(x16, wdw, bdw, bnw, bnb, bnm, bnv, B, T, C, out=None, eps=1e
     KS = wdw.shape[-1]
     if out is None:
         out = torch.empty_like(x16)
-    rc = L.sfm_dwconv_bn_swish(_p(x16), _p(wdw), _p(bdw), _p(bnw), _p(bnb), _p(bnm), _p(bnv), _p(out), B, T, C, KS,
-                               eps, _dt(), _stream())
-    _lib.check(rc, "sfm_dwconv_bn_swish")
+    _call("dwconv_bn_swish", L.sfm_dwconv_bn_swish, (_p(x16), _p(wdw), _p(bdw), _p(bnw), _p(bnb), _p(bnm), _p(bnv), _p(out), B, T, C, KS,
+                               eps, _dt(), _stream()),
+          *_cost_of("dwconv_bn_swish", locals()))
     return out
 
 
 def convert_rows(src32, dst16, M, C, Cz, ld_src, ld_dst):
     L = _lib.load()
-    rc = L.sfm_convert_rows(_p(src32), _p(dst16), M, C, Cz, ld_src, ld_dst, _dt(), _stream())
-    _lib.check(rc, "sfm_convert_rows")
+    _call("convert_rows", L.sfm_convert_rows, (_p(src32), _p(dst16), M, C, Cz, ld_src, ld_dst, _dt(), _stream()),
+          *_cost_of("convert_rows", locals()))
 
 
 def transpose(src, dst, B, R, C, src_batch, src_row, dst_batch, dst_row):
     L = _lib.load()
-    rc = L.sfm_transpose(_p(src), _p(dst), B, R, C, src_batch, src_row, dst_batch, dst_row,
+    _call("transpose", L.sfm_transpose, (_p(src), _p(dst), B, R, C, src_batch, src_row, dst_batch, dst_row,
                          1 if src.dtype == torch.float32 else 0, 1 if dst.dtype == torch.float32 else 0, _dt(),
-                         _stream())
-    _lib.check(rc, "sfm_transpose")
+                         _stream()),
+          *_cost_of("transpose", locals()))
 
 
 def pool_time(src32, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst):
     L = _lib.load()
-    rc = L.sfm_pool_time(_p(src32), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src, ld_dst, _dt(), _stream())
-    _lib.check(rc, "sfm_pool_time")
+    _call("pool_time", L.sfm_pool_time, (_p(src32), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src, ld_dst, _dt(), _stream()),
+          *_cost_of("pool_time", locals()))
 
 
 def stft_lognorm_pack(re, im, dst16, M, F, zpad, ld_dst):
     L = _lib.load()
-    rc = L.sfm_stft_lognorm_pack(_p(re), _p(im), _p(dst16), M, F, zpad, ld_dst, _dt(), _stream())
-    _lib.check(rc, "sfm_stft_lognorm_pack")
+    _call("stft_lognorm_pack", L.sfm_stft_lognorm_pack, (_p(re), _p(im), _p(dst16), M, F, zpad, ld_dst, _dt(), _stream()),
+          *_cost_of("stft_lognorm_pack", locals()))
 
 
 def polar_mask(lm, lp, B, rows, F, phase_scale, ld_logits, mag_bias=None, nr=None, ni=None, mr=None, mi=None, er=None,
                ei=None, mmag=None, ld_enh=0):
     L = _lib.load()
-    rc = L.sfm_polar_mask(_p(lm), _p(lp), _p(mag_bias), _p(nr), _p(ni), _p(mr), _p(mi), _p(er), _p(ei), _p(mmag), B,
-                          rows, F, float(phase_scale), ld_logits, ld_enh, _stream())
-    _lib.check(rc, "sfm_polar_mask")
+    _call("polar_mask", L.sfm_polar_mask, (_p(lm), _p(lp), _p(mag_bias), _p(nr), _p(ni), _p(mr), _p(mi), _p(er), _p(ei), _p(mmag), B,
+                          rows, F, float(phase_scale), ld_logits, ld_enh, _stream()),
+          *_cost_of("polar_mask", locals()))
 
 
 def complex_mul(sr, si, mr, mi):
     L = _lib.load()
     er, ei = torch.empty_like(sr), torch.empty_like(sr)
-    rc = L.sfm_complex_mul(_p(sr), _p(si), _p(mr), _p(mi), _p(er), _p(ei), sr.numel(), _stream())
-    _lib.check(rc, "sfm_complex_mul")
+    _call("complex_mul", L.sfm_complex_mul, (_p(sr), _p(si), _p(mr), _p(mi), _p(er), _p(ei), sr.numel(), _stream()),
+          *_cost_of("complex_mul", locals()))
     return er, ei
 
 
 def istft_ola(frames, win2, out, B, T, Ln, n_fft, hop, win, ld_frames):
     L = _lib.load()
-    rc = L.sfm_istft_ola(_p(frames), _p(win2), _p(out), B, T, Ln, n_fft, hop, win, ld_frames, _stream())
-    _lib.check(rc, "sfm_istft_ola")
+    _call("istft_ola", L.sfm_istft_ola, (_p(frames), _p(win2), _p(out), B, T, Ln, n_fft, hop, win, ld_frames, _stream()),
+          *_cost_of("istft_ola", locals()))
 
 
 def pack_spec(re, im, dst, M, F, ld, ld_src):
     L = _lib.load()
-    rc = L.sfm_pack_spec(_p(re), _p(im), _p(dst), M, F, ld, ld_src, _stream())
-    _lib.check(rc, "sfm_pack_spec")
+    _call("pack_spec", L.sfm_pack_spec, (_p(re), _p(im), _p(dst), M, F, ld, ld_src, _stream()),
+          *_cost_of("pack_spec", locals()))
 
 
 def sinc_filters(low_hz, band_hz, window, n_, C, K, sample_rate, min_low_hz, min_band_hz, want_filt=True):
@@ -261,17 +365,17 @@ def sinc_filters(low_hz, band_hz, window, n_, C, K, sample_rate, min_low_hz, min
     Npad = round_up(C, 64)
     Wt = torch.zeros(round_up(K, 32), Npad, device=dev, dtype=torch.float32)
     filt = torch.empty(C, K, device=dev, dtype=torch.float32) if want_filt else None
-    rc = L.sfm_sinc_filters(_p(low_hz), _p(band_hz), _p(window), _p(n_), _p(filt), _p(Wt), C, K, Npad,
-                            float(sample_rate), float(min_low_hz), float(min_band_hz), _stream())
-    _lib.check(rc, "sfm_sinc_filters")
+    _call("sinc_filters", L.sfm_sinc_filters, (_p(low_hz), _p(band_hz), _p(window), _p(n_), _p(filt), _p(Wt), C, K, Npad,
+                            float(sample_rate), float(min_low_hz), float(min_band_hz), _stream()),
+          *_cost_of("sinc_filters", locals()))
     return filt, Wt
 
 
 def bilstm_layer(xg, whh, B, T, H):
     L = _lib.load()
     out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)
-    rc = L.sfm_bilstm_layer(_p(xg), _p(whh), _p(out), B, T, H, _dt(), _stream())
-    _lib.check(rc, "sfm_bilstm_layer")
+    _call("bilstm_layer", L.sfm_bilstm_layer, (_p(xg), _p(whh), _p(out), B, T, H, _dt(), _stream()),
+          *_cost_of("bilstm_layer", locals()))
     return out
 
 
@@ -283,9 +387,9 @@ def memory_fwd(emb, params, key_dim, value_dim, slots, temperature):
     gate = torch.empty(Bn, 1, device=dev, dtype=torch.float32)
     top = torch.empty(Bn, device=dev, dtype=torch.int32)
     sim = torch.empty(Bn, device=dev, dtype=torch.float32)
-    rc = L.sfm_memory_fwd(_p(emb), _p(params), _p(bias), _p(gate), _p(top), _p(sim), Bn, key_dim, value_dim, slots,
-                          float(temperature), _stream())
-    _lib.check(rc, "sfm_memory_fwd")
+    _call("memory_fwd", L.sfm_memory_fwd, (_p(emb), _p(params), _p(bias), _p(gate), _p(top), _p(sim), Bn, key_dim, value_dim, slots,
+                          float(temperature), _stream()),
+          *_cost_of("memory_fwd", locals()))
     return bias, gate, top, sim
 
 

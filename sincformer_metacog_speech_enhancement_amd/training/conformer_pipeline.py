@@ -1,0 +1,155 @@
+"""Host-side mirror of the model/STFT part of training/conformer_pipeline.py
+(batch_stft :196, batch_istft :205, SpeechEnhancer :218-301) plus the
+inference half of ConformerPipeline (:611-685) and the north-star agent
+composition (EnhancementPath; SURVEY.md §3.3 with the glue of DESIGN.md).
+The data loaders / optimiser loop of the reference are out of scope.
+"""
+import math
+import os
+import numpy as np
+import torch
+from torch import nn
+
+from .. import config, functional as Fn, ops
+from .._hostmod import HipModule
+from ..models.conformer import ConformerBlock
+from ..agents.perception import PerceptionAgent
+from ..agents.cpea import CorrelationPhaseEstimationAgent
+from ..agents.msa import MaskSynthesisAgent
+from ..agents.memory import EpisodicMemory
+
+
+def batch_stft(waveform, fft_size, hop_size, frame_size):
+    """training/conformer_pipeline.py:196-202 -> (real, imag) each [B, T, fft_size/2+1] fp32
+    (contiguous; the reference returns transposed views of [B, F, T])."""
+    if not waveform.is_cuda:
+        raise RuntimeError("batch_stft: HIP path needs a device tensor (no CPU fallback)")
+    return Fn.stft(waveform.float(), fft_size, hop_size, frame_size)
+
+
+def batch_istft(stft_real, stft_imag, fft_size, hop_size, frame_size, length):
+    """training/conformer_pipeline.py:205-211 -> [B, length] fp32."""
+    if not stft_real.is_cuda:
+        raise RuntimeError("batch_istft: HIP path needs a device tensor (no CPU fallback)")
+    return Fn.istft(stft_real.float(), stft_imag.float(), length, fft_size, hop_size, frame_size)
+
+
+class SpeechEnhancer(HipModule):
+    """training/conformer_pipeline.py:218-301: LN(2F) -> Linear -> N ConformerBlocks -> LN ->
+    magnitude (sigmoid) / phase (tanh * pi/6) heads -> polar mask applied to the noisy STFT."""
+
+    def __init__(self, n_freq=None, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15):
+        super().__init__()
+        self.n_freq = n_freq or (config.FFT_SIZE // 2 + 1)
+        self.num_heads, self.num_blocks = num_heads, num_blocks
+        self.input_norm = nn.LayerNorm(2 * self.n_freq)
+        self.input_proj = nn.Linear(2 * self.n_freq, d_model)
+        self.blocks = nn.ModuleList([ConformerBlock(d_model, num_heads, d_ff, kernel_size, dropout)
+                                     for _ in range(num_blocks)])
+        self.output_norm = nn.LayerNorm(d_model)
+        self.mag_head = nn.Linear(d_model, self.n_freq)
+        self.phase_head = nn.Linear(d_model, self.n_freq)
+
+    def _pack(self, sd):
+        F2 = 2 * self.n_freq
+        heads_w = torch.cat([sd["mag_head.weight"], sd["phase_head.weight"]], dim=0)
+        heads_b = torch.cat([sd["mag_head.bias"], sd["phase_head.bias"]], dim=0)
+        return {"in_w": sd["input_norm.weight"].float().contiguous(), "in_b": sd["input_norm.bias"].float().contiguous(),
+                "proj": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(F2, 32)),
+                "blocks": [Fn.pack_block(Fn.sub(sd, "blocks.%d" % i)) for i in range(self.num_blocks)],
+                "on_w": sd["output_norm.weight"].float().contiguous(), "on_b": sd["output_norm.bias"].float().contiguous(),
+                "heads": ops.pack_linear(heads_w, heads_b)}
+
+    def forward(self, noisy_real, noisy_imag):
+        self._require_device(noisy_real, noisy_imag)
+        self._require_inference()
+        pk = self._packed(self._pack)
+        nr, ni = noisy_real.float().contiguous(), noisy_imag.float().contiguous()
+        B, T, F = nr.shape
+        M = B * T
+        dev = nr.device
+        ldc = ops.round_up(2 * F, 8)
+        cat = torch.empty(M, ldc, device=dev, dtype=torch.float32)
+        ops.pack_spec(nr, ni, cat, M, F, ldc, F)
+        ld16 = pk["proj"].Kpad
+        x16 = torch.zeros(M, ld16, device=dev, dtype=ops.compute_dtype())
+        ops.layernorm(cat, pk["in_w"], pk["in_b"], out16=x16)            # D = 2F columns, pad stays zero
+        x = ops.linear16(x16, pk["proj"], out_dtype=torch.float32)
+        for bp in pk["blocks"]:
+            x = Fn.block_forward(x, bp, B, T, self.num_heads)
+        h16 = Fn._ln16(x, pk["on_w"], pk["on_b"])
+        logits = ops.linear16(h16, pk["heads"], out_dtype=torch.float32)   # [M, 2F] = mag | phase
+        er = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+        ei = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+        mm = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+        ops.polar_mask(logits, logits[:, F:], B, T, F, math.pi / 6, logits.stride(0), nr=nr, ni=ni, er=er, ei=ei,
+                       mmag=mm, ld_enh=F)
+        return er, ei, mm
+
+    # LayerNorm over 2F needs D passed explicitly: ops.layernorm infers D from x32.shape[1]
+    # (cat has ldc >= 2F columns), so view the valid columns.
+
+
+class EnhancementPath(HipModule):
+    """North-star composition: PerceptionAgent -> (pool to STFT frames) -> CPEA -> STFT ->
+    [EpisodicMemory] -> MaskSynthesisAgent -> apply_mask -> iSTFT, fused in the internal
+    channels-last layouts (functional.enhance_path).  Glue G1-G3: DESIGN.md."""
+
+    def __init__(self, sample_rate=16000, use_memory=False):
+        super().__init__()
+        self.perception = PerceptionAgent(sample_rate=sample_rate)
+        self.cpea = CorrelationPhaseEstimationAgent()
+        self.msa = MaskSynthesisAgent()
+        self.memory = EpisodicMemory() if use_memory else None
+        self.sample_rate = sample_rate
+
+    def _pack(self, sd):
+        packs = {"pa": Fn.pack_perception(Fn.sub(sd, "perception"), self.sample_rate),
+                 "cpea": Fn.pack_cpea(Fn.sub(sd, "cpea"), self.cpea.num_layers),
+                 "msa": Fn.pack_msa(Fn.sub(sd, "msa"), self.msa.conformer.num_blocks)}
+        if self.memory is not None:
+            m = self.memory
+            packs["memory"] = (Fn.pack_memory_params(Fn.sub(sd, "memory")), m.key_dim, m.value_dim, m.num_slots,
+                               m.temperature)
+        return packs
+
+    def _pack_key(self):
+        return tuple([ops.compute_dtype()] + [(p.data_ptr(), p._version) for p in self.parameters()] +
+                     [(b.data_ptr(), b._version) for n, b in self.named_buffers() if "usage" not in n and "num_queries" not in n])
+
+    def forward(self, waveform, want=("mask", "wave")):
+        self._require_device(waveform)
+        self._require_inference()
+        packs = self._packed(self._pack)
+        return Fn.enhance_path(waveform.float(), packs, H=self.msa.conformer.num_heads,
+                               use_memory=self.memory is not None, want=want)
+
+
+class ConformerPipeline:
+    """Inference half of training/conformer_pipeline.py:308-685 (load_model :628, enhance_signal :653)."""
+
+    def __init__(self, fs=None, device=None):
+        self.fs = fs or config.SAMPLE_RATE
+        self.fft_size, self.hop_size, self.frame_size = config.FFT_SIZE, config.HOP_SIZE, config.FRAME_SIZE
+        if not torch.cuda.is_available():
+            raise RuntimeError("ConformerPipeline (HIP build) needs an MI355X; there is no CPU fallback")
+        self.device = torch.device(device or "cuda")
+        self.model = None
+
+    def load_model(self, path):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        self.model = SpeechEnhancer(n_freq=self.fft_size // 2 + 1, d_model=256, num_blocks=4, num_heads=4, d_ff=1024,
+                                    kernel_size=31, dropout=0.15)
+        self.model.load_state_dict(ckpt["model_state"])
+        self.model.to(self.device).eval()
+
+    @torch.no_grad()
+    def enhance_signal(self, noisy_signal):
+        if self.model is None:
+            raise RuntimeError("No model loaded.")
+        self.model.eval()
+        x = torch.from_numpy(np.asarray(noisy_signal, dtype=np.float32)).unsqueeze(0).to(self.device)
+        nr, ni = batch_stft(x, self.fft_size, self.hop_size, self.frame_size)
+        er, ei, _ = self.model(nr, ni)
+        y = batch_istft(er, ei, self.fft_size, self.hop_size, self.frame_size, length=len(noisy_signal))
+        return y.squeeze(0).cpu().numpy()

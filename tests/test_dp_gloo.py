@@ -1,0 +1,74 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise utterance sharding and the flat
+gradient all-reduce / NaN-flag agreement / global-norm clip used for data-parallel training."""
+import os
+import socket
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sincformer_metacog_speech_enhancement_amd import dp
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    sync = dp.FlatGradSynchronizer(model.parameters(), bucket_bytes=256)      # several buckets
+    assert len(sync.buckets) > 1
+    # rank-dependent gradients written through the views
+    sync.zero()
+    for i, p in enumerate(model.parameters()):
+        p.grad.add_(float(rank + 1) * (i + 1))
+    r = sync.sync(loss=torch.tensor(1.0), max_norm=None)
+    got = [float(p.grad.flatten()[0]) for p in model.parameters()]
+    exp = [(1 + 2) / 2.0 * (i + 1) for i in range(4)]
+    ok = np.allclose(got, exp) and not r["skip"]
+    # clip on the reduced gradient: same coefficient on both ranks
+    sync.zero()
+    for p in model.parameters():
+        p.grad.add_(float(rank + 1))
+    r2 = sync.sync(loss=torch.tensor(0.5), max_norm=5.0)
+    n = sum(p.numel() for p in model.parameters())
+    ok = ok and abs(r2["grad_norm"] - 1.5 * np.sqrt(n)) < 1e-4 and abs(float(torch.linalg.vector_norm(sync.flat)) - 5.0) < 1e-3
+    # a NaN loss on ONE rank makes BOTH ranks skip the step
+    sync.zero()
+    r3 = sync.sync(loss=torch.tensor(float("nan")) if rank == 1 else torch.tensor(1.0))
+    ok = ok and r3["skip"]
+    s, e = dp.shard_range(7, rank, world)
+    q.put((rank, ok, (s, e)))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[0][2] == (0, 4) and res[1][2] == (4, 7)
+
+
+def test_shard_range_covers_everything():
+    from sincformer_metacog_speech_enhancement_amd import dp
+    for n in (1, 7, 64, 255):
+        for w in (1, 2, 4, 8):
+            spans = [dp.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
