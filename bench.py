@@ -128,11 +128,11 @@ def main():
         # warm-up; the last warm-up step is instrumented per kernel family to find the dominant one
         for i in range(max(args.warmup, 1)):
             if i == max(args.warmup, 1) - 1:
-                ops.profiler.enable(None)
+                ops.profiler.enable(None, tags=bool(args.breakdown))
             step()
         breakdown = ops.profiler.summary()
         ops.profiler.disable()
-        dominant = max(breakdown, key=lambda k: breakdown[k]["ms_total"])
+        dominant = max((k for k in breakdown if "[" not in k), key=lambda k: breakdown[k]["ms_total"])
         ops.profiler.enable({dominant})
         barrier()
         t0 = time.perf_counter()
@@ -170,7 +170,8 @@ def main():
         if att:
             tf = att["flops"] / att["n"] / (att["ms_avg"] * 1e-3) / 1e12
             line["attention"] = {"tflops": tf, "frac_bf16_mfma_peak": tf / PEAKS["mfma16"], "avg_ms": att["ms_avg"]}
-        line["breakdown_ms_per_step"] = {k: round(v["ms_total"], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])}
+        line["breakdown_ms_per_step"] = {k: round(v["ms_total"], 4) for k, v in
+                                         sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]) if "[" not in k}
         print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
               (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:

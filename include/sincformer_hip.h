@@ -47,7 +47,7 @@ int sfm_abi_version(void);
  * :175,179 (real/imag proj), :185,187 (uncertainty head); agents/cpea.py:56-76.
  *   A   [B, Lin, Cin] 16-bit (position stride lda >= Cin, batch stride a_batch_stride; elements)
  *   W   [Npad, Kpad] 16-bit, row n = output channel, K order = (tap, cin);
- *       zero padded; Kpad % 32 == 0, Npad % 64 == 0
+ *       zero padded; Kpad % 64 == 0 (32 for variant 1), Npad % 64 == 0
  *   out row (b, l) = epi( sum_{tap,ci} A[b, l*stride-pad+tap, ci] W[n,(tap,ci)] + bias[n] )
  *   gn_partial (optional): per (batch, row-half-tile, group) {sum, sumsq} of the
  *       pre-activation outputs, [B][2*ceil(Lout/128)][N/gn_group][2] floats.
@@ -57,6 +57,19 @@ int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const
                long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
                int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
                int nsplit, int dtype, void* stream);
+
+/* Same contract with an explicit kernel variant: 0 auto, 1 register-staged (gemm16.hip),
+ * 2 / 3 LDS-DMA ring with 2 / 3 stages (gemm16v2.hip).  sfm_gemm16 == variant 0. */
+int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                  float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                  long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                  int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                  int nsplit, int dtype, int variant, void* stream);
+int sfm_gemm16_v1(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                  float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                  long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                  int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                  int nsplit, int dtype, void* stream);
 
 /* out[b,m,n] = bias[n] + sum_k sig[b, m*hop + k - padl] * Wt[k][n], exact fp32 on
  * v_mfma_f32_32x32x2_f32.  Replaces F.conv1d of SincConv1d (agents/perception.py:117),

@@ -232,7 +232,7 @@ static int launch_gemm16(const GemmParams& p, int bn, hipStream_t stream) {
 }
 
 // See include/sincformer_hip.h for the contract.
-extern "C" int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const float* resid,
+extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, void* out, const float* resid,
                           float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
                           long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
                           int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,

@@ -1,0 +1,395 @@
+// gemm16 v2 — same contract as gemm16.hip (sfm_gemm16), restructured for latency hiding:
+//   * operands go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`), no VGPR staging;
+//     the buffer descriptor's range check supplies the conv zero padding and the M tail
+//     (out-of-range rows/positions read as 0), so the loop has no predicates;
+//   * BK = 64 k-tiles in a STAGES-deep LDS ring, counted `s_waitcnt vmcnt(N)` + ONE raw
+//     `s_barrier` per k-tile: STAGES-1 tiles stay in flight under the MFMAs;
+//   * LDS rows are 128 B; the 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7)
+//     (applied on the SOURCE address, since LDS-DMA writes lane-linear), which makes the
+//     ds_read_b128 fragment reads conflict-free;
+//   * epilogue: accumulators -> per-wave fp32 LDS image -> 8-column vectors per thread:
+//     bias / activation / GLU / residual / GroupNorm partials, then 16-byte row stores;
+//   * XCD-aware block order: the N-tiles of one M-tile (same A rows) run on one XCD (L2 reuse).
+#include "sfm_common.h"
+
+#define EPI_NONE 0
+#define EPI_SWISH 1
+#define EPI_GELU 2
+#define EPI_RESID 3
+#define EPI_GLU 4
+#define EPI_SIGMOID 5
+#define EPI_TANH_SCALE 6
+#define EPI_SIGMA 7
+#define EPI_CPEA 8
+
+struct Gemm2Params {
+  const u16* A;
+  const u16* W;
+  const float* bias;
+  void* out;
+  const float* resid;
+  float* gn_partial;
+  long long a_batch_stride, o_batch_stride, r_batch_stride;
+  int B, Lout, Lin, Cin, lda, stride, pad, cin_shift;
+  int K, Kpad, N, Npad, ldo, ldr;
+  float alpha;
+  int epi, out_f32, gn_group, nsplit;
+  int nMt, nNt, a_records, w_records, vec_ok;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <class T, int BN, int STAGES>
+__global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
+  constexpr int BM = 128, BKB = 128;                 // k-tile: 64 elements = 128 bytes per row
+  constexpr int WN = BN / 2;                         // wave tile columns
+  constexpr int NJ = WN / 32;
+  constexpr int A_STAGE = BM * BKB, B_STAGE = BN * BKB, STAGE = A_STAGE + B_STAGE;
+  constexpr int NA = 4, NB = BN / 32;                // LDS-DMA instructions per wave per tile
+  constexpr int NLD = NA + NB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hl = lane >> 5;
+
+  // ---- XCD-aware tile order ----
+  const int total = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int ntile = id % p.nNt;
+  const int rest = id / p.nNt;
+  const int mtile = rest % p.nMt;
+  const int b = rest / p.nMt;
+  const int n0 = ntile * BN, l0 = mtile * BM;
+
+  auto a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)b * p.a_batch_stride), 0, p.a_records, 0x00020000);
+  auto w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_records, 0x00020000);
+
+  // ---- per-lane source coordinates of the LDS-DMA pieces (8 rows x 128 B per instruction) ----
+  int a_rowoff[NA], a_swz[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (wave * NA + i) * 8 + (lane >> 3);
+    const int pos0 = (l0 + row) * p.stride - p.pad;           // may be negative: wraps out of range -> 0
+    a_rowoff[i] = pos0 * p.lda * 2;                           // byte offset of the row's first element
+    a_swz[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;           // logical k element held by this lane's chunk
+  }
+  int b_rowoff[NB], b_swz[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (wave * NB + i) * 8 + (lane >> 3);
+    b_rowoff[i] = (n0 + row) * p.Kpad * 2;
+    b_swz[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  const bool contiguous = (p.lda == p.Cin) || (p.cin_shift >= 30);
+
+  auto issue = [&](int kt, int stage) {
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = kt * 64 + a_swz[i];
+      int eoff = contiguous ? j : ((j >> p.cin_shift) * p.lda + (j & (p.Cin - 1)));
+      // positions outside [0, Lin) of this batch fall outside the descriptor range (negative offsets
+      // wrap to > 2^31) and read as zero: that IS the conv zero padding; k beyond K is forced out of range
+      int voff = a_rowoff[i] + eoff * 2;
+      if (j >= p.K) voff = -1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(sa + (wave * NA + i) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int voff = b_rowoff[i] + (kt * 64 + b_swz[i]) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(sb + (wave * NB + i) * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = p.Kpad >> 6;
+  constexpr int D = STAGES - 1;                        // prefetch distance
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nt) issue(s, s);
+
+  // fragment read offsets (bytes) inside a stage
+  int fa_off[2][4], fb_off[NJ][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fa_off[i][s] = row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wn * WN + j * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb_off[j][s] = A_STAGE + row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+
+  int stage = 0;
+  for (int t = 0; t < nt; ++t) {
+    // tile t must have landed; up to D-1 younger tiles may stay in flight
+    const int younger = (nt - 1 - t) < (D - 1) ? (nt - 1 - t) : (D - 1);
+    if (younger >= 2) wait_vmcnt<2 * NLD>();
+    else if (younger == 1) wait_vmcnt<NLD>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + D < nt) {
+      int st = stage + D;
+      if (st >= STAGES) st -= STAGES;
+      issue(t + D, st);
+    }
+    const unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 fa[2], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sbase + fa_off[i][s]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sbase + fb_off[j][s]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    if (++stage == STAGES) stage = 0;
+  }
+
+  // ------------------------------ epilogue ------------------------------
+  __syncthreads();                                     // every wave is done reading the ring
+  constexpr int IMG_LD = WN + 4;                       // floats per image row
+  float* img = reinterpret_cast<float*>(smem) + wave * (64 * IMG_LD);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) img[(i * 32 + mfma_row(r, lane)) * IMG_LD + j * 32 + l31] = acc[i][j][r];
+  __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the wave's own image is complete
+  __builtin_amdgcn_wave_barrier();
+
+  const bool glu = (p.epi == EPI_GLU);
+  const int ecols = glu ? 32 : WN;                     // image columns that produce outputs
+  const int cpr = ecols >> 3;                          // 8-column chunks per row
+  const int rpp = 64 / cpr;                            // rows per pass
+  const int c8 = (lane % cpr) * 8, rsub = lane / cpr;
+  const int colb = n0 + wn * WN;                       // first packed column of this wave
+  const int ncol0 = glu ? ((colb >> 1) + c8) : (colb + c8);   // first output column of this thread
+  float bia[8], big[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;     // bias is padded to Npad
+    big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
+  }
+  float gsum = 0.f, gsq = 0.f;
+  const long long obase = (long long)b * p.o_batch_stride;
+  for (int r0 = 0; r0 < 64; r0 += rpp) {
+    const int row = r0 + rsub;
+    const int m = l0 + wm * 64 + row;
+    float v[8];
+    {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8 + 4]);
+      v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+      v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bia[e];
+    if (glu) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + 32 + c8]);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + 32 + c8 + 4]);
+      const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= sigmoid_f(g[e] + big[e]);
+    }
+    const bool mok = m < p.Lout;
+    if (p.gn_partial && mok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
+    }
+    switch (p.epi) {
+      case EPI_SWISH:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = swish_f(v[e]);
+        break;
+      case EPI_GELU:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        break;
+      case EPI_SIGMOID:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
+        break;
+      case EPI_TANH_SCALE:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p.alpha * tanhf(v[e]);
+        break;
+      case EPI_SIGMA:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = expf(0.5f * fminf(fmaxf(v[e], -10.f), 10.f));
+        break;
+      case EPI_CPEA:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (ncol0 + e < p.nsplit) ? sigmoid_f(v[e]) : p.alpha * tanhf(v[e]);
+        break;
+      default: break;
+    }
+    if (!mok) continue;
+    const long long orow = obase + (long long)m * p.ldo + ncol0;
+    if (p.vec_ok && ncol0 + 8 <= p.N) {
+      if (p.epi == EPI_RESID) {
+        const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
+        const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
+        const f32x4 r1v = *reinterpret_cast<const f32x4*>(rp + 4);
+        v[0] = r0v[0] + p.alpha * v[0]; v[1] = r0v[1] + p.alpha * v[1];
+        v[2] = r0v[2] + p.alpha * v[2]; v[3] = r0v[3] + p.alpha * v[3];
+        v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
+        v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
+      }
+      if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(p.out) + orow;
+        f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(op) = a;
+        *reinterpret_cast<f32x4*>(op + 4) = c;
+      } else {
+        u32x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (ncol0 + e < p.N) {
+          float y = v[e];
+          if (p.epi == EPI_RESID)
+            y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
+          if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
+          else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
+        }
+      }
+    }
+  }
+  if (p.gn_partial) {
+    // lanes with the same column chunk hold different rows: fold them, then fold the chunks of a group
+    for (int o = cpr; o < 64; o <<= 1) {
+      gsum += __shfl_xor(gsum, o, 64);
+      gsq += __shfl_xor(gsq, o, 64);
+    }
+    const int cpg = p.gn_group >> 3;                   // 8-column chunks per group (1, 2 or 4)
+    for (int o = 1; o < cpg; o <<= 1) {
+      gsum += __shfl_xor(gsum, o, 64);
+      gsq += __shfl_xor(gsq, o, 64);
+    }
+    if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N) {
+      const int ngroups = p.N / p.gn_group;
+      const long long slot = ((long long)b * (p.nMt * 2) + mtile * 2 + wm) * ngroups + ncol0 / p.gn_group;
+      p.gn_partial[slot * 2 + 0] = gsum;
+      p.gn_partial[slot * 2 + 1] = gsq;
+    }
+  }
+}
+
+template <class T, int BN, int STAGES>
+static int launch_v2(const Gemm2Params& p, hipStream_t stream) {
+  constexpr int ring = STAGES * (128 + BN) * 128, image = 4 * 64 * (BN / 2 + 4) * 4;
+  constexpr int lds = ring > image ? ring : image;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm16v2_kernel<T, BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(p.nMt * p.nNt * p.B), block(256);
+  SFM_LAUNCH((gemm16v2_kernel<T, BN, STAGES>), grid, block, lds, stream, p);
+  return SFM_OK;
+}
+
+extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                             float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                             long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                             int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                             int nsplit, int dtype, void* stream);
+
+// same contract as sfm_gemm16_v1 (include/sincformer_hip.h); `variant`: 0 = auto, 1 = v1 register-staged kernel,
+// 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU)
+extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                             float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                             long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                             int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                             int nsplit, int dtype, int variant, void* stream) {
+  if (!A || !W || !out) return SFM_ERR_ARG;
+  if (B <= 0 || Lout <= 0 || N <= 0) return SFM_ERR_SHAPE;
+  const long long a_rec = ((long long)(Lin - 1) * lda + Cin) * 2;
+  const long long w_rec = (long long)Npad * Kpad * 2;
+  const bool v2_ok = (Kpad % 64 == 0) && (Npad % 64 == 0) && a_rec < (1LL << 31) && w_rec < (1LL << 31) &&
+                     (!gn_partial || gn_group == 8 || gn_group == 16 || gn_group == 32) &&
+                     ((long long)Lout * stride * lda * 2 < (1LL << 31)) && (epi != EPI_GLU || Npad % 128 == 0);
+  if (variant == 1 || !v2_ok)
+    return sfm_gemm16_v1(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
+                         Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
+                         dtype, stream);
+  if (Cin % 8 != 0 || lda % 8 != 0 || lda < Cin) return SFM_ERR_SHAPE;
+  const int K = ksize * Cin;
+  if (K > Kpad) return SFM_ERR_SHAPE;
+  int shift = 30;
+  if (ksize > 1) {
+    if (Cin & (Cin - 1)) return SFM_ERR_SHAPE;
+    shift = 0;
+    while ((1 << shift) < Cin) ++shift;
+  }
+  if (epi == EPI_RESID && !resid) return SFM_ERR_ARG;
+  if (gn_partial && (N % gn_group) != 0) return SFM_ERR_SHAPE;
+  if (epi == EPI_GLU && Npad != 2 * N) return SFM_ERR_SHAPE;
+  Gemm2Params p;
+  p.A = (const u16*)A; p.W = (const u16*)W; p.bias = bias; p.out = out; p.resid = resid; p.gn_partial = gn_partial;
+  p.a_batch_stride = a_batch_stride; p.o_batch_stride = o_batch_stride; p.r_batch_stride = r_batch_stride;
+  p.B = B; p.Lout = Lout; p.Lin = Lin; p.Cin = Cin; p.lda = lda; p.stride = stride; p.pad = pad; p.cin_shift = shift;
+  p.K = K; p.Kpad = Kpad; p.N = N; p.Npad = Npad; p.ldo = ldo; p.ldr = ldr; p.alpha = alpha; p.epi = epi;
+  p.out_f32 = out_f32; p.gn_group = gn_group; p.nsplit = nsplit;
+  p.a_records = (int)a_rec; p.w_records = (int)w_rec;
+  const int osz = out_f32 ? 4 : 2;
+  const bool o_al = (((uintptr_t)out) % 16 == 0) && ((ldo * osz) % 16 == 0) && ((o_batch_stride * osz) % 16 == 0);
+  const bool r_al = (epi != EPI_RESID) || ((((uintptr_t)resid) % 16 == 0) && ((ldr * 4) % 16 == 0) && ((r_batch_stride * 4) % 16 == 0));
+  p.vec_ok = (o_al && r_al) ? 1 : 0;
+  const bool bn128 = (Npad % 128 == 0);
+  const int BNv = bn128 ? 128 : 64;
+  p.nMt = (Lout + 127) / 128;
+  p.nNt = Npad / BNv;
+  hipStream_t st = (hipStream_t)stream;
+  const bool s3 = (variant == 3);
+#define GO(TT)                                                         \
+  if (bn128) return s3 ? launch_v2<TT, 128, 3>(p, st) : launch_v2<TT, 128, 2>(p, st); \
+  else return s3 ? launch_v2<TT, 64, 3>(p, st) : launch_v2<TT, 64, 2>(p, st);
+  if (dtype == SFM_DT_BF16) { GO(BF16) }
+  if (dtype == SFM_DT_F16) { GO(F16) }
+#undef GO
+  return SFM_ERR_ARG;
+}
+
+extern "C" int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                          float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                          long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                          int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                          int nsplit, int dtype, void* stream) {
+  return sfm_gemm16_ex(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
+                       Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
+                       dtype, 0, stream);
+}

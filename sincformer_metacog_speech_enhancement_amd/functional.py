@@ -15,7 +15,7 @@ from . import ops
 
 N_FFT, HOP, WIN = 256, 80, 160
 N_FREQ = N_FFT // 2 + 1
-FUSE_LD = 1056           # 2*256 + 4*64 + 2*129 = 1026 -> padded to 33*32
+FUSE_LD = 1088           # 2*256 + 4*64 + 2*129 = 1026 -> padded to 17*64
 
 
 def _f32(t):
@@ -180,7 +180,7 @@ def block_forward(x32, pk, B, T, H, want16=False):
 def pack_complex_conformer(sd, num_blocks):
     nf2 = sd["input_proj.weight"].shape[1]
     return {"in": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"],
-                                  k_pad_to=ops.round_up(nf2, 32)),
+                                  k_pad_to=ops.round_up(nf2, 64)),
             "out": ops.pack_linear(sd["output_proj.weight"], sd["output_proj.bias"]),
             "blocks": [pack_block(sub(sd, "blocks.%d" % i)) for i in range(num_blocks)], "nf2": nf2}
 

@@ -7,6 +7,11 @@ infrastructure and is never imported from here.)
 import ctypes
 import os
 
+# torch must be imported BEFORE the shared library is dlopen'ed: torch ships its own
+# libamdhip64 (same SONAME as the system one).  Loading ours first would pull a second HIP
+# runtime into the process and every launch on a torch stream would then fail.
+import torch  # noqa: F401  (device memory / stream plumbing; see ops.py)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsincformer_hip.so")
 
@@ -19,6 +24,10 @@ c_f = ctypes.c_float
 SIGNATURES = {
     "sfm_abi_version": [],
     "sfm_gemm16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i,
+                   c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_gemm16_ex": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i,
+                   c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_gemm16_v1": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i,
                    c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_framed_gemm_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i,
                             c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_vp],

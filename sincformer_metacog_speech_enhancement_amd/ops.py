@@ -11,7 +11,14 @@ from . import lib as _lib
 EPI_NONE, EPI_SWISH, EPI_GELU, EPI_RESID, EPI_GLU, EPI_SIGMOID, EPI_TANH_SCALE, EPI_SIGMA, EPI_CPEA = range(9)
 
 _DT_ID = {torch.bfloat16: 0, torch.float16: 1}
-_state = {"dtype": torch.bfloat16}
+import os as _os
+_state = {"dtype": torch.bfloat16, "gemm_variant": int(_os.environ.get("SFM_GEMM_VARIANT", "0"))}
+
+
+def set_gemm_variant(v):
+    """0 auto, 1 register-staged kernel, 2/3 LDS-DMA ring with 2/3 stages (A/B testing)."""
+    _state["gemm_variant"] = int(v)
+
 
 
 def set_compute_dtype(dt):
@@ -63,8 +70,10 @@ class KernelProfiler:
         self.families = set()
         self.all = False
         self.records = []
+        self.tags = False
 
-    def enable(self, families=None):
+    def enable(self, families=None, tags=False):
+        self.tags = tags
         self.all = families is None
         self.families = set(families or ())
         self.records = []
@@ -94,7 +103,7 @@ class KernelProfiler:
 profiler = KernelProfiler()
 
 
-def _call(name, fn, args, flops=0.0, nbytes=0.0):
+def _call(name, fn, args, flops=0.0, nbytes=0.0, tag=None):
     if profiler.active(name):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -102,6 +111,8 @@ def _call(name, fn, args, flops=0.0, nbytes=0.0):
         rc = fn(*args)
         e1.record()
         profiler.records.append((name, e0, e1, float(flops), float(nbytes)))
+        if tag is not None and profiler.tags:
+            profiler.records.append(("%s[%s]" % (name, tag), e0, e1, float(flops), float(nbytes)))
     else:
         rc = fn(*args)
     _lib.check(rc, name)
@@ -121,11 +132,12 @@ def _cost_of(name, v):
             by = v["B"] * v["Lin"] * pw.cin * 2 + pw.Npad * pw.Kpad * 2 + rows * pw.N * osz
             if v.get("resid") is not None:
                 by += rows * pw.N * 4
-            return fl, by
+            return fl, by, "M%d N%d K%d k%d s%d epi%d o%d" % (rows, ncols, pw.K, pw.ksize, v["stride"], v["epi"], osz)
         if name == "framed_gemm_f32":
             rows = v["B"] * v["M"]
             osz = 4 if v["out"].dtype == torch.float32 else 2
-            return 2.0 * rows * v["N"] * v["K"], v["B"] * v["Ls"] * 4 + rows * v["N"] * osz
+            return (2.0 * rows * v["N"] * v["K"], v["B"] * v["Ls"] * 4 + rows * v["N"] * osz,
+                    "M%d N%d K%d hop%d" % (rows, v["N"], v["K"], v["hop"]))
         if name == "attention_fwd":
             B, T, H, hd = v["B"], v["T"], v["H"], v["hd"]
             return 4.0 * B * H * T * T * hd, 4.0 * B * T * H * hd * 2
@@ -187,7 +199,7 @@ def pack_linear(weight, bias=None, glu=False, k_pad_to=None, dtype=None):
         blk, t = idx // 64, idx % 64
         src = torch.where(t < 32, blk * 32 + t, C + blk * 32 + (t - 32))
         w, b = w[src], b[src]
-    Kpad = round_up(k_pad_to or K, 32)
+    Kpad = round_up(k_pad_to or K, 64)
     if glu or (N > 64 and round_up(N, 128) - N < 64):
         Npad = round_up(N, 128)          # 128-column tiles
     else:
@@ -211,9 +223,9 @@ def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda
     cin = pw.cin
     lda = cin if lda is None else lda
     out_f32 = 1 if out.dtype == torch.float32 else 0
-    _call("gemm16", L.sfm_gemm16, (_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin, lda,
+    _call("gemm16", L.sfm_gemm16_ex, (_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin, lda,
                       pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo, o_batch_stride, ldr, r_batch_stride,
-                      float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _stream()),
+                      float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _state["gemm_variant"], _stream()),
           *_cost_of("gemm16", locals()))
     return out
 

@@ -55,7 +55,7 @@ class SpeechEnhancer(HipModule):
         heads_w = torch.cat([sd["mag_head.weight"], sd["phase_head.weight"]], dim=0)
         heads_b = torch.cat([sd["mag_head.bias"], sd["phase_head.bias"]], dim=0)
         return {"in_w": sd["input_norm.weight"].float().contiguous(), "in_b": sd["input_norm.bias"].float().contiguous(),
-                "proj": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(F2, 32)),
+                "proj": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(F2, 64)),
                 "blocks": [Fn.pack_block(Fn.sub(sd, "blocks.%d" % i)) for i in range(self.num_blocks)],
                 "on_w": sd["output_norm.weight"].float().contiguous(), "on_b": sd["output_norm.bias"].float().contiguous(),
                 "heads": ops.pack_linear(heads_w, heads_b)}

@@ -95,8 +95,8 @@ def test_pack_linear_layouts():
     w = arr("pw", (200, 96), 1)
     b = arr("pb", (200,), 2)
     pk = ops.pack_linear(w, b)
-    assert pk.w.shape == (256, 96) and pk.N == 200 and pk.cin == 96 and pk.ksize == 1
-    assert maxerr(pk.w[:200].float(), w.half().float()) == 0 and float(pk.w[200:].abs().max()) == 0
+    assert pk.w.shape == (256, 128) and pk.N == 200 and pk.cin == 96 and pk.ksize == 1
+    assert maxerr(pk.w[:200, :96].float(), w.half().float()) == 0 and float(pk.w[200:].abs().max()) == 0 and float(pk.w[:, 96:].abs().max()) == 0
     assert maxerr(pk.bias[:200], b) == 0
     pk = ops.pack_linear(arr("p2", (129, 128), 3))
     assert pk.Npad == 192                                      # 64-column tiles when the 128 padding would waste >= 64
@@ -113,14 +113,14 @@ def test_pack_linear_layouts():
     wg, bg = arr("pg", (128, 32), 6), arr("pgb", (128,), 7)
     pk = ops.pack_linear(wg, bg, glu=True)
     assert pk.N == 64 and pk.Npad == 128 and pk.glu
-    assert maxerr(pk.w[0:32].float(), wg[0:32].half().float()) == 0
-    assert maxerr(pk.w[32:64].float(), wg[64:96].half().float()) == 0
-    assert maxerr(pk.w[64:96].float(), wg[32:64].half().float()) == 0
+    assert maxerr(pk.w[0:32, :32].float(), wg[0:32].half().float()) == 0
+    assert maxerr(pk.w[32:64, :32].float(), wg[64:96].half().float()) == 0
+    assert maxerr(pk.w[64:96, :32].float(), wg[32:64].half().float()) == 0
     assert maxerr(pk.bias[96:128], bg[96:128]) == 0
     with pytest.raises(ValueError):
         ops.pack_linear(arr("p3", (8, 1026), 8))                 # K % 8 != 0 needs k_pad_to
-    pk = ops.pack_linear(arr("p3", (8, 1026), 8), k_pad_to=1056)
-    assert pk.cin == 1056 and pk.Kpad == 1056
+    pk = ops.pack_linear(arr("p3", (8, 1026), 8), k_pad_to=1088)
+    assert pk.cin == 1088 and pk.Kpad == 1088
     ops.set_compute_dtype(torch.bfloat16)
 
 

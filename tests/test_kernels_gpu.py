@@ -53,10 +53,22 @@ def test_mfma_layout_identity(ops):
     report("mfma identity", out.cpu(), ref, 1e-6)
 
 
+VARIANTS = [1, 2, 3]          # gemm16 kernels: register-staged, LDS-DMA ring x2, x3
+
+
+@pytest.fixture(autouse=True)
+def _reset_variant(ops):
+    yield
+    ops.set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,K,N", [(300, 256, 256), (129, 1024, 256), (77, 64, 129), (513, 256, 1024), (40, 128, 64), (5, 64, 1)])
-def test_gemm16_plain(ops, dt, M, K, N):
+@pytest.mark.parametrize("M,K,N", [(300, 256, 256), (129, 1024, 256), (77, 64, 129), (513, 256, 1024), (40, 128, 64), (5, 64, 1),
+                                   (1000, 192, 384), (128, 64, 128)])
+def test_gemm16_plain(ops, dt, M, K, N, variant):
     ops.set_compute_dtype(dt)
+    ops.set_gemm_variant(variant)
     x = arr("gx", (M, K), 1)
     w = arr("gw", (N, K), 2) / math.sqrt(K)
     b = arr("gb", (N,), 3)
@@ -66,9 +78,28 @@ def test_gemm16_plain(ops, dt, M, K, N):
     report("gemm16 %s %dx%dx%d" % (dt, M, K, N), out.cpu(), ref, 2e-4)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_gemm16_strided_operand_views(ops, variant):
+    """A is a column slice of a wider buffer (lda > K), output goes into a column slice (ldo > N)"""
+    ops.set_compute_dtype(torch.float16)
+    ops.set_gemm_variant(variant)
+    M = 333
+    buf = arr("sv", (M, 256), 15)
+    w, b = arr("svw", (129, 128), 16) / 11.0, arr("svb", (129,), 17)
+    pw = ops.pack_linear(dev(w), dev(b))
+    x16 = dev(buf).half().contiguous()
+    out = torch.full((M, 300), 9.0, device="cuda", dtype=torch.float32)
+    ops.linear16(x16[:, 128:], pw, out=out[:, 100:229])
+    ref = q16(buf[:, 128:], torch.float16) @ q16(w, torch.float16).t() + b
+    report("gemm16 strided views v%d" % variant, out[:, 100:229].cpu(), ref, 2e-4)
+    assert float(out[:, :100].min()) == 9.0 and float(out[:, 229:].min()) == 9.0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm16_epilogues(ops, dt):
+def test_gemm16_epilogues(ops, dt, variant):
     ops.set_compute_dtype(dt)
+    ops.set_gemm_variant(variant)
     M, K, N = 200, 256, 256
     x, w, b = arr("ex", (M, K), 4), arr("ew", (N, K), 5) / 16.0, arr("eb", (N,), 6)
     xq, wq = q16(x, dt), q16(w, dt)
@@ -93,11 +124,13 @@ def test_gemm16_epilogues(ops, dt):
     report("epi glu", ops.linear16(xd, pg, epi=ops.EPI_GLU, out_dtype=torch.float32).cpu(), h[:, :256] * torch.sigmoid(h[:, 256:]), 5e-4)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,s,p,L", [(64, 128, 7, 2, 3, 301), (128, 128, 3, 1, 1, 150), (64, 128, 1, 2, 0, 301),
-                                              (256, 256, 5, 2, 2, 77), (256, 64, 3, 1, 1, 40)])
-def test_gemm16_conv_and_groupnorm(ops, dt, cin, cout, k, s, p, L):
+                                              (256, 256, 5, 2, 2, 77), (256, 64, 3, 1, 1, 40), (8, 16, 3, 1, 1, 50)])
+def test_gemm16_conv_and_groupnorm(ops, dt, cin, cout, k, s, p, L, variant):
     ops.set_compute_dtype(dt)
+    ops.set_gemm_variant(variant)
     B = 2
     x = arr("cx", (B, cin, L), 10)
     w = arr("cw", (cout, cin, k), 11) / math.sqrt(cin * k)
