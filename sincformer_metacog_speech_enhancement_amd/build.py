@@ -17,6 +17,9 @@ LIB = os.path.join(HERE, "libsincformer_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I", CSRC]
+# per-source extras: keep the attention accumulators in VGPRs (the softmax works on them with
+# VALU instructions; the default AGPR placement costs ~220 v_accvgpr moves per key tile)
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(src, dst, deps):
@@ -39,7 +42,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 

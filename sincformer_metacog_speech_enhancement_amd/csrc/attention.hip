@@ -20,6 +20,7 @@
 #define KS_ROW 72    // u16 elements: 144-byte K rows  (ds_read_b128 conflict-free)
 #define VS_ROW 96    // u16 elements: 192-byte V rows  (4 rows x 64 B tile the 256-B bank row for tr reads)
 #define OS_ROW 72
+#define DEFER_THR 4.0f
 
 template <class T>
 __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
@@ -95,45 +96,51 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     f32x16 s[2];
 #pragma unroll
     for (int kj = 0; kj < 2; ++kj) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kj][r] = 0.f;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[(kj * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
-        s[kj] = T::mfma(kf, qf[ks], s[kj]);
+        s[kj] = T::mfma(kf, qf[ks], ks == 0 ? zero : s[kj]);
       }
     }
     // ---- online softmax (row = query = lane&31; keys spread over regs and lane halves) ----
+    // Scores stay raw; the 1/sqrt(hd)*log2(e) factor is folded into the exp2 argument (one FMA).
+    // The running max is only raised when some row's max grew by more than DEFER_THR (log2 units):
+    // then O and l of every lane are rescaled (a wave-uniform, rare branch); otherwise P is formed
+    // against the old max (values up to 2^DEFER_THR, exact in floating point) and nothing is rescaled.
     const int kbase = kt * 64;
-    float mx = -1e30f;
+    if (kbase + 64 > Tlen) {                            // wave-uniform: only the last, partial tile masks keys
 #pragma unroll
-    for (int kj = 0; kj < 2; ++kj)
+      for (int kj = 0; kj < 2; ++kj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int key = kbase + kj * 32 + mfma_row(r, lane);
-        float v = s[kj][r] * scale_log2e;
-        v = (key < Tlen) ? v : -1e30f;
-        s[kj][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    float psum = 0.f;
+        for (int r = 0; r < 16; ++r)
+          if (kbase + kj * 32 + mfma_row(r, lane) >= Tlen) s[kj][r] = -3.0e38f;
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int kj = 0; kj < 2; ++kj)
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+    if (__any(mx > m_run + DEFER_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pv = exp2f(s[kj][r] - m_new);
-        s[kj][r] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+      for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
+        for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+    }
+    float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], scale_log2e, -m_run));
+      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][r], scale_log2e, -m_run));
+      s[0][r] = p0;
+      s[1][r] = p1;
+      psum0 += p0;
+      psum1 += p1;
+    }
+    l_run += psum0 + psum1;
 
     // ---- O^T += V^T P^T ----
 #pragma unroll

@@ -3,63 +3,97 @@
 // BOTH directions is done beforehand by one GEMM (xg [B, T, 2, 4H] fp32); this
 // kernel runs only the sequential recurrence.  Chains are independent per
 // (utterance, direction): one 8H-thread workgroup per chain keeps the whole
-// fp32 W_hh (4H x H) distributed in registers (H/2 weights per thread) and h in
-// LDS, so a time step costs one H/2-long FMA chain, three shuffles and ONE
-// workgroup barrier; nothing but xg / h traffic touches HBM.
-// thread = (unit j, gate q, k-half): the 8 threads of a unit sit in adjacent lanes.
+// fp32 W_hh (4H x H) in registers and h in LDS; nothing but xg / h touches HBM.
+// thread = (unit j, k-slice ks of H/8): it owns the 4 gate rows of its unit over
+// its slice (4 x H/8 weights), reads only H/8 values of h per step (LDS traffic
+// is what bounds the step), reduces the 4 partial sums over the unit's 8 adjacent
+// lanes with DPP adds, evaluates one gate per lane with a single fast sigmoid
+// (tanh(x) = 2 sigmoid(2x) - 1), and lane 0 of the unit updates c, h.  ONE
+// workgroup barrier per time step.
 #include "sfm_common.h"
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {          // v + v[permuted lane] (within a row of 16 lanes)
+  const int x = __builtin_bit_cast(int, v);
+  const int y = __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, y);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(float, y);
+}
+#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141  // lane i <-> 7-i inside each group of 8
+#define DPP_Q0 0x00          // quad_perm [0,0,0,0]
+#define DPP_Q1 0x55
+#define DPP_Q2 0xAA
+#define DPP_Q3 0xFF
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
 template <int H>
 __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __restrict__ xg,
                                                              const float* __restrict__ whh,
                                                              float* __restrict__ out, int T) {
   __shared__ __attribute__((aligned(16))) float hs[2][H];
-  constexpr int KH = H / 2;
+  constexpr int KS = H / 8;                                  // k-slice length per lane
   const int tid = threadIdx.x;
-  const int j = tid >> 3, gate = (tid >> 1) & 3, half = tid & 1;
+  const int j = tid >> 3, ks = tid & 7;
   const int dir = blockIdx.x, b = blockIdx.y;
-  const int row = gate * H + j;
-  float w[KH];
-  {
-    const float* wr = whh + ((long long)dir * 4 * H + row) * H + half * KH;
+  float w[4][KS];
 #pragma unroll
-    for (int i = 0; i < KH; ++i) w[i] = wr[i];
+  for (int g = 0; g < 4; ++g) {
+    const float* wr = whh + ((long long)dir * 4 * H + g * H + j) * H + ks * KS;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) w[g][i] = wr[i];
   }
   if (tid < H) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; }
   __syncthreads();
   float c = 0.f;
-  const float* xb = xg + (long long)b * T * (8 * H) + (long long)dir * 4 * H + row;
+  const int mygate = ks & 3;                                  // lanes 0-3 (and 4-7) carry gate i,f,g,o
+  const float* xb = xg + (long long)b * T * (8 * H) + (long long)dir * 4 * H + mygate * H + j;
   float* ob = out + (long long)b * T * (2 * H) + dir * H + j;
   int t = dir ? (T - 1) : 0;
   const int dt = dir ? -1 : 1;
-  float xnext = (half == 0) ? xb[(long long)t * (8 * H)] : 0.f;
+  const float gsc = (mygate == 2) ? 2.0f : 1.0f, gof = (mygate == 2) ? -1.0f : 0.0f;
+  float xnext = (ks < 4) ? xb[(long long)t * (8 * H)] : 0.f;
   for (int s = 0; s < T; ++s, t += dt) {
     const float xcur = xnext;
-    if (s + 1 < T && half == 0) xnext = xb[(long long)(t + dt) * (8 * H)];
-    const float* hc = hs[s & 1] + half * KH;
-    float acc = 0.f;
+    if (s + 1 < T && ks < 4) xnext = xb[(long long)(t + dt) * (8 * H)];
+    const float* hc = hs[s & 1] + ks * KS;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < KH; i += 4) {
-      f32x4 hv = *reinterpret_cast<const f32x4*>(hc + i);
-      acc += w[i] * hv[0];
-      acc += w[i + 1] * hv[1];
-      acc += w[i + 2] * hv[2];
-      acc += w[i + 3] * hv[3];
+    for (int i = 0; i < KS; i += 4) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + i);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        a[g] += w[g][i] * hv[0];
+        a[g] += w[g][i + 1] * hv[1];
+        a[g] += w[g][i + 2] * hv[2];
+        a[g] += w[g][i + 3] * hv[3];
+      }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += xcur;                       // valid on half==0 lanes (xcur = 0 on the others)
-    // bring the four gates of unit j to its first lane (lane%8 == 0)
-    float gi = acc;
-    float gf = __shfl_down(acc, 2, 64);
-    float gg = __shfl_down(acc, 4, 64);
-    float go = __shfl_down(acc, 6, 64);
-    if ((tid & 7) == 0) {
-      float ig = 1.0f / (1.0f + expf(-gi));
-      float fg = 1.0f / (1.0f + expf(-gf));
-      float cg = tanhf(gg);
-      float og = 1.0f / (1.0f + expf(-go));
-      c = fg * c + ig * cg;
-      float h = og * tanhf(c);
+    // the input projection of gate `mygate` enters through lanes 0..3 (xcur = 0 on lanes 4..7)
+    a[0] += (mygate == 0) ? xcur : 0.f;
+    a[1] += (mygate == 1) ? xcur : 0.f;
+    a[2] += (mygate == 2) ? xcur : 0.f;
+    a[3] += (mygate == 3) ? xcur : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      a[g] = dpp_add<DPP_XOR1>(a[g]);
+      a[g] = dpp_add<DPP_XOR2>(a[g]);
+      a[g] = dpp_add<DPP_HALF_MIRROR>(a[g]);
+    }
+    // every lane now holds the 4 complete pre-activations of its unit; lane q of each quad activates gate q
+    const float pre = (mygate == 0) ? a[0] : (mygate == 1) ? a[1] : (mygate == 2) ? a[2] : a[3];
+    const float act = gsc * fast_sigmoid(gsc * pre) + gof;
+    const float ig = dpp_get<DPP_Q0>(act), fg = dpp_get<DPP_Q1>(act);
+    const float cg = dpp_get<DPP_Q2>(act), og = dpp_get<DPP_Q3>(act);
+    c = fg * c + ig * cg;
+    const float h = og * (2.0f * fast_sigmoid(2.0f * c) - 1.0f);
+    if (ks == 0) {
       hs[(s + 1) & 1][j] = h;
       ob[(long long)t * (2 * H)] = h;
     }
