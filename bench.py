@@ -25,17 +25,18 @@ WORKLOADS = {
     "c1": (1, 16000, "B1 x 1 s (L16000, T201) forward"),
     "c2": (64, 64000, "B64 x 4 s (L64000, T801) SincNet+Conformer forward (BASELINE configs[1])"),
     "c3p": (256, 40880, "B256 x 512-frame utterances (L40880, T512) forward"),
+    "c5": (32, 480000, "B32 x 30 s (L480000, T6001) forward with episodic memory (BASELINE configs[4], fwd)"),
 }
 PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "hbm": 8000.0}      # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
 FAMILY_BOUND = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32"}
 
 
-def build_path(dtype, seed=1234):
+def build_path(dtype, seed=1234, use_memory=False):
     import torch
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
     ops.set_compute_dtype(dtype)
-    path = EnhancementPath(sample_rate=16000, use_memory=False)
+    path = EnhancementPath(sample_rate=16000, use_memory=use_memory)
     sd = path.state_dict()
     shapes = {k: tuple(v.shape) for k, v in sd.items()}
     keep = {k: v.numpy() for k, v in sd.items() if k.split(".")[-1] in ("low_hz_", "band_hz_", "window", "n_")}
@@ -109,7 +110,7 @@ def main():
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
     B, L, desc = WORKLOADS[args.workload]
     T = 1 + L // 80
-    path, weights = build_path(args.dtype)
+    path, weights = build_path(args.dtype, use_memory=(args.workload == "c5"))
     path = path.cuda().eval()
     noisy, _ = syn.synth_wave(B, L, 1234 + rank)          # each rank enhances its own utterance shard
     wave = torch.from_numpy(noisy).cuda()

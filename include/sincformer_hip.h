@@ -85,7 +85,8 @@ int sfm_framed_gemm_f32(const float* sig, const float* Wt, const float* bias, vo
 
 /* softmax(Q K^T * scale) V per (batch, head); replaces the attention core of
  * nn.MultiheadAttention (models/conformer.py:69).  qkv [B,T,ldqkv] 16-bit with
- * q at column h*hd, k at koff+h*hd, v at voff+h*hd; out [B,T,ldo] 16-bit at h*hd. */
+ * q at column h*hd, k at koff+h*hd, v at voff+h*hd; out [B,T,ldo] 16-bit at h*hd.
+ * scale <= 0 means Q is pre-multiplied by softmax_scale*log2(e) (folded into W_q/b_q). */
 int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                       int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
                       float scale, int dtype, void* stream);

@@ -43,6 +43,6 @@ class MaskSynthesisAgent(HipModule):
         if z_real.shape[-1] != noisy_stft_real.shape[1]:
             raise RuntimeError("Sizes of tensors must match except in dimension 2. Expected size %d but got size %d "
                                "(latents must be at the STFT frame rate)" % (z_real.shape[-1], noisy_stft_real.shape[1]))
-        pk = self._packed(lambda sd: Fn.pack_msa(sd, self.conformer.num_blocks))
+        pk = self._packed(lambda sd: Fn.pack_msa(sd, self.conformer.num_blocks, self.conformer.num_heads))
         return Fn.msa_forward(z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag, pk,
                               self.conformer.num_heads, mag_bias=mag_logit_bias)

@@ -7,7 +7,10 @@
 //   S^T = K Q^T   (32x32x16 MFMA; A = K rows from LDS, B = Q held in registers)
 //         -> each lane holds 16 keys of ONE query row (col = lane&31), so the
 //            row max / row sum are in-lane + one exchange with lane^32
-//   online softmax in fp32 (exp2 domain, scale folded in)
+//   online softmax in fp32, exp2 domain.  Two extra MFMAs per key tile take VALU work off the
+//   softmax: an augmented k-step (K side [1,1,0..], Q side [-m_hi,-m_lo,0..]) makes the matrix
+//   core deliver s*c - m_run directly (the scale c is folded into Q), and a ones-row on the V^T
+//   side accumulates the row sums l; per score only max / exp2 / convert remain on the VALU.
 //   O^T += V^T P^T: the S^T accumulator, converted to 16-bit, IS the B operand
 //            (k order 16s + 8(j>>2) + 4h + (j&3)); the matching A operand V^T
 //            comes from ds_read_b64_tr_b16 on the row-major V tile.
@@ -27,9 +30,8 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
                                                             int Tlen, int ldqkv, int ldo, int koff, int voff,
                                                             long long qkv_batch_stride, long long o_batch_stride,
                                                             float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) u16 smem[64 * KS_ROW + 64 * VS_ROW];
-  u16* Ks = smem;
-  u16* Vs = smem + 64 * KS_ROW;
+  constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -49,12 +51,29 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     }
   }
 
-  f32x16 o[2];
+  if (scale_log2e != 1.0f) {          // fold softmax scale * log2(e) into Q (callers may pre-fold it into W_q)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t w = qf[ks][e];
+        qf[ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
+      }
+  }
+  const uint32_t one16 = T::from_f32(1.0f);
+  const uint32_t ones2 = one16 | (one16 << 16);
+  const u32x4 kaug = {hl == 0 ? ones2 : 0u, 0u, 0u, 0u};            // K side of the augmented k-step
+  const u32x4 vones = {ones2, ones2, ones2, ones2};                 // V^T side: a row of ones -> row sums
+  u32x4 qaug = {0u, 0u, 0u, 0u};                                    // Q side: (-m_hi, -m_lo, 0, ...)
+
+  f32x16 o[2], lacc;
 #pragma unroll
   for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dj][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  float m_run = 0.f;                                                // value currently subtracted by the MFMA
 
   // staging coordinates: 64 rows x 8 chunks(16 B) for K and for V; 2 chunks each per thread
   int srow[2], scol[2];
@@ -82,32 +101,43 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     }
   };
 
-  load_kv(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  auto store_kv = [&](int buf) {
+    u16* Kd = smem + buf * KV_BUF;
+    u16* Vd = Kd + 64 * KS_ROW;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(&Ks[srow[i] * KS_ROW + scol[i]]) = rk[i];
-      *reinterpret_cast<u32x4*>(&Vs[srow[i] * VS_ROW + scol[i]]) = rv[i];
+      *reinterpret_cast<u32x4*>(&Kd[srow[i] * KS_ROW + scol[i]]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Vd[srow[i] * VS_ROW + scol[i]]) = rv[i];
     }
-    __syncthreads();
-    if (kt + 1 < ntiles) load_kv(kt + 1);
+  };
+
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const u16* Ks = smem + (kt & 1) * KV_BUF;
+    const u16* Vs = Ks + 64 * KS_ROW;
+    if (kt + 1 < ntiles) load_kv(kt + 1);             // global -> registers, lands under this tile's math
 
     // ---- S^T = K Q^T : two 32-key sub-tiles ----
     f32x16 s[2];
 #pragma unroll
     for (int kj = 0; kj < 2; ++kj) {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      u32x4 kf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[(kj * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
-        s[kj] = T::mfma(kf, qf[ks], ks == 0 ? zero : s[kj]);
-      }
+      for (int ks = 0; ks < 4; ++ks)
+        kf[ks] = *reinterpret_cast<const u32x4*>(&Ks[(kj * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
+      __builtin_amdgcn_s_setprio(1);
+      s[kj] = T::mfma(kaug, qaug, zero);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[kj] = T::mfma(kf[ks], qf[ks], s[kj]);
+      __builtin_amdgcn_s_setprio(0);
     }
     // ---- online softmax (row = query = lane&31; keys spread over regs and lane halves) ----
-    // Scores stay raw; the 1/sqrt(hd)*log2(e) factor is folded into the exp2 argument (one FMA).
-    // The running max is only raised when some row's max grew by more than DEFER_THR (log2 units):
-    // then O and l of every lane are rescaled (a wave-uniform, rare branch); otherwise P is formed
-    // against the old max (values up to 2^DEFER_THR, exact in floating point) and nothing is rescaled.
+    // s already equals score*c - m_run.  The running max is raised only when some row grew by more than
+    // DEFER_THR (log2 units) - a rare, wave-uniform branch that rescales O, l and this tile's scores;
+    // otherwise P = exp2(s) directly (values up to 2^DEFER_THR).
     const int kbase = kt * 64;
     if (kbase + 64 > Tlen) {                            // wave-uniform: only the last, partial tile masks keys
 #pragma unroll
@@ -119,28 +149,35 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
-    if (__any(mx > m_run + DEFER_THR)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (kt == 0 || __any(mx > DEFER_THR)) {
+      // new subtracted value = m_run + mx, split in two 16-bit terms so the MFMA subtracts it to ~2^-17
+      const float want = m_run + mx;
+      const float hi = T::to_f32(T::from_f32(want));
+      const float lo = T::to_f32(T::from_f32(want - hi));
+      const float m_new = hi + lo;
+      const float delta = m_new - m_run;
+      if (kt > 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+      }
+#pragma unroll
+      for (int kj = 0; kj < 2; ++kj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kj][r] -= delta;
       m_run = m_new;
-#pragma unroll
-      for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+      qaug[0] = (hl == 0) ? pack2<T>(-hi, -lo) : 0u;
     }
-    float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], scale_log2e, -m_run));
-      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][r], scale_log2e, -m_run));
-      s[0][r] = p0;
-      s[1][r] = p1;
-      psum0 += p0;
-      psum1 += p1;
+      s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
+      s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
     }
-    l_run += psum0 + psum1;
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -152,6 +189,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
         pf[1] = pack2<T>(s[kj][8 * s2 + 2], s[kj][8 * s2 + 3]);
         pf[2] = pack2<T>(s[kj][8 * s2 + 4], s[kj][8 * s2 + 5]);
         pf[3] = pack2<T>(s[kj][8 * s2 + 6], s[kj][8 * s2 + 7]);
+        lacc = T::mfma(vones, pf, lacc);                  // row sums of the (rounded) P, all 32 rows equal
         // transposed V reads: 16-lane group g -> d block (g&1)*16, lane half = g>>1;
         // lane 4q+p of the group addresses row q, cols 4p..4p+3 and receives column (lane&15)
         const int g16 = lane >> 4, i16 = lane & 15;
@@ -171,12 +209,12 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
         }
       }
     }
+    if (kt + 1 < ntiles) store_kv((kt + 1) & 1);      // the other buffer: its readers finished before the last barrier
     __syncthreads();
   }
 
   // ---- epilogue: normalise, transpose through LDS, coalesced stores ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  const float inv = 1.0f / lacc[0];
   u16* Os = smem + wave * (32 * OS_ROW);
 #pragma unroll
   for (int dj = 0; dj < 2; ++dj)
@@ -261,7 +299,8 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
   if (hd == 64 && (ldqkv % 8) == 0 && (ldo % 8) == 0 && (koff % 8) == 0 && (voff % 8) == 0 &&
       (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
     dim3 grid((T + 127) / 128, H, B), block(256);
-    float sl2 = scale * 1.44269504088896340736f;
+    // scale <= 0: Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
+    float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
     if (dtype == SFM_DT_F16)
       SFM_LAUNCH((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
                          koff, voff, qkv_batch_stride, o_batch_stride, sl2);
@@ -270,6 +309,7 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
                          koff, voff, qkv_batch_stride, o_batch_stride, sl2);
   } else {
     dim3 grid((T + 3) / 4, H, B), block(256);
+    if (scale <= 0.f) scale = 0.69314718055994530942f;      // pre-scaled Q carries log2(e): exp(x ln2) = 2^x
     if (dtype == SFM_DT_F16)
       SFM_LAUNCH((attn_fwd_generic_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd, ldqkv,
                          ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);

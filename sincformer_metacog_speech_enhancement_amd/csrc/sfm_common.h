@@ -24,6 +24,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // 8 x 16-bit packed
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 struct BF16 {
   static constexpr int id = SFM_DT_BF16;
@@ -33,6 +36,10 @@ struct BF16 {
   }
   static __device__ __forceinline__ float to_f32(u16 b) {
     return __builtin_bit_cast(float, (uint32_t)b << 16);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (RNE)
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
   }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
@@ -49,6 +56,10 @@ struct F16 {
   static __device__ __forceinline__ float to_f32(u16 b) {
     return (float)__builtin_bit_cast(_Float16, b);
   }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {   // RNE (not the RTZ pk convert)
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
                                                   __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -57,7 +68,7 @@ struct F16 {
 
 template <class T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+  return T::pack(lo, hi);
 }
 
 // row of C/D register r for lane l (32x32 tiles)

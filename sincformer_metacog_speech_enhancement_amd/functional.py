@@ -115,9 +115,15 @@ def pack_ffn(sd):
             "w2": ops.pack_linear(sd["linear2.weight"], sd["linear2.bias"])}
 
 
-def pack_mhsa(sd):
+def pack_mhsa(sd, num_heads=4):
+    w, b = sd["attention.in_proj_weight"].detach().float(), sd["attention.in_proj_bias"].detach().float()
+    D = w.shape[1]
+    # fold softmax_scale * log2(e) into the Q rows so the attention kernel's exp2 needs no per-score multiply
+    qs = ops.ATTN_QSCALE_LOG2E / math.sqrt(D // num_heads)
+    w = torch.cat([w[:D] * qs, w[D:]], dim=0)
+    b = torch.cat([b[:D] * qs, b[D:]], dim=0)
     return {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
-            "win": ops.pack_linear(sd["attention.in_proj_weight"], sd["attention.in_proj_bias"]),
+            "win": ops.pack_linear(w, b), "heads": num_heads,
             "wout": ops.pack_linear(sd["attention.out_proj.weight"], sd["attention.out_proj.bias"])}
 
 
@@ -131,8 +137,8 @@ def pack_convmod(sd):
             "pw2": ops.pack_linear(sd["pointwise2.weight"].reshape(D, D), sd["pointwise2.bias"])}
 
 
-def pack_block(sd):
-    return {"ff1": pack_ffn(sub(sd, "ff1")), "mhsa": pack_mhsa(sub(sd, "mhsa")), "conv": pack_convmod(sub(sd, "conv")),
+def pack_block(sd, num_heads=4):
+    return {"ff1": pack_ffn(sub(sd, "ff1")), "mhsa": pack_mhsa(sub(sd, "mhsa"), num_heads), "conv": pack_convmod(sub(sd, "conv")),
             "ff2": pack_ffn(sub(sd, "ff2")), "fn_w": _f32(sd["final_norm.weight"]), "fn_b": _f32(sd["final_norm.bias"])}
 
 
@@ -153,7 +159,9 @@ def mhsa_forward(x32, pk, B, T, H):
     D = x32.shape[1]
     h = _ln16(x32, pk["ln_w"], pk["ln_b"])
     qkv = ops.linear16(h, pk["win"])
-    o = ops.attention(qkv, B, T, H, D // H)
+    if pk["heads"] != H:
+        raise RuntimeError("packed attention weights were scaled for %d heads, got %d" % (pk["heads"], H))
+    o = ops.attention(qkv, B, T, H, D // H, prescaled=True)
     return ops.linear16(o, pk["wout"], epi=ops.EPI_RESID, resid=x32, alpha=1.0)
 
 
@@ -177,12 +185,12 @@ def block_forward(x32, pk, B, T, H, want16=False):
     return (out, out16) if want16 else out
 
 
-def pack_complex_conformer(sd, num_blocks):
+def pack_complex_conformer(sd, num_blocks, num_heads=4):
     nf2 = sd["input_proj.weight"].shape[1]
     return {"in": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"],
                                   k_pad_to=ops.round_up(nf2, 64)),
             "out": ops.pack_linear(sd["output_proj.weight"], sd["output_proj.bias"]),
-            "blocks": [pack_block(sub(sd, "blocks.%d" % i)) for i in range(num_blocks)], "nf2": nf2}
+            "blocks": [pack_block(sub(sd, "blocks.%d" % i), num_heads) for i in range(num_blocks)], "nf2": nf2}
 
 
 def complex_conformer_core(x16, pk, B, T, H, out_dtype=torch.float32):
@@ -356,12 +364,12 @@ def pack_memory_params(sd):
 # ---------------------------------------------------------------------------
 # MaskSynthesisAgent (agents/msa.py:106-174)
 # ---------------------------------------------------------------------------
-def pack_msa(sd, num_blocks):
+def pack_msa(sd, num_blocks, num_heads=4):
     return {"f0": ops.pack_linear(sd["fusion.0.weight"], sd["fusion.0.bias"], k_pad_to=FUSE_LD),
             "f1w": _f32(sd["fusion.1.weight"]), "f1b": _f32(sd["fusion.1.bias"]),
             "f3": ops.pack_linear(sd["fusion.3.weight"], sd["fusion.3.bias"]),
             "f4w": _f32(sd["fusion.4.weight"]), "f4b": _f32(sd["fusion.4.bias"]),
-            "conf": pack_complex_conformer(sub(sd, "conformer"), num_blocks),
+            "conf": pack_complex_conformer(sub(sd, "conformer"), num_blocks, num_heads),
             "r0": ops.pack_linear(sd["mask_proj_real.0.weight"], sd["mask_proj_real.0.bias"]),
             "r2": ops.pack_linear(sd["mask_proj_real.2.weight"], sd["mask_proj_real.2.bias"]),
             "i0": ops.pack_linear(sd["mask_proj_imag.0.weight"], sd["mask_proj_imag.0.bias"]),

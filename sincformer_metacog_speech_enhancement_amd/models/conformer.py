@@ -45,7 +45,7 @@ class MultiHeadSelfAttention(HipModule):
     def forward(self, x):
         self._require_device(x)
         self._require_inference()
-        pk = self._packed(Fn.pack_mhsa)
+        pk = self._packed(lambda sd: Fn.pack_mhsa(sd, self.num_heads))
         B, T, D = x.shape
         y = Fn.mhsa_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T, self.num_heads)
         return y.reshape(B, T, D)
@@ -88,7 +88,7 @@ class ConformerBlock(HipModule):
     def forward(self, x):
         self._require_device(x)
         self._require_inference()
-        pk = self._packed(Fn.pack_block)
+        pk = self._packed(lambda sd: Fn.pack_block(sd, self.num_heads))
         B, T, D = x.shape
         y = Fn.block_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T, self.num_heads)
         return y.reshape(B, T, D)
@@ -116,7 +116,7 @@ class ComplexConformer(HipModule):
     def forward(self, stft_real, stft_imag):
         self._require_device(stft_real, stft_imag)
         self._require_inference()
-        pk = self._packed(lambda sd: Fn.pack_complex_conformer(sd, self.num_blocks))
+        pk = self._packed(lambda sd: Fn.pack_complex_conformer(sd, self.num_blocks, self.num_heads))
         return Fn.complex_conformer_forward(stft_real.float(), stft_imag.float(), pk, self.num_heads)
 
     def apply_mask(self, stft_real, stft_imag, mask_real, mask_imag):

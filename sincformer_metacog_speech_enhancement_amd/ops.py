@@ -262,8 +262,12 @@ def pack_f32_matrix(wt_kn):
     return W
 
 
-def attention(qkv16, B, T, H, hd, out=None):
-    """qkv16 [B*T, 3*H*hd] (q | k | v) -> [B*T, H*hd]."""
+ATTN_QSCALE_LOG2E = 1.4426950408889634
+
+
+def attention(qkv16, B, T, H, hd, out=None, prescaled=False):
+    """qkv16 [B*T, 3*H*hd] (q | k | v) -> [B*T, H*hd].  prescaled: q already multiplied by
+    log2(e)/sqrt(hd) (functional.pack_mhsa folds it into W_q, b_q before the 16-bit rounding)."""
     _need_dev(qkv16)
     L = _lib.load()
     D = H * hd
@@ -271,7 +275,7 @@ def attention(qkv16, B, T, H, hd, out=None):
     if out is None:
         out = torch.empty(B * T, D, device=qkv16.device, dtype=qkv16.dtype)
     _call("attention_fwd", L.sfm_attention_fwd, (_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld, T * out.stride(0),
-                             1.0 / math.sqrt(hd), _dt(), _stream()),
+                             (-1.0 if prescaled else 1.0 / math.sqrt(hd)), _dt(), _stream()),
           *_cost_of("attention_fwd", locals()))
     return out
 

@@ -56,7 +56,7 @@ class SpeechEnhancer(HipModule):
         heads_b = torch.cat([sd["mag_head.bias"], sd["phase_head.bias"]], dim=0)
         return {"in_w": sd["input_norm.weight"].float().contiguous(), "in_b": sd["input_norm.bias"].float().contiguous(),
                 "proj": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(F2, 64)),
-                "blocks": [Fn.pack_block(Fn.sub(sd, "blocks.%d" % i)) for i in range(self.num_blocks)],
+                "blocks": [Fn.pack_block(Fn.sub(sd, "blocks.%d" % i), self.num_heads) for i in range(self.num_blocks)],
                 "on_w": sd["output_norm.weight"].float().contiguous(), "on_b": sd["output_norm.bias"].float().contiguous(),
                 "heads": ops.pack_linear(heads_w, heads_b)}
 
@@ -106,7 +106,7 @@ class EnhancementPath(HipModule):
     def _pack(self, sd):
         packs = {"pa": Fn.pack_perception(Fn.sub(sd, "perception"), self.sample_rate),
                  "cpea": Fn.pack_cpea(Fn.sub(sd, "cpea"), self.cpea.num_layers),
-                 "msa": Fn.pack_msa(Fn.sub(sd, "msa"), self.msa.conformer.num_blocks)}
+                 "msa": Fn.pack_msa(Fn.sub(sd, "msa"), self.msa.conformer.num_blocks, self.msa.conformer.num_heads)}
         if self.memory is not None:
             m = self.memory
             packs["memory"] = (Fn.pack_memory_params(Fn.sub(sd, "memory")), m.key_dim, m.value_dim, m.num_slots,

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Attention-only microbenchmark (headline of BASELINE.json: Conformer attention at batch 256 x 512-frame
+utterances, 4 heads x 64): HIP-event timing of sfm_attention_fwd, TFLOP/s = 4*B*H*T^2*hd / t."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sincformer_metacog_speech_enhancement_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--frames", type=int, default=512)
+ap.add_argument("--heads", type=int, default=4)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+ops.set_compute_dtype(a.dtype)
+B, T, H, hd = a.batch, a.frames, a.heads, 64
+g = torch.Generator(device="cuda").manual_seed(1)
+qkv = (torch.randn(B * T, 3 * H * hd, device="cuda", generator=g) * 1.0).to(ops.compute_dtype())
+out = torch.empty(B * T, H * hd, device="cuda", dtype=ops.compute_dtype())
+for _ in range(3):
+    ops.attention(qkv, B, T, H, hd, out=out)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.iters):
+    ops.attention(qkv, B, T, H, hd, out=out)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.iters
+fl = 4.0 * B * H * T * T * hd
+print(json.dumps({"kernel": "attn_fwd_hd64", "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
+                  "tflops": fl / ms / 1e9, "frac_of_2.5PF": fl / ms / 1e9 / 2500.0}))
