@@ -135,6 +135,13 @@ int sfm_pack_spec(const float* re, const float* im, float* dst, long long M, int
 int sfm_sinc_filters(const float* low_hz, const float* band_hz, const float* window, const float* n_,
                      float* filt, float* Wt, int C, int K, int Npad, float sample_rate, float min_low_hz,
                      float min_band_hz, void* stream);
+/* SincConv1d FIR (agents/perception.py:117) on the 16-bit matrix cores with hi/lo split operands
+ * (3 MFMA passes, ~fp32 accuracy).  filt [64,K] fp32 from sfm_sinc_filters; wsh = workspace of
+ * 8*2*64*272 uint16; out [B,L,64] channels-last; gn_partial [B][sfm_sinc_fir16_tiles(L)][8][2],
+ * which the caller must zero-fill (tiles past L are not written). */
+int sfm_sinc_fir16_tiles(int L);
+int sfm_sinc_fir16(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B,
+                   int L, int C, int K, int out_f32, int dtype, void* stream);
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
 /* EpisodicMemory.forward eval (agents/memory.py:112-133) in one launch, see memory.hip */

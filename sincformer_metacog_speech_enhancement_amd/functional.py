@@ -15,6 +15,7 @@ from . import ops
 
 N_FFT, HOP, WIN = 256, 80, 160
 N_FREQ = N_FFT // 2 + 1
+SINC_ON_16BIT_MFMA = True  # False: exact-fp32 matrix instruction (framed_gemm) for the sinc FIR
 FUSE_LD = 1088           # 2*256 + 4*64 + 2*129 = 1026 -> padded to 17*64
 
 
@@ -269,13 +270,17 @@ def perception_forward(wave, pk, keep_sinc=False):
     B, L = wave.shape
     C0, K = pk["C0"], pk["K"]
     dev = wave.device
-    _, Wt = ops.sinc_filters(pk["low_hz_"], pk["band_hz_"], pk["window"], pk["n_"], C0, K, pk["fs"], 50.0, 50.0,
-                             want_filt=False)
+    filt, Wt = ops.sinc_filters(pk["low_hz_"], pk["band_hz_"], pk["window"], pk["n_"], C0, K, pk["fs"], 50.0, 50.0,
+                                want_filt=True)
     raw = torch.empty(B, L, C0, device=dev, dtype=dt)
-    P0 = 4 * ((L + 127) // 128)
-    part = torch.empty(B, P0, 8, 2, device=dev, dtype=torch.float32)
-    ops.framed_gemm(wave, Wt, raw, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=K // 2, K=K, N=C0,
-                    o_batch_stride=L * C0, ldm=C0, ldn=1, mode=0, gn_partial=part, gn_group=C0 // 8)
+    if C0 == 64 and K + 7 <= 272 and SINC_ON_16BIT_MFMA:
+        # split-operand 16-bit MFMA FIR (~fp32 accuracy, 3 passes of the 16x faster matrix rate)
+        part, P0 = ops.sinc_fir16(wave, filt, raw, B, L, C0, K)
+    else:
+        P0 = 4 * ((L + 127) // 128)
+        part = torch.empty(B, P0, 8, 2, device=dev, dtype=torch.float32)
+        ops.framed_gemm(wave, Wt, raw, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=K // 2, K=K, N=C0,
+                        o_batch_stride=L * C0, ldm=C0, ldn=1, mode=0, gn_partial=part, gn_group=C0 // 8)
     sc, sh = ops.gn_finalize(part, pk["sn_w"], pk["sn_b"], B, P0, 8, C0, L)
     x = torch.empty(B, L, C0, device=dev, dtype=dt)
     ops.gn_apply(raw, sc, sh, x, B, L, C0, act=1)

@@ -387,6 +387,20 @@ def sinc_filters(low_hz, band_hz, window, n_, C, K, sample_rate, min_low_hz, min
     return filt, Wt
 
 
+def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True):
+    """SincConv1d FIR on split 16-bit operands -> out [B, L, C] channels-last (+ GroupNorm partials)."""
+    Lb = _lib.load()
+    dev = wave.device
+    wsh = torch.empty(8 * 2 * 64 * 272, device=dev, dtype=torch.int16)
+    P = Lb.sfm_sinc_fir16_tiles(L)
+    part = torch.zeros(B, P, 8, 2, device=dev, dtype=torch.float32) if want_stats else None
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    flops, nbytes = 2.0 * B * L * C * K, B * L * 4 + B * L * C * (4 if out_f32 else 2)
+    _call("sinc_fir16", Lb.sfm_sinc_fir16, (_p(wave), _p(filt), _p(wsh), _p(out), _p(part), B, L, C, K, out_f32, _dt(),
+                                            _stream()), flops, nbytes)
+    return part, P
+
+
 def bilstm_layer(xg, whh, B, T, H):
     L = _lib.load()
     out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)

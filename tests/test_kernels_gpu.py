@@ -368,3 +368,30 @@ def test_memory(ops):
     report("memory gate", gate.cpu(), ref["gate"], 2e-5)
     report("memory sim", sim.cpu(), ref["similarity"], 2e-5)
     assert np.array_equal(top.cpu().numpy().astype(np.int64), ref["top_indices"].numpy())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("L", [1000, 8192, 20011])
+def test_sinc_fir16_split_mfma(ops, dt, L):
+    """16-bit split-operand FIR (hi/lo x hi/lo, 3 MFMA passes) against the fp32 conv"""
+    ops.set_compute_dtype(dt)
+    fs = 16000
+    p = orc.sinc_init(64, 251, fs)
+    p["low_hz_"], p["band_hz_"] = p["low_hz_"] * (fs / 8.0), p["band_hz_"] * (fs / 8.0)
+    ref_f = orc.sinc_filters(p["low_hz_"], p["band_hz_"], p["window"], p["n_"], fs)
+    filt, _ = ops.sinc_filters(dev(p["low_hz_"].reshape(-1)), dev(p["band_hz_"].reshape(-1)), dev(p["window"]),
+                               dev(p["n_"].reshape(-1)), 64, 251, fs, 50.0, 50.0)
+    B = 2
+    x = arr("fx", (B, L), 23, 0.3)
+    out = torch.empty(B, L, 64, device="cuda", dtype=torch.float32)
+    part, P = ops.sinc_fir16(dev(x), filt, out, B, L, 64, 251)
+    ref = orc.sinc_conv(x, ref_f)
+    report("sinc fir16 %s L%d" % (dt, L), out.cpu().transpose(1, 2), ref, 2e-6 if dt is torch.float16 else 2e-5)
+    gw, gb = arr("sgw", (64,), 21) * 0.1 + 1.0, arr("sgb", (64,), 22) * 0.1
+    sc, sh = ops.gn_finalize(part, dev(gw), dev(gb), B, P, 8, 64, L)
+    y = torch.empty(B, L, 64, device="cuda", dtype=torch.float32)
+    ops.gn_apply(out, sc, sh, y, B, L, 64, act=1)
+    report("sinc fir16 GN(8)+GELU", y.cpu().transpose(1, 2), orc.gelu(orc.group_norm(ref, 8, gw, gb)), 3e-4)
+    o16 = torch.empty(B, L, 64, device="cuda", dtype=dt)
+    ops.sinc_fir16(dev(x), filt, o16, B, L, 64, 251)
+    report("sinc fir16 16-bit out", o16.float().cpu().transpose(1, 2), ref, 2 * EPS[dt] * 0.1)
