@@ -156,6 +156,12 @@ def main():
             ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
         else:
             ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # tools/pmc_summary.py) for this workload, when present; None otherwise
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
         att = breakdown.get("attention_fwd")
         line = {
             "metric": "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref",
@@ -165,7 +171,10 @@ def main():
             "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": ach / peak, "traffic": None, "launches": dom["n"], "avg_ms": dom["ms_avg"]},
+                         "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)",
+                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
+                         "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"],
+                         "avg_ms": dom["ms_avg"]},
             "frames_per_s_per_gpu": frames / elapsed / world,
         }
         if att:

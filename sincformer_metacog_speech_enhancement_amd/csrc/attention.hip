@@ -29,13 +29,21 @@ template <class T>
 __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
                                                             int Tlen, int ldqkv, int ldo, int koff, int voff,
                                                             long long qkv_batch_stride, long long o_batch_stride,
-                                                            float scale_log2e) {
+                                                            float scale_log2e, int nqt, int nheads) {
   constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+  // run of (batch, head, q-tile) ids: the q-tiles that share one (batch, head)'s K/V then share an L2.
+  int id = blockIdx.x;
+  {
+    const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int qt = id % nqt;
+  const int h = (id / nqt) % nheads, b = id / (nqt * nheads);
+  const int q0 = qt * 128 + wave * 32;
   const int hl = lane >> 5, l31 = lane & 31;
   const u16* base = qkv + (long long)b * qkv_batch_stride + h * 64;
 
@@ -298,15 +306,16 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
   hipStream_t st = (hipStream_t)stream;
   if (hd == 64 && (ldqkv % 8) == 0 && (ldo % 8) == 0 && (koff % 8) == 0 && (voff % 8) == 0 &&
       (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
-    dim3 grid((T + 127) / 128, H, B), block(256);
+    const int nqt = (T + 127) / 128;
+    dim3 grid(nqt * H * B), block(256);
     // scale <= 0: Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
     float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
     if (dtype == SFM_DT_F16)
       SFM_LAUNCH((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
-                         koff, voff, qkv_batch_stride, o_batch_stride, sl2);
+                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H);
     else
       SFM_LAUNCH((attn_fwd_hd64_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
-                         koff, voff, qkv_batch_stride, o_batch_stride, sl2);
+                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H);
   } else {
     dim3 grid((T + 3) / 4, H, B), block(256);
     if (scale <= 0.f) scale = 0.69314718055994530942f;      // pre-scaled Q carries log2(e): exp(x ln2) = 2^x
