@@ -135,6 +135,11 @@ int sfm_pack_spec(const float* re, const float* im, float* dst, long long M, int
 int sfm_sinc_filters(const float* low_hz, const float* band_hz, const float* window, const float* n_,
                      float* filt, float* Wt, int C, int K, int Npad, float sample_rate, float min_low_hz,
                      float min_band_hz, void* stream);
+/* Whole FeedForwardModule in one launch (models/conformer.py:41-49, eval): out = x + alpha*(W2 swish(W1 LN(x)+b1)+b2).
+ * x/out [M,256] fp32; W1 [FF,256], W2 [256,FF] 16-bit row-major (nn.Linear layout); D must be 256, FF % 64 == 0. */
+int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb, const void* W1, const float* b1,
+                  const void* W2, const float* b2, float* out, int M, int D, int FF, float alpha, float eps,
+                  int dtype, void* stream);
 /* SincConv1d FIR (agents/perception.py:117) on the 16-bit matrix cores with hi/lo split operands
  * (3 MFMA passes, ~fp32 accuracy).  filt [64,K] fp32 from sfm_sinc_filters; wsh = workspace of
  * 8*2*64*272 uint16; out [B,L,64] channels-last; gn_partial [B][sfm_sinc_fir16_tiles(L)][8][2],

@@ -89,6 +89,26 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// wave-wide sum without LDS traffic: 4 DPP steps leave every 16-lane row's total in all of its lanes,
+// then the four row totals are combined through scalar registers (v_readlane)
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm_add(float v) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_perm_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_perm_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_perm_add<0x141>(v);    // row_half_mirror
+  v = dpp_perm_add<0x140>(v);    // row_mirror
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 // hipGetLastError() is sticky on ROCm 7 (it reports the last *error* of any earlier runtime call
 // in this thread, e.g. a benign hipErrorNotReady from an event query made by the caller's
 // framework), so the state is cleared right before the launch and read right after it.

@@ -110,10 +110,19 @@ def istft(real, imag, length, n_fft=N_FFT, hop=HOP, win=WIN):
 # ---------------------------------------------------------------------------
 # Conformer (models/conformer.py)
 # ---------------------------------------------------------------------------
+FUSED_FFN = True      # False: LayerNorm + two gemm16 launches
+
+
 def pack_ffn(sd):
-    return {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
-            "w1": ops.pack_linear(sd["linear1.weight"], sd["linear1.bias"]),
-            "w2": ops.pack_linear(sd["linear2.weight"], sd["linear2.bias"])}
+    pk = {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
+          "w1": ops.pack_linear(sd["linear1.weight"], sd["linear1.bias"]),
+          "w2": ops.pack_linear(sd["linear2.weight"], sd["linear2.bias"])}
+    FF, D = sd["linear1.weight"].shape
+    if D == 256 and FF % 64 == 0:          # operands of the fused kernel: plain nn.Linear layouts in 16-bit
+        dt = ops.compute_dtype()
+        pk["fused"] = (sd["linear1.weight"].detach().to(dt).contiguous(), _f32(sd["linear1.bias"]),
+                       sd["linear2.weight"].detach().to(dt).contiguous(), _f32(sd["linear2.bias"]))
+    return pk
 
 
 def pack_mhsa(sd, num_heads=4):
@@ -151,6 +160,9 @@ def _ln16(x32, w, b, act=0):
 
 def ffn_forward(x32, pk):
     """FeedForwardModule.forward (eval): x + 0.5 * W2 swish(W1 LN(x))   [M, D] fp32 -> fp32"""
+    if FUSED_FFN and "fused" in pk and x32.is_contiguous():
+        w1, b1, w2, b2 = pk["fused"]
+        return ops.ffn_fused(x32, pk["ln_w"], pk["ln_b"], w1, b1, w2, b2, alpha=0.5)
     h = _ln16(x32, pk["ln_w"], pk["ln_b"])
     u = ops.linear16(h, pk["w1"], epi=ops.EPI_SWISH)
     return ops.linear16(u, pk["w2"], epi=ops.EPI_RESID, resid=x32, alpha=0.5)

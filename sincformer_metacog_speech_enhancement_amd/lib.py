@@ -46,6 +46,7 @@ SIGNATURES = {
     "sfm_istft_ola": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_vp],
     "sfm_pack_spec": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_vp],
     "sfm_sinc_filters": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_f, c_vp],
+    "sfm_ffn_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_i, c_vp],
     "sfm_sinc_fir16_tiles": [c_i],
     "sfm_sinc_fir16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],

@@ -387,6 +387,19 @@ def sinc_filters(low_hz, band_hz, window, n_, C, K, sample_rate, min_low_hz, min
     return filt, Wt
 
 
+def ffn_fused(x32, lnw, lnb, w1_16, b1, w2_16, b2, alpha=0.5, eps=1e-5, out=None):
+    """FeedForwardModule in one launch: x32 [M, 256] fp32 -> [M, 256] fp32."""
+    _need_dev(x32)
+    Lb = _lib.load()
+    M, D = x32.shape
+    FF = w1_16.shape[0]
+    if out is None:
+        out = torch.empty_like(x32)
+    _call("ffn_fused", Lb.sfm_ffn_fused, (_p(x32), _p(lnw), _p(lnb), _p(w1_16), _p(b1), _p(w2_16), _p(b2), _p(out), M, D, FF,
+                                          float(alpha), float(eps), _dt(), _stream()), 4.0 * M * D * FF, M * D * 8.0)
+    return out
+
+
 def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True):
     """SincConv1d FIR on split 16-bit operands -> out [B, L, C] channels-last (+ GroupNorm partials)."""
     Lb = _lib.load()

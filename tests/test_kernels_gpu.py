@@ -395,3 +395,21 @@ def test_sinc_fir16_split_mfma(ops, dt, L):
     o16 = torch.empty(B, L, 64, device="cuda", dtype=dt)
     ops.sinc_fir16(dev(x), filt, o16, B, L, 64, 251)
     report("sinc fir16 16-bit out", o16.float().cpu().transpose(1, 2), ref, 2 * EPS[dt] * 0.1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,FF", [(300, 1024), (128, 64), (1000, 256)])
+def test_ffn_fused(ops, dt, M, FF):
+    """LN -> W1 -> swish -> W2 -> half-step residual in one launch vs fp32 math on 16-bit-rounded weights"""
+    ops.set_compute_dtype(dt)
+    D = 256
+    x = arr("ffx", (M, D), 91, 1.5) + 0.2
+    lw, lb = arr("fflw", (D,), 92) * 0.1 + 1.0, arr("fflb", (D,), 93) * 0.1
+    w1, b1 = arr("ffw1", (FF, D), 94) / 16.0, arr("ffb1", (FF,), 95) * 0.1
+    w2, b2 = arr("ffw2", (D, FF), 96) / math.sqrt(FF), arr("ffb2", (D,), 97) * 0.1
+    out = ops.ffn_fused(dev(x), dev(lw), dev(lb), dev(w1).to(dt).contiguous(), dev(b1), dev(w2).to(dt).contiguous(), dev(b2))
+    h = q16(orc.layer_norm(x, lw, lb), dt)
+    u = q16(orc.swish(h @ q16(w1, dt).t() + b1), dt)
+    ref = x + 0.5 * (u @ q16(w2, dt).t() + b2)
+    report("ffn fused %s M%d FF%d" % (dt, M, FF), out.cpu(), ref, 6 * EPS[dt])
+    assert rmse(out.cpu(), ref) < EPS[dt]
