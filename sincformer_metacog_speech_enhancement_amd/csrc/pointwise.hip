@@ -269,6 +269,97 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(const u16* __restr
   }
 }
 
+// Register-weight variant for the shapes of the path (KS = 31 or 7, C/2 | 256): the 2*KS taps of a
+// thread's channel pair live in registers, LDS holds only the 16-bit input tile (3 workgroups per CU),
+// weights arrive pre-transposed [KS][C] with BatchNorm folded into per-channel scale/shift.
+template <class T, int KS>
+__global__ __launch_bounds__(256) void dwconv_reg_kernel(const u16* __restrict__ x, const float* __restrict__ wT,
+                                                         const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         u16* __restrict__ out, int Tlen, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  u16* xs = reinterpret_cast<u16*>(dsm);                                 // [DW_TT + KS - 1][C]
+  constexpr int padl = (KS - 1) / 2, rows = DW_TT + KS - 1;
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * DW_TT, b = blockIdx.y;
+  const u16* xb = x + (long long)b * Tlen * C;
+  const int cpr = C >> 3;
+  for (int e = tid; e < rows * cpr; e += 256) {
+    const int r = e / cpr, c8 = (e - r * cpr) * 8;
+    const int t = t0 - padl + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t >= 0 && t < Tlen) v = *reinterpret_cast<const u32x4*>(xb + (long long)t * C + c8);
+    *reinterpret_cast<u32x4*>(&xs[r * C + c8]) = v;
+  }
+  const int npair = C >> 1;
+  const int p = tid % npair, grp = tid / npair, ngrp = 256 / npair;
+  const int c = 2 * p;
+  float w0[KS], w1[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const f32x2 w = *reinterpret_cast<const f32x2*>(wT + k * C + c);
+    w0[k] = w[0];
+    w1[k] = w[1];
+  }
+  const float s0 = sc[c], s1 = sc[c + 1], h0 = sh[c], h1 = sh[c + 1];
+  __syncthreads();
+  u16* ob = out + (long long)b * Tlen * C;
+  const int per = DW_TT / ngrp;                                          // frames per thread (multiple of 4)
+  for (int tl = grp * per; tl < (grp + 1) * per; tl += 4) {
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS + 3; ++k) {
+      const uint32_t pk = *reinterpret_cast<const uint32_t*>(&xs[(tl + k) * C + c]);
+      const float x0 = T::to_f32((u16)(pk & 0xffffu)), x1 = T::to_f32((u16)(pk >> 16));
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int kk = k - o;                                            // compile-time after unrolling
+        if (kk >= 0 && kk < KS) {
+          a0[o] += w0[kk] * x0;
+          a1[o] += w1[kk] * x1;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int t = t0 + tl + o;
+      if (t < Tlen) {
+        const float y0 = swish_f(a0[o] * s0 + h0), y1 = swish_f(a1[o] * s1 + h1);
+        *reinterpret_cast<uint32_t*>(&ob[(long long)t * C + c]) = pack2<T>(y0, y1);
+      }
+    }
+  }
+}
+
+template <class T, int KS>
+static int launch_dwconv_reg(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int Tn,
+                             int C, hipStream_t st) {
+  const int lds = (DW_TT + KS - 1) * C * 2;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)dwconv_reg_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr = true;
+  }
+  SFM_LAUNCH((dwconv_reg_kernel<T, KS>), dim3((Tn + DW_TT - 1) / DW_TT, B), dim3(256), lds, st, (const u16*)x, wT, sc, sh,
+             (u16*)out, Tn, C);
+  return SFM_OK;
+}
+
+// wT [KS][C] fp32 (transposed depthwise weights), sc/sh [C] = BatchNorm(eval) folded with the conv bias:
+// y = swish(conv(x) * sc + sh)
+extern "C" int sfm_dwconv_folded(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int T,
+                                 int C, int KS, int dtype, void* stream) {
+  if (!x || !wT || !sc || !sh || !out) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || C % 8 != 0 || C > 512 || (256 % (C / 2)) != 0 || (DW_TT / (256 / (C / 2))) % 4 != 0)
+    return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (KS == 31) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 31>(x, wT, sc, sh, out, B, T, C, st)
+                                           : launch_dwconv_reg<BF16, 31>(x, wT, sc, sh, out, B, T, C, st);
+  if (KS == 7) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 7>(x, wT, sc, sh, out, B, T, C, st)
+                                          : launch_dwconv_reg<BF16, 7>(x, wT, sc, sh, out, B, T, C, st);
+  return SFM_ERR_SHAPE;
+}
+
 extern "C" int sfm_dwconv_bn_swish(const void* x, const float* wdw, const float* bdw, const float* bnw,
                                    const float* bnb, const float* bnm, const float* bnv, void* out, int B, int T,
                                    int C, int KS, float eps, int dtype, void* stream) {

@@ -139,7 +139,14 @@ def pack_mhsa(sd, num_heads=4):
 
 def pack_convmod(sd):
     D = sd["pointwise2.weight"].shape[0]
-    return {"ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
+    KS = sd["depthwise.weight"].shape[-1]
+    folded = None
+    if KS in (7, 31) and D in (64, 128, 256, 512):
+        # BatchNorm(eval) and the depthwise bias folded into one scale/shift per channel; taps transposed to [KS][C]
+        bsc = _f32(sd["batch_norm.weight"]) * torch.rsqrt(_f32(sd["batch_norm.running_var"]) + 1e-5)
+        bsh = _f32(sd["batch_norm.bias"]) - _f32(sd["batch_norm.running_mean"]) * bsc + _f32(sd["depthwise.bias"]) * bsc
+        folded = (_f32(sd["depthwise.weight"].reshape(D, KS)).t().contiguous(), bsc.contiguous(), bsh.contiguous())
+    return {"dw_folded": folded, "ln_w": _f32(sd["layer_norm.weight"]), "ln_b": _f32(sd["layer_norm.bias"]),
             "pw1": ops.pack_linear(sd["pointwise1.weight"].reshape(2 * D, D), sd["pointwise1.bias"], glu=True),
             "dw_w": _f32(sd["depthwise.weight"].reshape(D, -1)), "dw_b": _f32(sd["depthwise.bias"]),
             "bn_w": _f32(sd["batch_norm.weight"]), "bn_b": _f32(sd["batch_norm.bias"]),
@@ -182,7 +189,10 @@ def convmod_forward(x32, pk, B, T):
     D = x32.shape[1]
     h = _ln16(x32, pk["ln_w"], pk["ln_b"])
     g = ops.linear16(h, pk["pw1"], epi=ops.EPI_GLU)
-    d = ops.dwconv_bn_swish(g, pk["dw_w"], pk["dw_b"], pk["bn_w"], pk["bn_b"], pk["bn_m"], pk["bn_v"], B, T, D)
+    if pk["dw_folded"] is not None:
+        d = ops.dwconv_folded(g, pk["dw_folded"][0], pk["dw_folded"][1], pk["dw_folded"][2], B, T, D)
+    else:
+        d = ops.dwconv_bn_swish(g, pk["dw_w"], pk["dw_b"], pk["bn_w"], pk["bn_b"], pk["bn_m"], pk["bn_v"], B, T, D)
     return ops.linear16(d, pk["pw2"], epi=ops.EPI_RESID, resid=x32, alpha=1.0)
 
 

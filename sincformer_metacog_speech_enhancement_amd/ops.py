@@ -321,6 +321,17 @@ def dwconv_bn_swish(x16, wdw, bdw, bnw, bnb, bnm, bnv, B, T, C, out=None, eps=1e
     return out
 
 
+def dwconv_folded(x16, wT, sc, sh, B, T, C, out=None):
+    """depthwise conv + folded BatchNorm(eval) + Swish with register-resident taps (KS 7 / 31)."""
+    L = _lib.load()
+    KS = wT.shape[0]
+    if out is None:
+        out = torch.empty_like(x16)
+    _call("dwconv_bn_swish", L.sfm_dwconv_folded, (_p(x16), _p(wT), _p(sc), _p(sh), _p(out), B, T, C, KS, _dt(), _stream()),
+          2.0 * B * T * C * KS, B * T * C * 4.0)
+    return out
+
+
 def convert_rows(src32, dst16, M, C, Cz, ld_src, ld_dst):
     L = _lib.load()
     _call("convert_rows", L.sfm_convert_rows, (_p(src32), _p(dst16), M, C, Cz, ld_src, ld_dst, _dt(), _stream()),

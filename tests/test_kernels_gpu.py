@@ -413,3 +413,20 @@ def test_ffn_fused(ops, dt, M, FF):
     ref = x + 0.5 * (u @ q16(w2, dt).t() + b2)
     report("ffn fused %s M%d FF%d" % (dt, M, FF), out.cpu(), ref, 6 * EPS[dt])
     assert rmse(out.cpu(), ref) < EPS[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,KS,T", [(256, 31, 200), (64, 7, 20), (256, 31, 801), (128, 7, 3)])
+def test_dwconv_folded(ops, dt, C, KS, T):
+    ops.set_compute_dtype(dt)
+    B = 2
+    x = arr("dx", (B, T, C), 60)
+    w, b = arr("dw", (C, 1, KS), 61) / math.sqrt(KS), arr("db", (C,), 62) * 0.1
+    bw, bb = arr("dbw", (C,), 63) * 0.1 + 1, arr("dbb", (C,), 64) * 0.1
+    rm, rv = arr("drm", (C,), 65) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5
+    sc = bw / torch.sqrt(rv + 1e-5)
+    sh = bb - rm * sc + b * sc
+    out = ops.dwconv_folded(dev(x).to(dt).contiguous(), dev(w.reshape(C, KS).t().contiguous()), dev(sc), dev(sh), B, T, C)
+    h = F.conv1d(q16(x, dt).transpose(1, 2), w, b, padding=(KS - 1) // 2, groups=C)
+    ref = orc.swish(orc.batch_norm_eval(h, bw, bb, rm, rv)).transpose(1, 2)
+    report("dwconv folded C%d k%d T%d" % (C, KS, T), out.float().cpu(), ref, 8 * EPS[dt])
