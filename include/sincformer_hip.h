@@ -152,6 +152,13 @@ int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb, const void
 int sfm_sinc_fir16_tiles(int L);
 int sfm_sinc_fir16(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B,
                    int L, int C, int K, int out_f32, int dtype, void* stream);
+/* Forward of the training objective (training/conformer_pipeline.py:52-108, 539-572): reductions in fp64.
+ * S buffers must be zero-filled by the caller (kernels accumulate with f64 atomics). */
+int sfm_wave_moments(const float* est, const float* tgt, double* S, int B, int L, void* stream);
+int sfm_spec_sums(const float* pr, const float* pi, const float* tr, const float* ti, double* S, long long n,
+                  void* stream);
+int sfm_enhancer_loss_finalize(const double* Sw, const double* Sm, const double* Sr, const long long* nr, int B,
+                               int L, long long n_mag, int R, float* out, void* stream);
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
 /* EpisodicMemory.forward eval (agents/memory.py:112-133) in one launch, see memory.hip */

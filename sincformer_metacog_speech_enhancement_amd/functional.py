@@ -501,3 +501,28 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     if "wave" in want:
         out["enhanced"] = istft_from_packed(spec, B, T, L)
     return out
+
+
+# ---------------------------------------------------------------------------
+# Training objective, forward only (training/conformer_pipeline.py:52-108, 539-572)
+# ---------------------------------------------------------------------------
+MR_STFT = ((256, 64, 256), (512, 128, 512), (1024, 256, 1024))
+
+
+def enhancer_loss(enh_real, enh_imag, clean_wave, clean_real, clean_imag):
+    """_compute_loss after the model call: iSTFT -> SI-SNR + 0.5 * L1 magnitude + multi-resolution STFT.
+    Returns (losses [4] = total, neg_sisnr, l1_mag, mr_stft — a device tensor, no host sync), enhanced waveform."""
+    B, L = clean_wave.shape
+    enh_wav = istft(enh_real, enh_imag, L)
+    Sw = ops.wave_moments(enh_wav, clean_wave.contiguous())
+    Sm = ops.spec_sums(enh_real.contiguous(), enh_imag.contiguous(), clean_real.contiguous(), clean_imag.contiguous())
+    Sr = torch.zeros(len(MR_STFT), 4, device=clean_wave.device, dtype=torch.float64)
+    counts = []
+    for i, (nf, hp, wn) in enumerate(MR_STFT):
+        pr, pi = stft(enh_wav, nf, hp, wn)
+        tr, ti = stft(clean_wave, nf, hp, wn)
+        s = ops.spec_sums(pr, pi, tr, ti)
+        Sr[i].copy_(s)
+        counts.append(pr.numel())
+    nr = torch.tensor(counts, device=clean_wave.device, dtype=torch.int64)
+    return ops.enhancer_loss_finalize(Sw, Sm, Sr, nr, B, L, enh_real.numel()), enh_wav

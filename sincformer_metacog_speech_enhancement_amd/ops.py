@@ -425,6 +425,30 @@ def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True):
     return part, P
 
 
+def wave_moments(est, tgt):
+    L = _lib.load()
+    B, Ln = est.shape
+    S = torch.zeros(B, 5, device=est.device, dtype=torch.float64)
+    _call("loss_reduce", L.sfm_wave_moments, (_p(est), _p(tgt), _p(S), B, Ln, _stream()), 0.0, 8.0 * B * Ln)
+    return S
+
+
+def spec_sums(pr, pi, tr, ti):
+    L = _lib.load()
+    S = torch.zeros(4, device=pr.device, dtype=torch.float64)
+    _call("loss_reduce", L.sfm_spec_sums, (_p(pr), _p(pi), _p(tr), _p(ti), _p(S), pr.numel(), _stream()), 0.0,
+          16.0 * pr.numel())
+    return S
+
+
+def enhancer_loss_finalize(Sw, Sm, Sr, nr, B, Ln, n_mag):
+    L = _lib.load()
+    out = torch.empty(4, device=Sw.device, dtype=torch.float32)
+    _call("loss_reduce", L.sfm_enhancer_loss_finalize, (_p(Sw), _p(Sm), _p(Sr), _p(nr), B, Ln, n_mag, Sr.shape[0], _p(out),
+                                                        _stream()))
+    return out
+
+
 def bilstm_layer(xg, whh, B, T, H):
     L = _lib.load()
     out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)

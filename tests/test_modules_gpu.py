@@ -247,3 +247,36 @@ def test_end_to_end_path_vs_golden(pkg, dt):
     rw, rlw = show("PATH enhanced wave %s" % dt, out["enhanced"], g["enhanced"])
     assert r <= HARD_BOUND[dt], "mask RMSE %.3e" % r
     assert rlw < (2e-2 if dt is torch.bfloat16 else 3e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_enhancer_loss_forward_vs_golden(pkg, dt):
+    """A21 forward: SI-SNR + 0.5 L1-mag + MR-STFT of ConformerPipeline._compute_loss on the golden enhancer outputs"""
+    pkg.ops.set_compute_dtype(dt)
+    g = gold("g8_enhancer")
+    noisy, clean = syn.synth_wave(2, 2000, 82)
+    cw = torch.from_numpy(clean).cuda()
+    cr, ci = pkg.cp.batch_stft(cw, 256, 80, 160)
+    # reference model outputs in, so that only the loss arithmetic is under test
+    losses, enh = pkg.Fn.enhancer_loss(torch.from_numpy(g["enh_real"]).cuda(), torch.from_numpy(g["enh_imag"]).cuda(), cw, cr, ci)
+    lv = losses.cpu().numpy()
+    print("loss total %.6f (ref %.6f)  neg_sisnr %.6f (ref %.6f)" % (lv[0], float(g["loss"]), lv[1], float(g["neg_sisnr"])))
+    assert maxerr(enh.cpu(), g["enh_wav"]) < 2e-5
+    assert abs(lv[0] - float(g["loss"])) < 5e-4 and abs(lv[1] - float(g["neg_sisnr"])) < 5e-4
+    # and end to end through the HIP SpeechEnhancer
+    se = load(pkg.cp.SpeechEnhancer(n_freq=129), "SpeechEnhancer", 81)
+    nr, ni = pkg.cp.batch_stft(torch.from_numpy(noisy).cuda(), 256, 80, 160)
+    er, ei, _ = se(nr, ni)
+    l2, _ = pkg.Fn.enhancer_loss(er, ei, cw, cr, ci)
+    tol = 0.05 if dt is torch.bfloat16 else 0.01
+    assert abs(float(l2[0]) - float(g["loss"])) < tol
+
+
+def test_mrstft_sizes_vs_golden(pkg):
+    g = gold("g3_mrstft")
+    noisy, clean = syn.synth_wave(2, 2048, 32)
+    w = torch.from_numpy(noisy).cuda()
+    for nf, hp in ((256, 64), (512, 128), (1024, 256)):
+        r, i = pkg.Fn.stft(w, nf, hp, nf)
+        mag = torch.sqrt(r ** 2 + i ** 2).transpose(1, 2)
+        assert maxerr(mag.cpu(), g["mag%d" % nf]) < 2e-4
