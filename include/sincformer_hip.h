@@ -159,6 +159,31 @@ int sfm_spec_sums(const float* pr, const float* pi, const float* tr, const float
                   void* stream);
 int sfm_enhancer_loss_finalize(const double* Sw, const double* Sm, const double* Sr, const long long* nr, int B,
                                int L, long long n_mag, int R, float* out, void* stream);
+/* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
+/* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); bias grad */
+int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,
+                  int dtype, void* stream);
+int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream);
+int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
+                      float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream);
+/* mode 0 swish fwd, 1 swish bwd, 2 GLU fwd, 3 GLU bwd, 4 alpha*g*dropout; counter-based dropout (p, seed) */
+int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
+                 float alpha, float p, unsigned int seed, int dtype, void* stream);
+/* BatchNorm1d training statistics / backward (through the following Swish) */
+int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C,
+                  void* stream);
+int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, float* S, float* dy, int M, int C, int g_f32, int pass, int dtype,
+                     void* stream);
+int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, int B, int T, int C, int KS,
+                     int dtype, void* stream);
+/* attention forward for training (writes log2-domain LSE [B,H,T], applies attention dropout) and its backward */
+int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
+                            int ldo, int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
+                            float scale, float p_drop, unsigned int seed, int dtype, void* stream);
+int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv,
+                      int B, int T, int H, int hd, int ldqkv, int ldo, int koff, int voff, float p_drop,
+                      unsigned int seed, int dtype, void* stream);
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
 /* EpisodicMemory.forward eval (agents/memory.py:112-133) in one launch, see memory.hip */

@@ -25,11 +25,19 @@
 #define OS_ROW 72
 #define DEFER_THR 4.0f
 
+// same counter-based keep function as attention_bwd.hip / backward.hip
+__device__ __forceinline__ float attn_keep_fwd(uint32_t seed, unsigned long long idx, float p, float inv_keep) {
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return ((x >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
                                                             int Tlen, int ldqkv, int ldo, int koff, int voff,
                                                             long long qkv_batch_stride, long long o_batch_stride,
-                                                            float scale_log2e, int nqt, int nheads) {
+                                                            float scale_log2e, int nqt, int nheads,
+                                                            float* __restrict__ lse_out, float p_drop, uint32_t seed) {
   constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
 
@@ -198,6 +206,20 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
         pf[2] = pack2<T>(s[kj][8 * s2 + 4], s[kj][8 * s2 + 5]);
         pf[3] = pack2<T>(s[kj][8 * s2 + 6], s[kj][8 * s2 + 7]);
         lacc = T::mfma(vones, pf, lacc);                  // row sums of the (rounded) P, all 32 rows equal
+        if (p_drop > 0.f) {                               // attention dropout (training): O uses keep/(1-p) * P, l does not
+          const float ik = 1.0f / (1.0f - p_drop);
+          const unsigned long long rowbase = (((unsigned long long)b * nheads + h) * Tlen + (q0 + l31 < Tlen ? q0 + l31 : 0)) * Tlen;
+          float pd[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int key = kbase + kj * 32 + mfma_row(8 * s2 + e, lane);
+            pd[e] = s[kj][8 * s2 + e] * attn_keep_fwd(seed, rowbase + key, p_drop, ik);
+          }
+          pf[0] = pack2<T>(pd[0], pd[1]);
+          pf[1] = pack2<T>(pd[2], pd[3]);
+          pf[2] = pack2<T>(pd[4], pd[5]);
+          pf[3] = pack2<T>(pd[6], pd[7]);
+        }
         // transposed V reads: 16-lane group g -> d block (g&1)*16, lane half = g>>1;
         // lane 4q+p of the group addresses row q, cols 4p..4p+3 and receives column (lane&15)
         const int g16 = lane >> 4, i16 = lane & 15;
@@ -223,6 +245,8 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
 
   // ---- epilogue: normalise, transpose through LDS, coalesced stores ----
   const float inv = 1.0f / lacc[0];
+  if (lse_out && hl == 0 && q0 + l31 < Tlen)             // log2-domain log-sum-exp of the scaled scores (for the backward)
+    lse_out[((long long)b * nheads + h) * Tlen + q0 + l31] = m_run + __builtin_amdgcn_logf(lacc[0]);
   u16* Os = smem + wave * (32 * OS_ROW);
 #pragma unroll
   for (int dj = 0; dj < 2; ++dj)
@@ -298,10 +322,28 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
 }
 
 // qkv: [B, T, ldqkv] 16-bit with q at column h*hd, k at koff + h*hd, v at voff + h*hd.
+extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
+                                       int ldo, int koff, int voff, long long qkv_batch_stride,
+                                       long long o_batch_stride, float scale, float p_drop, unsigned int seed,
+                                       int dtype, void* stream);
+
 extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                                  int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
                                  float scale, int dtype, void* stream) {
+  return sfm_attention_fwd_train(qkv, out, nullptr, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride,
+                                 scale, 0.f, 0u, dtype, stream);
+}
+
+// training-mode forward: also writes lse [B,H,T] (log2 domain) and applies attention dropout (head_dim 64 only
+// when lse != NULL or p_drop > 0)
+extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
+                                       int ldo, int koff, int voff, long long qkv_batch_stride,
+                                       long long o_batch_stride, float scale, float p_drop, unsigned int seed,
+                                       int dtype, void* stream) {
   if (!qkv || !out) return SFM_ERR_ARG;
+  if ((lse || p_drop > 0.f) && hd != 64) return SFM_ERR_SHAPE;
+  if (p_drop < 0.f || p_drop >= 1.f) return SFM_ERR_SHAPE;
+  if ((lse || p_drop > 0.f) && (qkv_batch_stride != (long long)T * ldqkv)) return SFM_ERR_SHAPE;
   if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 256) return SFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (hd == 64 && (ldqkv % 8) == 0 && (ldo % 8) == 0 && (koff % 8) == 0 && (voff % 8) == 0 &&
@@ -312,10 +354,10 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
     float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
     if (dtype == SFM_DT_F16)
       SFM_LAUNCH((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
-                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H);
+                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed);
     else
       SFM_LAUNCH((attn_fwd_hd64_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
-                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H);
+                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed);
   } else {
     dim3 grid((T + 3) / 4, H, B), block(256);
     if (scale <= 0.f) scale = 0.69314718055994530942f;      // pre-scaled Q carries log2(e): exp(x ln2) = 2^x

@@ -1,0 +1,295 @@
+// Backward / training-mode kernels of the ConformerBlock (models/conformer.py:28-151) that are not GEMMs:
+// LayerNorm backward, activation (Swish / GLU) backward with counter-based dropout, BatchNorm1d
+// training statistics and backward, depthwise-conv weight gradient.  All HBM-bound streaming kernels.
+#include "sfm_common.h"
+
+// ---- counter-based dropout: keep(seed, idx) is a pure function, so forward and backward agree and no
+//      mask is stored.  (Statistically equivalent to, not bit-identical with, torch's Philox stream.)
+__device__ __forceinline__ uint32_t sfm_hash(uint32_t seed, unsigned long long idx) {
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float sfm_keep_scale(uint32_t seed, unsigned long long idx, float p, float inv_keep) {
+  // 0 if dropped, 1/(1-p) if kept
+  return ((sfm_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm backward: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//                     dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy          (D <= 512)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int M, int D, int ldx, int ld,
+                                                            float eps) {
+  __shared__ float red[4][2][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[8], pb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float* xr = x + (long long)row * ldx;
+    const float* gr = dy + (long long)row * ld;
+    float v[8], g[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = lane + 64 * i;
+      v[i] = (d < D) ? xr[d] : 0.f;
+      g[i] = (d < D) ? gr[d] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum_dpp(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = lane + 64 * i;
+      const float c = (d < D) ? v[i] - mean : 0.f;
+      v[i] = c;
+      q += c * c;
+    }
+    const float rstd = rsqrtf(wave_sum_dpp(q) / (float)D + eps);
+    float a = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = lane + 64 * i;
+      const float xh = v[i] * rstd;
+      v[i] = xh;
+      pg[i] += g[i] * xh;
+      pb[i] += g[i];
+      const float gg = (d < D) ? g[i] * gamma[d] : 0.f;
+      g[i] = gg;
+      a += gg;
+      bsum += gg * xh;
+    }
+    a = wave_sum_dpp(a) / (float)D;
+    bsum = wave_sum_dpp(bsum) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) {
+        float o = rstd * (g[i] - a - v[i] * bsum);
+        if (dres) o += dres[(long long)row * ld + d];
+        dx[(long long)row * ld + d] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    red[wave][0][lane + 64 * i] = pg[i];
+    red[wave][1][lane + 64 * i] = pb[i];
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    atomicAdd(&dgamma[d], red[0][0][d] + red[1][0][d] + red[2][0][d] + red[3][0][d]);
+    atomicAdd(&dbeta[d], red[0][1][d] + red[1][1][d] + red[2][1][d] + red[3][1][d]);
+  }
+}
+
+extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
+                                 float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream) {
+  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta) return SFM_ERR_ARG;
+  if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
+  int nb = (M + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  SFM_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dres, dx, dgamma, dbeta, M, D,
+             ldx, ld, eps);
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Element-wise forward/backward helpers (training mode)
+//   mode 0  SWISH_FWD : out16 = drop(swish(z))                       z 16-bit [M, N]
+//   mode 1  SWISH_BWD : out16 = g * drop * swish'(z)                 g fp32 or 16-bit
+//   mode 2  GLU_FWD   : out16 = a * sigmoid(b)                       z = [a | b] 16-bit [M, 2N]
+//   mode 3  GLU_BWD   : out16[M, 2N] = [ g*sigmoid(b) | g*a*sigmoid(b)*(1-sigmoid(b)) ]
+//   mode 4  SCALE_DROP: out(fp32|16) = alpha * g * drop              (residual-branch dropout, fwd and bwd)
+// `drop` = counter-based keep/(1-p) with element index m*N+n (p == 0 -> 1).
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void ew_train_kernel(const void* __restrict__ z, const void* __restrict__ g, void* __restrict__ out,
+                                                       long long M, int N, int mode, int g_f32, int out_f32, float alpha,
+                                                       float p, uint32_t seed) {
+  const float inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  const long long total = M * N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long m = e / N;
+    const int n = (int)(e - m * N);
+    const float dr = (p > 0.f) ? sfm_keep_scale(seed, (unsigned long long)e, p, inv_keep) : 1.0f;
+    float gv = 1.0f;
+    if (g) gv = g_f32 ? reinterpret_cast<const float*>(g)[e] : T::to_f32(reinterpret_cast<const u16*>(g)[e]);
+    if (mode == 0 || mode == 1) {
+      const float zv = T::to_f32(reinterpret_cast<const u16*>(z)[e]);
+      const float sg = sigmoid_f(zv);
+      const float r = (mode == 0) ? zv * sg * dr : gv * dr * sg * (1.0f + zv * (1.0f - sg));
+      reinterpret_cast<u16*>(out)[e] = T::from_f32(r);
+    } else if (mode == 2 || mode == 3) {
+      const u16* zr = reinterpret_cast<const u16*>(z) + m * (2LL * N);
+      const float a = T::to_f32(zr[n]), b = T::to_f32(zr[N + n]);
+      const float sg = sigmoid_f(b);
+      if (mode == 2) reinterpret_cast<u16*>(out)[e] = T::from_f32(a * sg);
+      else {
+        u16* orow = reinterpret_cast<u16*>(out) + m * (2LL * N);
+        orow[n] = T::from_f32(gv * sg);
+        orow[N + n] = T::from_f32(gv * a * sg * (1.0f - sg));
+      }
+    } else {
+      const float r = alpha * gv * dr;
+      if (out_f32) reinterpret_cast<float*>(out)[e] = r;
+      else reinterpret_cast<u16*>(out)[e] = T::from_f32(r);
+    }
+  }
+}
+
+extern "C" int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
+                            float alpha, float p, unsigned int seed, int dtype, void* stream) {
+  if (!out || (mode <= 3 && !z) || ((mode == 1 || mode == 3 || mode == 4) && !g)) return SFM_ERR_ARG;
+  if (M <= 0 || N <= 0 || mode < 0 || mode > 4 || p < 0.f || p >= 1.f) return SFM_ERR_SHAPE;
+  long long nb = (M * N + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (dtype == SFM_DT_F16)
+    SFM_LAUNCH((ew_train_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, z, g, out, M, N, mode, g_f32,
+               out_f32, alpha, p, seed);
+  else
+    SFM_LAUNCH((ew_train_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, z, g, out, M, N, mode, g_f32,
+               out_f32, alpha, p, seed);
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm1d training (models/conformer.py:95,118): statistics over all B*T rows per channel.
+//   col_stats: S[c] = { sum y, sum y^2 }  or, with aux (backward), { sum dy, sum dy * xhat }
+//   (accumulated with atomics; S must be zero-filled; y fp32 [M, C])
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, const float* __restrict__ aux,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        float* __restrict__ S, int M, int C, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f;
+  if (!aux) {
+    for (int m = m0; m < m1; ++m) {
+      const float v = y[(long long)m * C + c];
+      s0 += v;
+      s1 += v * v;
+    }
+  } else {                                               // y = dy, aux = pre-normalisation activations
+    const float mu = mean[c], rs = rstd[c];
+    for (int m = m0; m < m1; ++m) {
+      const float d = y[(long long)m * C + c];
+      s0 += d;
+      s1 += d * (aux[(long long)m * C + c] - mu) * rs;
+    }
+  }
+  atomicAdd(&S[2 * c], s0);
+  atomicAdd(&S[2 * c + 1], s1);
+}
+
+extern "C" int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C,
+                             void* stream) {
+  if (!y || !S || (aux && (!mean || !rstd))) return SFM_ERR_ARG;
+  if (M <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  const int rpb = 256;
+  SFM_LAUNCH(col_stats_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, y, aux, mean,
+             rstd, S, M, C, rpb);
+  return SFM_OK;
+}
+
+// BatchNorm backward applied through the following Swish:  given g = dL/d(swish out), y (pre-BN), batch mean/rstd,
+// gamma/beta:  t = (y-mu)*rs*gamma+beta ; dt = g * swish'(t) ;
+//   pass 0 (stats): S[c] = { sum dt, sum dt * xhat }       pass 1 (apply): dy = gamma*rs*(dt - S0/M - xhat*S1/M)
+template <class T>
+__global__ __launch_bounds__(256) void bn_swish_bwd_kernel(const void* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ S, float* __restrict__ dy, int M, int C,
+                                                           int g_f32, int pass, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  const float invM = 1.0f / (float)M;
+  float s0 = 0.f, s1 = 0.f;
+  const float a0 = pass ? S[2 * c] * invM : 0.f, a1 = pass ? S[2 * c + 1] * invM : 0.f;
+  for (int m = m0; m < m1; ++m) {
+    const long long e = (long long)m * C + c;
+    const float xh = (y[e] - mu) * rs;
+    const float t = xh * ga + be;
+    const float sg = sigmoid_f(t);
+    const float gv = g_f32 ? reinterpret_cast<const float*>(g)[e] : T::to_f32(reinterpret_cast<const u16*>(g)[e]);
+    const float dt = gv * sg * (1.0f + t * (1.0f - sg));
+    if (!pass) { s0 += dt; s1 += dt * xh; }
+    else dy[e] = ga * rs * (dt - a0 - xh * a1);
+  }
+  if (!pass) {
+    atomicAdd(&S[2 * c], s0);
+    atomicAdd(&S[2 * c + 1], s1);
+  }
+}
+
+extern "C" int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, float* S, float* dy, int M, int C, int g_f32, int pass, int dtype,
+                                void* stream) {
+  if (!g || !y || !mean || !rstd || !gamma || !beta || !S || (pass && !dy)) return SFM_ERR_ARG;
+  if (M <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  const int rpb = 256;
+  dim3 grid((C + 255) / 256, (M + rpb - 1) / rpb), block(256);
+  if (dtype == SFM_DT_F16)
+    SFM_LAUNCH((bn_swish_bwd_kernel<F16>), grid, block, 0, (hipStream_t)stream, g, y, mean, rstd, gamma, beta, S, dy, M, C,
+               g_f32, pass, rpb);
+  else
+    SFM_LAUNCH((bn_swish_bwd_kernel<BF16>), grid, block, 0, (hipStream_t)stream, g, y, mean, rstd, gamma, beta, S, dy, M, C,
+               g_f32, pass, rpb);
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Depthwise conv weight gradient: dW[c][k] += sum_{b,t} dY[b,t,c] * X[b, t+k-pad, c]   (X 16-bit, dY fp32)
+// one thread per channel, KS accumulators, a block covers a span of frames of one utterance
+// ---------------------------------------------------------------------------
+template <class T, int KS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const u16* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ db, int Tlen,
+                                                           int C, int span) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * span, t1 = min(Tlen, t0 + span);
+  constexpr int pad = (KS - 1) / 2;
+  const u16* xb = x + (long long)b * Tlen * C + c;
+  const float* gb = dy + (long long)b * Tlen * C + c;
+  float acc[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) acc[k] = 0.f;
+  float sb = 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const float g = gb[(long long)t * C];
+    sb += g;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int tt = t + k - pad;
+      const float xv = (tt >= 0 && tt < Tlen) ? T::to_f32(xb[(long long)tt * C]) : 0.f;
+      acc[k] += g * xv;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KS; ++k) atomicAdd(&dw[c * KS + k], acc[k]);
+  atomicAdd(&db[c], sb);
+}
+
+extern "C" int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, int B, int T, int C, int KS,
+                                int dtype, void* stream) {
+  if (!x || !dy || !dw || !db) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || C <= 0 || (KS != 31 && KS != 7)) return SFM_ERR_SHAPE;
+  const int span = 64;
+  dim3 grid((C + 255) / 256, (T + span - 1) / span, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define GO(TT, KK) SFM_LAUNCH((dwconv_wgrad_kernel<TT, KK>), grid, block, 0, st, (const u16*)x, dy, dw, db, T, C, span)
+  if (dtype == SFM_DT_F16) { if (KS == 31) GO(F16, 31); else GO(F16, 7); }
+  else { if (KS == 31) GO(BF16, 31); else GO(BF16, 7); }
+#undef GO
+  return SFM_OK;
+}

@@ -1,0 +1,174 @@
+// Weight-gradient GEMM of every Linear / 1x1 conv on the path (backward of models/conformer.py:44,47,
+// 113,122 and of in_proj/out_proj):   dW[n, k] += sum_m G[m, n] * X[m, k]      (G = dL/dY, X = layer input)
+// Both operands are row-major with the CONTRACTION index m as the slow dimension, so both MFMA
+// fragments (8 consecutive m for one n / one k) are transposed reads: the [64 m][128] 16-bit tiles are
+// staged row-major in LDS (320-byte rows: the 4 rows x 64 B of a transposed read tile the 256-B bank
+// row) and fetched with ds_read_b64_tr_b16.  Output tile 128 (n) x 128 (k), 4 waves x 64x64.
+// M is split over gridDim.z; partial tiles are accumulated into the fp32 dW with float atomics
+// (128-byte contiguous per wave-instruction).  sfm_colsum gives the bias gradient.
+#include "sfm_common.h"
+
+#define TN_ROW 160      // u16 elements per LDS row (128 + 32 pad) = 320 B
+
+template <class T>
+__global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
+                                                        float* __restrict__ dW, int M, int N, int K, int ldg, int ldx,
+                                                        int ldw, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) u16 Gs[64 * TN_ROW];
+  __shared__ __attribute__((aligned(16))) u16 Xs[64 * TN_ROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int m_begin = blockIdx.z * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: 64 rows x 16 chunks (16 B) per operand -> 4 chunks per thread per operand
+  int srow[4], scol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    srow[i] = c >> 4;
+    scol[i] = (c & 15) * 8;
+  }
+  u32x4 rg[4], rx[4];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mt + srow[i];
+      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+      if (m < m_end) {
+        if (n0 + scol[i] + 8 <= N) a = *reinterpret_cast<const u32x4*>(G + (long long)m * ldg + n0 + scol[i]);
+        else {
+          u16 t[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = (n0 + scol[i] + e < N) ? G[(long long)m * ldg + n0 + scol[i] + e] : (u16)0;
+          a = *reinterpret_cast<const u32x4*>(t);
+        }
+        if (k0 + scol[i] + 8 <= K) b = *reinterpret_cast<const u32x4*>(X + (long long)m * ldx + k0 + scol[i]);
+        else {
+          u16 t[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = (k0 + scol[i] + e < K) ? X[(long long)m * ldx + k0 + scol[i] + e] : (u16)0;
+          b = *reinterpret_cast<const u32x4*>(t);
+        }
+      }
+      rg[i] = a;
+      rx[i] = b;
+    }
+  };
+
+  // transposed-read lane coordinates (see attention.hip): 16-lane group g -> column block (g&1)*16,
+  // contraction rows 4*(g>>1) + q (and +8); lane 4q+p supplies row q, columns 4p..4p+3
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  const int trow = 4 * (g16 >> 1) + qq;
+  const int tcol = (g16 & 1) * 16 + 4 * pp;
+
+  load_tile(m_begin);
+  for (int mt = m_begin; mt < m_end; mt += 64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(&Gs[srow[i] * TN_ROW + scol[i]]) = rg[i];
+      *reinterpret_cast<u32x4*>(&Xs[srow[i] * TN_ROW + scol[i]]) = rx[i];
+    }
+    __syncthreads();
+    if (mt + 64 < m_end) load_tile(mt + 64);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u16* base = &Gs[(16 * s + trow) * TN_ROW + wn * 64 + i * 32 + tcol];
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 8 * TN_ROW));
+        const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
+        fa[i] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u16* base = &Xs[(16 * s + trow) * TN_ROW + wk * 64 + j * 32 + tcol];
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 8 * TN_ROW));
+        const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
+        fb[j] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + mfma_row(r, lane);
+        if (n < N && k < K) atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+      }
+    }
+}
+
+// out[n] += sum_m G[m, n]   (bias gradient); G fp32 or 16-bit
+template <class T>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, float* __restrict__ out, int M, int N,
+                                                     int ldg, int g_f32, int rows_per_block) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  if (g_f32) {
+    const float* g = reinterpret_cast<const float*>(G);
+    for (int m = m0; m < m1; ++m) s += g[(long long)m * ldg + n];
+  } else {
+    const u16* g = reinterpret_cast<const u16*>(G);
+    for (int m = m0; m < m1; ++m) s += T::to_f32(g[(long long)m * ldg + n]);
+  }
+  atomicAdd(&out[n], s);
+}
+
+extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,
+                             int dtype, void* stream) {
+  if (!G || !X || !dW) return SFM_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (ldx % 8) != 0) return SFM_ERR_SHAPE;
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int splits = (1024 + tiles - 1) / tiles;                    // aim at ~1024 workgroups
+  const int max_splits = (M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rows = (M + splits - 1) / splits;
+  rows = (rows + 63) / 64 * 64;
+  splits = (M + rows - 1) / rows;
+  dim3 grid((N + 127) / 128, (K + 127) / 128, splits), block(256);
+  if (dtype == SFM_DT_F16)
+    SFM_LAUNCH((gemm16_tn_kernel<F16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, M, N, K, ldg,
+               ldx, ldw, rows);
+  else
+    SFM_LAUNCH((gemm16_tn_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, M, N, K,
+               ldg, ldx, ldw, rows);
+  return SFM_OK;
+}
+
+extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream) {
+  if (!G || !out) return SFM_ERR_ARG;
+  if (M <= 0 || N <= 0) return SFM_ERR_SHAPE;
+  int rpb = 512;
+  dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb), block(256);
+  if (dtype == SFM_DT_F16)
+    SFM_LAUNCH((colsum_kernel<F16>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, g_f32, rpb);
+  else
+    SFM_LAUNCH((colsum_kernel<BF16>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, g_f32, rpb);
+  return SFM_OK;
+}

@@ -53,6 +53,17 @@ SIGNATURES = {
     "sfm_wave_moments": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "sfm_spec_sums": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
     "sfm_enhancer_loss_finalize": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_ll, c_i, c_vp, c_vp],
+    "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
+    "sfm_ew_train": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_uint, c_i, c_vp],
+    "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "sfm_bn_swish_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_dwconv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_attention_fwd_train": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_f,
+                                ctypes.c_uint, c_i, c_vp],
+    "sfm_attention_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
+                          ctypes.c_uint, c_i, c_vp],
     "sfm_bilstm_layer": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_memory_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
 }

@@ -449,6 +449,99 @@ def enhancer_loss_finalize(Sw, Sm, Sr, nr, B, Ln, n_mag):
     return out
 
 
+# ---------------------------------------------------------------------------
+# training path (ConformerBlock backward)
+# ---------------------------------------------------------------------------
+def gemm16_tn(G16, X16, dW):
+    """dW[n,k] += sum_m G16[m,n] * X16[m,k]   (dW fp32, accumulated)."""
+    L = _lib.load()
+    M, N = G16.shape
+    K = X16.shape[1]
+    _call("gemm16_tn", L.sfm_gemm16_tn, (_p(G16), _p(X16), _p(dW), M, N, K, G16.stride(0), X16.stride(0), dW.stride(0), _dt(),
+                                         _stream()), 2.0 * M * N * K, M * (N + K) * 2.0)
+
+
+def colsum(G, out):
+    L = _lib.load()
+    M, N = G.shape
+    _call("colsum", L.sfm_colsum, (_p(G), _p(out), M, N, G.stride(0), 1 if G.dtype == torch.float32 else 0, _dt(), _stream()))
+
+
+def layernorm_bwd(x32, gamma, dy32, dres32, dgamma, dbeta, eps=1e-5):
+    L = _lib.load()
+    M, D = dy32.shape
+    dx = torch.empty_like(dy32)
+    _call("layernorm_bwd", L.sfm_layernorm_bwd, (_p(x32), _p(gamma), _p(dy32), _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
+                                                 x32.stride(0), dy32.stride(0), eps, _stream()))
+    return dx
+
+
+EW_SWISH_FWD, EW_SWISH_BWD, EW_GLU_FWD, EW_GLU_BWD, EW_SCALE_DROP = range(5)
+
+
+def ew_train(mode, out, z=None, g=None, N=None, alpha=1.0, p=0.0, seed=0):
+    L = _lib.load()
+    M = out.shape[0]
+    N = N if N is not None else (out.shape[1] // 2 if mode == EW_GLU_BWD else out.shape[1])
+    _call("ew_train", L.sfm_ew_train, (_p(z), _p(g), _p(out), M, N, mode, 1 if (g is not None and g.dtype == torch.float32) else 0,
+                                       1 if out.dtype == torch.float32 else 0, float(alpha), float(p), int(seed) & 0xffffffff,
+                                       _dt(), _stream()))
+    return out
+
+
+def col_stats(y32, aux=None, mean=None, rstd=None):
+    L = _lib.load()
+    M, C = y32.shape
+    S = torch.zeros(C, 2, device=y32.device, dtype=torch.float32)
+    _call("col_stats", L.sfm_col_stats, (_p(y32), _p(aux), _p(mean), _p(rstd), _p(S), M, C, _stream()))
+    return S
+
+
+def bn_swish_bwd(g, y32, mean, rstd, gamma, beta):
+    """backward through Swish(BatchNorm_train(y)): returns dy [M,C] fp32, dgamma, dbeta."""
+    L = _lib.load()
+    M, C = y32.shape
+    S = torch.zeros(C, 2, device=y32.device, dtype=torch.float32)
+    dy = torch.empty_like(y32)
+    gf = 1 if g.dtype == torch.float32 else 0
+    for ps in (0, 1):
+        _call("bn_swish_bwd", L.sfm_bn_swish_bwd, (_p(g), _p(y32), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(S), _p(dy), M, C, gf,
+                                                   ps, _dt(), _stream()))
+    return dy, S[:, 1].contiguous(), S[:, 0].contiguous()
+
+
+def dwconv_wgrad(x16, dy32, B, T, C, KS):
+    L = _lib.load()
+    dw = torch.zeros(C, KS, device=x16.device, dtype=torch.float32)
+    db = torch.zeros(C, device=x16.device, dtype=torch.float32)
+    _call("dwconv_wgrad", L.sfm_dwconv_wgrad, (_p(x16), _p(dy32), _p(dw), _p(db), B, T, C, KS, _dt(), _stream()))
+    return dw, db
+
+
+def attention_train(qkv16, B, T, H, hd, p_drop=0.0, seed=0):
+    """training forward (q pre-scaled): returns O [B*T, D] 16-bit and LSE [B,H,T] fp32 (log2 domain)."""
+    L = _lib.load()
+    D = H * hd
+    ld = qkv16.stride(0)
+    out = torch.empty(B * T, D, device=qkv16.device, dtype=qkv16.dtype)
+    lse = torch.empty(B, H, T, device=qkv16.device, dtype=torch.float32)
+    _call("attention_fwd", L.sfm_attention_fwd_train, (_p(qkv16), _p(out), _p(lse), B, T, H, hd, ld, out.stride(0), D, 2 * D,
+                                                       T * ld, T * out.stride(0), -1.0, float(p_drop), int(seed) & 0xffffffff,
+                                                       _dt(), _stream()), 4.0 * B * H * T * T * hd, 4.0 * B * T * D * 2)
+    return out, lse
+
+
+def attention_bwd(qkv16, O16, dO16, lse, B, T, H, hd, p_drop=0.0, seed=0):
+    L = _lib.load()
+    D = H * hd
+    dqkv = torch.empty_like(qkv16)
+    delta = torch.empty(B, H, T, device=qkv16.device, dtype=torch.float32)
+    _call("attention_bwd", L.sfm_attention_bwd, (_p(qkv16), _p(O16), _p(dO16), _p(lse), _p(delta), _p(dqkv), B, T, H, hd,
+                                                 qkv16.stride(0), O16.stride(0), D, 2 * D, float(p_drop), int(seed) & 0xffffffff,
+                                                 _dt(), _stream()), 10.0 * B * H * T * T * hd, 8.0 * B * T * D * 2)
+    return dqkv
+
+
 def bilstm_layer(xg, whh, B, T, H):
     L = _lib.load()
     out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)

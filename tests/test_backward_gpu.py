@@ -1,0 +1,194 @@
+"""Parity of the training-path kernels (backward of the ConformerBlock) against torch autograd on CPU."""
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import arr, maxerr, rmse
+from oracle import sfm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.bfloat16, torch.float16]
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from sincformer_metacog_speech_enhancement_amd import ops as _ops
+    return _ops
+
+
+def q16(x, dt):
+    return x.to(dt).float()
+
+
+def report(name, got, ref, tol):
+    e, r = maxerr(got, ref), rmse(got, ref)
+    print("%-44s max|err| %.3e rmse %.3e tol %.1e ref_rms %.3e" % (name, e, r, tol, float(torch.as_tensor(np.asarray(ref)).double().pow(2).mean().sqrt())))
+    assert math.isfinite(e) and e <= tol, name
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (5000, 1024, 256), (333, 129, 128), (4096, 256, 1024), (70, 768, 256)])
+def test_gemm16_tn_and_colsum(ops, dt, M, N, K):
+    ops.set_compute_dtype(dt)
+    g, x = arr("tg", (M, N), 1) * 0.1, arr("tx", (M, K), 2)
+    dW = torch.zeros(N, K, device="cuda")
+    gbuf = torch.zeros(M, (N + 7) // 8 * 8, device="cuda", dtype=dt)       # row stride must be a multiple of 8 elements
+    gbuf[:, :N] = g.cuda().to(dt)
+    ops.gemm16_tn(gbuf[:, :N], x.cuda().to(dt).contiguous(), dW)
+    ref = q16(g, dt).t() @ q16(x, dt)
+    report("wgrad %dx%dx%d %s" % (M, N, K, dt), dW.cpu(), ref, 2e-3 * math.sqrt(M / 1000.0))
+    db = torch.zeros(N, device="cuda")
+    ops.colsum(g.cuda(), db)
+    report("colsum fp32", db.cpu(), g.sum(0), 1e-3)
+    db.zero_()
+    ops.colsum(g.cuda().to(dt), db)
+    report("colsum 16", db.cpu(), q16(g, dt).sum(0), 1e-3)
+
+
+@pytest.mark.parametrize("M,D", [(300, 256), (77, 64), (50, 258)])
+def test_layernorm_bwd(ops, M, D):
+    x = (arr("lx", (M, D), 3, 2.0) + 0.3).requires_grad_(True)
+    w = (arr("lw", (D,), 4) * 0.1 + 1).requires_grad_(True)
+    b = (arr("lb", (D,), 5) * 0.1).requires_grad_(True)
+    dy, dres = arr("ldy", (M, D), 6), arr("ldr", (M, D), 7)
+    y = orc.layer_norm(x, w, b)
+    y.backward(dy)
+    dg, dbt = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx = ops.layernorm_bwd(x.detach().cuda(), w.detach().cuda(), dy.cuda(), dres.cuda(), dg, dbt)
+    report("ln bwd dx", dx.cpu(), x.grad + dres, 2e-5)
+    report("ln bwd dgamma", dg.cpu(), w.grad, 2e-4)
+    report("ln bwd dbeta", dbt.cpu(), b.grad, 2e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_elementwise_train(ops, dt):
+    ops.set_compute_dtype(dt)
+    M, N = 200, 256
+    z, g = arr("ez", (M, N), 8, 2.0), arr("eg", (M, N), 9)
+    zq = q16(z, dt).requires_grad_(True)
+    u = orc.swish(zq)
+    u.backward(g)
+    z16 = z.cuda().to(dt)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.ew_train(ops.EW_SWISH_FWD, out, z=z16)
+    report("swish fwd", out.float().cpu(), u.detach(), 4 * EPS[dt] * 3)
+    ops.ew_train(ops.EW_SWISH_BWD, out, z=z16, g=g.cuda())
+    report("swish bwd", out.float().cpu(), zq.grad, 4 * EPS[dt] * 4)
+    # GLU
+    h = arr("eh", (M, 2 * N), 10, 1.5)
+    hq = q16(h, dt).requires_grad_(True)
+    y = hq[:, :N] * torch.sigmoid(hq[:, N:])
+    y.backward(g)
+    h16 = h.cuda().to(dt)
+    ops.ew_train(ops.EW_GLU_FWD, out, z=h16)
+    report("glu fwd", out.float().cpu(), y.detach(), 4 * EPS[dt] * 3)
+    o2 = torch.empty(M, 2 * N, device="cuda", dtype=dt)
+    ops.ew_train(ops.EW_GLU_BWD, o2, z=h16, g=g.cuda())
+    report("glu bwd", o2.float().cpu(), hq.grad, 4 * EPS[dt] * 4)
+    # dropout: keep fraction, scaling, determinism
+    o32 = torch.empty(M, N, device="cuda")
+    ones = torch.ones(M, N, device="cuda")
+    ops.ew_train(ops.EW_SCALE_DROP, o32, g=ones, alpha=0.5, p=0.25, seed=123)
+    vals = o32.cpu()
+    kept = (vals != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.02 and abs(float(vals.max()) - 0.5 / 0.75) < 1e-6
+    o33 = torch.empty(M, N, device="cuda")
+    ops.ew_train(ops.EW_SCALE_DROP, o33, g=ones, alpha=0.5, p=0.25, seed=123)
+    assert torch.equal(o32, o33)
+    ops.ew_train(ops.EW_SCALE_DROP, o33, g=ones, alpha=0.5, p=0.25, seed=124)
+    assert not torch.equal(o32, o33)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_batchnorm_train_and_dwconv_wgrad(ops, dt):
+    ops.set_compute_dtype(dt)
+    B, T, C, KS = 3, 50, 256, 31
+    M = B * T
+    y = (arr("by", (M, C), 11, 1.5) + 0.2).requires_grad_(True)
+    gamma = (arr("bg", (C,), 12) * 0.1 + 1).requires_grad_(True)
+    beta = (arr("bb", (C,), 13) * 0.1).requires_grad_(True)
+    g = arr("bgr", (M, C), 14)
+    mu = y.mean(0)
+    var = ((y - mu) ** 2).mean(0)
+    t = (y - mu) / torch.sqrt(var + 1e-5) * gamma + beta
+    out = orc.swish(t)
+    out.backward(g)
+    S = ops.col_stats(y.detach().cuda())
+    mean = S[:, 0] / M
+    varg = S[:, 1] / M - mean * mean
+    report("bn batch mean", mean.cpu(), mu.detach(), 1e-5)
+    report("bn batch var", varg.cpu(), var.detach(), 1e-4)
+    rstd = torch.rsqrt(varg + 1e-5)
+    dy, dgam, dbet = ops.bn_swish_bwd(g.cuda(), y.detach().cuda(), mean, rstd, gamma.detach().cuda(), beta.detach().cuda())
+    report("bn+swish bwd dy", dy.cpu(), y.grad, 2e-4)
+    report("bn dgamma", dgam.cpu(), gamma.grad, 2e-3)
+    report("bn dbeta", dbet.cpu(), beta.grad, 2e-3)
+    # depthwise conv weight gradient
+    x = arr("wx", (B, T, C), 15)
+    w = (arr("ww", (C, 1, KS), 16) / math.sqrt(KS)).requires_grad_(True)
+    bb = (arr("wb", (C,), 17) * 0.1).requires_grad_(True)
+    gy = arr("wg", (B, T, C), 18)
+    o = F.conv1d(q16(x, dt).transpose(1, 2), w, bb, padding=15, groups=C).transpose(1, 2)
+    o.backward(gy)
+    dw, db = ops.dwconv_wgrad(x.cuda().to(dt).contiguous(), gy.cuda().contiguous(), B, T, C, KS)
+    report("dwconv wgrad", dw.cpu(), w.grad.reshape(C, KS), 2e-4)
+    report("dwconv bgrad", db.cpu(), bb.grad, 2e-4)
+
+
+def _attn_ref(qkv, B, T, H, hd, keep=None):
+    """q pre-scaled (log2 domain): P = softmax(ln2 * q'.k)"""
+    D = H * hd
+    q, k, v = qkv.reshape(B, T, 3 * D).split(D, dim=-1)
+    q = q.reshape(B, T, H, hd).transpose(1, 2)
+    k = k.reshape(B, T, H, hd).transpose(1, 2)
+    v = v.reshape(B, T, H, hd).transpose(1, 2)
+    s2 = q @ k.transpose(-1, -2)
+    p = torch.softmax(s2 * math.log(2.0), dim=-1)
+    lse2 = torch.logsumexp(s2 * math.log(2.0), dim=-1) / math.log(2.0)
+    if keep is not None:
+        p = p * keep
+    return (p @ v).transpose(1, 2).reshape(B * T, D), lse2
+
+
+def _keep_mask(seed, B, H, T, p):
+    """numpy replica of the counter-based keep function (attention.hip / attention_bwd.hip)"""
+    idx = np.arange(B * H * T * T, dtype=np.uint64)
+    x = ((idx & np.uint64(0xFFFFFFFF)) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    x ^= ((idx >> np.uint64(32)) * np.uint64(0x85EBCA77)) & np.uint64(0xFFFFFFFF)
+    x ^= np.uint64(seed)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    u = (x >> np.uint64(8)).astype(np.float64) / 16777216.0
+    keep = (u >= p).astype(np.float32) / (1.0 - p)
+    return torch.from_numpy(keep.reshape(B, H, T, T))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,H,p", [(2, 200, 4, 0.0), (1, 64, 2, 0.0), (2, 129, 1, 0.0), (1, 150, 2, 0.15)])
+def test_attention_train_fwd_bwd(ops, dt, B, T, H, p):
+    ops.set_compute_dtype(dt)
+    hd, seed = 64, 77
+    D = H * hd
+    qkv = arr("aq", (B * T, 3 * D), 40 + T, 1.0)
+    qkv[:, :D] *= 0.35                       # q' ~ pre-scaled magnitude
+    dO = arr("ado", (B * T, D), 41 + T, 0.5)
+    qq = q16(qkv, dt).requires_grad_(True)
+    keep = _keep_mask(seed, B, H, T, p) if p > 0 else None
+    ref_o, ref_lse = _attn_ref(qq, B, T, H, hd, keep)
+    ref_o.backward(q16(dO, dt))
+    q16d = qkv.cuda().to(dt).contiguous()
+    O, lse = ops.attention_train(q16d, B, T, H, hd, p_drop=p, seed=seed)
+    report("attn train fwd O p=%.2f" % p, O.float().cpu(), ref_o.detach(), 8 * EPS[dt])
+    report("attn train lse", lse.cpu(), ref_lse.detach(), 6e-3 if dt is torch.bfloat16 else 1e-3)
+    dqkv = ops.attention_bwd(q16d, O, dO.cuda().to(dt).contiguous(), lse, B, T, H, hd, p_drop=p, seed=seed)
+    gref = qq.grad
+    scale = float(gref.abs().max())
+    report("attn bwd dq", dqkv.float().cpu()[:, :D], gref[:, :D], 0.03 * scale + 8 * EPS[dt] * scale)
+    report("attn bwd dk", dqkv.float().cpu()[:, D:2 * D], gref[:, D:2 * D], 0.03 * scale + 8 * EPS[dt] * scale)
+    report("attn bwd dv", dqkv.float().cpu()[:, 2 * D:], gref[:, 2 * D:], 0.03 * scale + 8 * EPS[dt] * scale)
+    assert rmse(dqkv.float().cpu(), gref) < (0.02 if dt is torch.bfloat16 else 0.004) * float(gref.pow(2).mean().sqrt()) + 1e-6
