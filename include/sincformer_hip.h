@@ -112,7 +112,7 @@ int sfm_dwconv_bn_swish(const void* x, const float* wdw, const float* bdw, const
 /* same operation with host-folded operands (wT [KS][C], BatchNorm+bias folded into sc/sh), register-resident
  * taps; KS in {7, 31}, C in {64, 128, 256, 512} */
 int sfm_dwconv_folded(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int T,
-                      int C, int KS, int dtype, void* stream);
+                      int C, int KS, int act, int out_f32, int dtype, void* stream);
 
 /* layout / packing */
 int sfm_convert_rows(const float* src, void* dst, long long M, int C, int Cz, long long ld_src,

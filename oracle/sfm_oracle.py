@@ -284,8 +284,16 @@ def mhsa(x, sd, num_heads):
     return x + o
 
 
-def conv_module(x, sd):
-    """ConvolutionModule.forward eval — models/conformer.py:101-128."""
+def batch_norm_train(x, w, b, eps=1e-5):
+    """nn.BatchNorm1d in training mode on [B, C, T]: biased batch statistics over (B, T)."""
+    mu = x.mean(dim=(0, 2), keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=(0, 2), keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w.view(1, -1, 1) + b.view(1, -1, 1)
+
+
+def conv_module(x, sd, bn_train=False):
+    """ConvolutionModule.forward — models/conformer.py:101-128 (bn_train: BatchNorm batch statistics,
+    i.e. module.train() with dropout p = 0)."""
     B, T, D = x.shape
     h = layer_norm(x, sd["layer_norm.weight"], sd["layer_norm.bias"]).transpose(1, 2)
     h = F.conv1d(h, sd["pointwise1.weight"], sd["pointwise1.bias"])
@@ -293,18 +301,21 @@ def conv_module(x, sd):
     h = a * torch.sigmoid(g)
     ksz = sd["depthwise.weight"].shape[-1]
     h = F.conv1d(h, sd["depthwise.weight"], sd["depthwise.bias"], padding=(ksz - 1) // 2, groups=D)
-    h = batch_norm_eval(h, sd["batch_norm.weight"], sd["batch_norm.bias"],
-                        sd["batch_norm.running_mean"], sd["batch_norm.running_var"])
+    if bn_train:
+        h = batch_norm_train(h, sd["batch_norm.weight"], sd["batch_norm.bias"])
+    else:
+        h = batch_norm_eval(h, sd["batch_norm.weight"], sd["batch_norm.bias"],
+                            sd["batch_norm.running_mean"], sd["batch_norm.running_var"])
     h = swish(h)
     h = F.conv1d(h, sd["pointwise2.weight"], sd["pointwise2.bias"]).transpose(1, 2)
     return x + h
 
 
-def conformer_block(x, sd, num_heads):
+def conformer_block(x, sd, num_heads, bn_train=False):
     """ConformerBlock.forward — models/conformer.py:145-151."""
     x = ffn(x, sub(sd, "ff1"))
     x = mhsa(x, sub(sd, "mhsa"), num_heads)
-    x = conv_module(x, sub(sd, "conv"))
+    x = conv_module(x, sub(sd, "conv"), bn_train)
     x = ffn(x, sub(sd, "ff2"))
     return layer_norm(x, sd["final_norm.weight"], sd["final_norm.bias"])
 

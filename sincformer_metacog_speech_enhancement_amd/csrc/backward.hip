@@ -105,7 +105,7 @@ extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float
 //   mode 1  SWISH_BWD : out16 = g * drop * swish'(z)                 g fp32 or 16-bit
 //   mode 2  GLU_FWD   : out16 = a * sigmoid(b)                       z = [a | b] 16-bit [M, 2N]
 //   mode 3  GLU_BWD   : out16[M, 2N] = [ g*sigmoid(b) | g*a*sigmoid(b)*(1-sigmoid(b)) ]
-//   mode 4  SCALE_DROP: out(fp32|16) = alpha * g * drop              (residual-branch dropout, fwd and bwd)
+//   mode 4  SCALE_DROP: out(fp32|16) = [z fp32 +] alpha * g * drop   (residual-branch dropout, fwd and bwd)
 // `drop` = counter-based keep/(1-p) with element index m*N+n (p == 0 -> 1).
 // ---------------------------------------------------------------------------
 template <class T>
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void ew_train_kernel(const void* __restrict__ 
         orow[N + n] = T::from_f32(gv * a * sg * (1.0f - sg));
       }
     } else {
-      const float r = alpha * gv * dr;
+      float r = alpha * gv * dr;
+      if (z) r += reinterpret_cast<const float*>(z)[e];          // mode 4: optional fp32 residual
       if (out_f32) reinterpret_cast<float*>(out)[e] = r;
       else reinterpret_cast<u16*>(out)[e] = T::from_f32(r);
     }

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, const flo
     if (act == 1) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+    } else if (act == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = swish_f(v[i]);
     }
     store8<T>(out, out_f32, e * 8, v);
   }
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(const u16* __restr
 template <class T, int KS>
 __global__ __launch_bounds__(256) void dwconv_reg_kernel(const u16* __restrict__ x, const float* __restrict__ wT,
                                                          const float* __restrict__ sc, const float* __restrict__ sh,
-                                                         u16* __restrict__ out, int Tlen, int C) {
+                                                         void* __restrict__ out, int Tlen, int C, int act, int out_f32) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   u16* xs = reinterpret_cast<u16*>(dsm);                                 // [DW_TT + KS - 1][C]
   constexpr int padl = (KS - 1) / 2, rows = DW_TT + KS - 1;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const u16* __restrict__
   }
   const float s0 = sc[c], s1 = sc[c + 1], h0 = sh[c], h1 = sh[c + 1];
   __syncthreads();
-  u16* ob = out + (long long)b * Tlen * C;
+  const long long obase = (long long)b * Tlen * C;
   const int per = DW_TT / ngrp;                                          // frames per thread (multiple of 4)
   for (int tl = grp * per; tl < (grp + 1) * per; tl += 4) {
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -323,8 +326,15 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const u16* __restrict__
     for (int o = 0; o < 4; ++o) {
       const int t = t0 + tl + o;
       if (t < Tlen) {
-        const float y0 = swish_f(a0[o] * s0 + h0), y1 = swish_f(a1[o] * s1 + h1);
-        *reinterpret_cast<uint32_t*>(&ob[(long long)t * C + c]) = pack2<T>(y0, y1);
+        float y0 = a0[o] * s0 + h0, y1 = a1[o] * s1 + h1;
+        if (act) { y0 = swish_f(y0); y1 = swish_f(y1); }
+        const long long off = obase + (long long)t * C + c;
+        if (out_f32) {
+          f32x2 w = {y0, y1};
+          *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(out) + off) = w;
+        } else {
+          *reinterpret_cast<uint32_t*>(reinterpret_cast<u16*>(out) + off) = pack2<T>(y0, y1);
+        }
       }
     }
   }
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const u16* __restrict__
 
 template <class T, int KS>
 static int launch_dwconv_reg(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int Tn,
-                             int C, hipStream_t st) {
+                             int C, int act, int out_f32, hipStream_t st) {
   const int lds = (DW_TT + KS - 1) * C * 2;
   static bool attr = false;
   if (!attr) {
@@ -341,22 +351,22 @@ static int launch_dwconv_reg(const void* x, const float* wT, const float* sc, co
     attr = true;
   }
   SFM_LAUNCH((dwconv_reg_kernel<T, KS>), dim3((Tn + DW_TT - 1) / DW_TT, B), dim3(256), lds, st, (const u16*)x, wT, sc, sh,
-             (u16*)out, Tn, C);
+             out, Tn, C, act, out_f32);
   return SFM_OK;
 }
 
 // wT [KS][C] fp32 (transposed depthwise weights), sc/sh [C] = BatchNorm(eval) folded with the conv bias:
-// y = swish(conv(x) * sc + sh)
+// y = act ? swish(conv(x) * sc + sh) : conv(x) * sc + sh ; 16-bit or fp32 output
 extern "C" int sfm_dwconv_folded(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int T,
-                                 int C, int KS, int dtype, void* stream) {
+                                 int C, int KS, int act, int out_f32, int dtype, void* stream) {
   if (!x || !wT || !sc || !sh || !out) return SFM_ERR_ARG;
   if (B <= 0 || T <= 0 || C % 8 != 0 || C > 512 || (256 % (C / 2)) != 0 || (DW_TT / (256 / (C / 2))) % 4 != 0)
     return SFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (KS == 31) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 31>(x, wT, sc, sh, out, B, T, C, st)
-                                           : launch_dwconv_reg<BF16, 31>(x, wT, sc, sh, out, B, T, C, st);
-  if (KS == 7) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 7>(x, wT, sc, sh, out, B, T, C, st)
-                                          : launch_dwconv_reg<BF16, 7>(x, wT, sc, sh, out, B, T, C, st);
+  if (KS == 31) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 31>(x, wT, sc, sh, out, B, T, C, act, out_f32, st)
+                                           : launch_dwconv_reg<BF16, 31>(x, wT, sc, sh, out, B, T, C, act, out_f32, st);
+  if (KS == 7) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 7>(x, wT, sc, sh, out, B, T, C, act, out_f32, st)
+                                          : launch_dwconv_reg<BF16, 7>(x, wT, sc, sh, out, B, T, C, act, out_f32, st);
   return SFM_ERR_SHAPE;
 }
 

@@ -36,7 +36,7 @@ SIGNATURES = {
     "sfm_gn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_f, c_vp],
     "sfm_gn_apply": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_dwconv_bn_swish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp],
-    "sfm_dwconv_folded": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_dwconv_folded": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_convert_rows": [c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_transpose": [c_vp, c_vp, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_vp],
     "sfm_pool_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],

@@ -87,11 +87,26 @@ class ConformerBlock(HipModule):
 
     def forward(self, x):
         self._require_device(x)
-        self._require_inference()
+        if self.training:
+            return self._train_forward(x)
         pk = self._packed(lambda sd: Fn.pack_block(sd, self.num_heads))
         B, T, D = x.shape
         y = Fn.block_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T, self.num_heads)
         return y.reshape(B, T, D)
+
+
+    def _train_forward(self, x):
+        """Training mode (dropout active, BatchNorm batch statistics + running-stat update): one autograd node
+        whose forward and backward run on the HIP kernels (train.ConformerBlockFunction).  The dropout seed is
+        drawn from torch's default CPU generator, so torch.manual_seed() makes a step reproducible."""
+        from .. import train
+        named = dict(self.named_parameters())
+        params = [named[k] for k in train.PARAM_NAMES]
+        bn = self.conv.batch_norm
+        buffers = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        meta = (self.num_heads, float(self.ff1.dropout.p), seed, buffers, float(bn.momentum or 0.1), float(bn.eps))
+        return train.ConformerBlockFunction.apply(x, meta, *params)
 
 
 class ComplexConformer(HipModule):

@@ -321,13 +321,15 @@ def dwconv_bn_swish(x16, wdw, bdw, bnw, bnb, bnm, bnv, B, T, C, out=None, eps=1e
     return out
 
 
-def dwconv_folded(x16, wT, sc, sh, B, T, C, out=None):
-    """depthwise conv + folded BatchNorm(eval) + Swish with register-resident taps (KS 7 / 31)."""
+def dwconv_folded(x16, wT, sc, sh, B, T, C, out=None, act=1):
+    """depthwise conv + folded BatchNorm(eval) (+ Swish when act) with register-resident taps (KS 7 / 31);
+    `out` may be 16-bit (default) or fp32."""
     L = _lib.load()
     KS = wT.shape[0]
     if out is None:
         out = torch.empty_like(x16)
-    _call("dwconv_bn_swish", L.sfm_dwconv_folded, (_p(x16), _p(wT), _p(sc), _p(sh), _p(out), B, T, C, KS, _dt(), _stream()),
+    _call("dwconv_bn_swish", L.sfm_dwconv_folded, (_p(x16), _p(wT), _p(sc), _p(sh), _p(out), B, T, C, KS, int(act),
+                                                   1 if out.dtype == torch.float32 else 0, _dt(), _stream()),
           2.0 * B * T * C * KS, B * T * C * 4.0)
     return out
 

@@ -1,0 +1,158 @@
+"""Training-mode ConformerBlock on the HIP path (forward with batch statistics + backward) against torch
+autograd of the CPU oracle (dropout p = 0), plus statistical checks of the dropout path."""
+import math
+import numpy as np
+import pytest
+import torch
+
+from helpers import arr, maxerr, rmse, synth_sd
+from oracle import sfm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _block(dropout, seed=11):
+    from sincformer_metacog_speech_enhancement_amd.models.conformer import ConformerBlock
+    m = ConformerBlock(256, 4, 1024, 31, dropout)
+    sd = synth_sd("ConformerBlock", seed)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda(), sd
+
+
+def _rel(got, ref):
+    ref = torch.as_tensor(np.asarray(ref)).double()
+    return rmse(got, ref) / (float(ref.pow(2).mean().sqrt()) + 1e-12)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T", [(3, 200), (2, 77)])
+def test_block_train_forward_backward_matches_autograd(dt, B, T):
+    from sincformer_metacog_speech_enhancement_amd import ops, train
+    ops.set_compute_dtype(dt)
+    m, sd = _block(0.0)
+    m.train()
+    x = arr("bx", (B, T, 256), 5 + T, 1.0)
+    dy = arr("bdy", (B, T, 256), 6 + T, 1.0)
+    # oracle: same math in fp32 on CPU, BatchNorm batch statistics
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = orc.conformer_block(xr, ref_sd, 4, bn_train=True)
+    yr.backward(dy)
+    rm0 = m.conv.batch_norm.running_mean.clone()
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    assert y.shape == (B, T, 256) and y.requires_grad
+    y.backward(dy.cuda())
+    tol_y = 4e-3 if dt is torch.float16 else 2.5e-2
+    e = maxerr(y.detach().cpu(), yr.detach())
+    print("train fwd %s B%d T%d: max|err| %.3e rmse %.3e" % (dt, B, T, e, rmse(y.detach().cpu(), yr.detach())))
+    assert rmse(y.detach().cpu(), yr.detach()) < tol_y
+    tol_g = 0.01 if dt is torch.float16 else 0.05
+    r = _rel(xg.grad.cpu(), xr.grad)
+    print("  dx rel rmse %.3e" % r)
+    assert r < tol_g
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in train.PARAM_NAMES:
+        g = named[k].grad
+        assert g is not None, k
+        r = _rel(g.cpu(), ref_sd[k].grad)
+        worst = max(worst, r)
+        print("  d%-36s rel rmse %.3e  ref_rms %.3e" % (k, r, float(ref_sd[k].grad.pow(2).mean().sqrt())))
+        assert r < tol_g, k
+    # running statistics: momentum 0.1 update with the batch statistics of the depthwise output
+    assert int(m.conv.batch_norm.num_batches_tracked) == int(sd["conv.batch_norm.num_batches_tracked"]) + 1
+    assert not torch.equal(rm0, m.conv.batch_norm.running_mean)
+
+
+def test_block_running_stats_match_torch_batchnorm():
+    """running_mean/var after one training step equal nn.BatchNorm1d's update on the same pre-BN activations."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    ops.set_compute_dtype(torch.float16)
+    m, sd = _block(0.0, seed=13)
+    m.train()
+    B, T = 2, 160
+    x = arr("rx", (B, T, 256), 9, 1.0)
+    # pre-BN activations from the oracle
+    s = orc.sub(sd, "conv")
+    h = orc.mhsa(orc.ffn(x, orc.sub(sd, "ff1")), orc.sub(sd, "mhsa"), 4)
+    u = orc.layer_norm(h, s["layer_norm.weight"], s["layer_norm.bias"]).transpose(1, 2)
+    u = torch.nn.functional.conv1d(u, s["pointwise1.weight"], s["pointwise1.bias"])
+    a, g = u.split(256, dim=1)
+    u = torch.nn.functional.conv1d(a * torch.sigmoid(g), s["depthwise.weight"], s["depthwise.bias"], padding=15, groups=256)
+    bn = torch.nn.BatchNorm1d(256)
+    bn.load_state_dict({k[len("batch_norm."):]: v for k, v in s.items() if k.startswith("batch_norm.")})
+    bn.train()
+    bn(u)
+    with torch.no_grad():
+        m(x.cuda())
+    assert maxerr(m.conv.batch_norm.running_mean.cpu(), bn.running_mean) < 2e-3
+    assert maxerr(m.conv.batch_norm.running_var.cpu(), bn.running_var) < 2e-3 * float(bn.running_var.max())
+
+
+def test_block_dropout_statistics_and_determinism():
+    """p > 0: the same torch seed reproduces the step bit-for-bit, a different one does not; the expectation of the
+    output over masks approaches the p = 0 output (inverted dropout is unbiased on the residual branches)."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    ops.set_compute_dtype(torch.float16)
+    m, sd = _block(0.15, seed=17)
+    m.train()
+    B, T = 2, 96
+    x = arr("dx", (B, T, 256), 21, 1.0).cuda()
+    torch.manual_seed(5)
+    y1 = m(x).detach().clone()
+    torch.manual_seed(5)
+    y2 = m(x).detach().clone()
+    torch.manual_seed(6)
+    y3 = m(x).detach().clone()
+    assert torch.equal(y1, y2)
+    assert not torch.equal(y1, y3)
+    m0, _ = _block(0.0, seed=17)
+    m0.train()
+    y0 = m0(x).detach()
+    d1 = float((y1 - y0).pow(2).mean().sqrt())
+    acc = torch.zeros_like(y0)
+    n = 24
+    for i in range(n):
+        torch.manual_seed(100 + i)
+        acc += m(x).detach()
+    dm = float((acc / n - y0).pow(2).mean().sqrt())
+    print("dropout: single-draw rms dev %.3e, mean-of-%d rms dev %.3e" % (d1, n, dm))
+    assert d1 > 1e-2 and dm < 0.45 * d1
+    # backward under dropout runs and is reproducible
+    xg = x.clone().requires_grad_(True)
+    torch.manual_seed(5)
+    m(xg).sum().backward()
+    g1 = xg.grad.clone()
+    xg.grad = None
+    for p_ in m.parameters():
+        p_.grad = None
+    torch.manual_seed(5)
+    m(xg).sum().backward()
+    assert torch.isfinite(g1).all()
+    assert rmse(g1.cpu(), xg.grad.cpu()) < 1e-3 * float(g1.pow(2).mean().sqrt()) + 1e-7   # float atomics reorder only
+
+
+def test_block_trains_under_autocast_and_gradscaler():
+    """the reference's loop shape (training/conformer_pipeline.py:535-560): autocast + GradScaler + AdamW + clip."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    ops.set_compute_dtype(torch.bfloat16)
+    m, _ = _block(0.1, seed=19)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.01)
+    x = arr("tx", (4, 64, 256), 31, 1.0).cuda()
+    tgt = arr("tt", (4, 64, 256), 32, 1.0).cuda()
+    losses = []
+    for it in range(12):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+        loss = (y.float() - tgt).pow(2).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        opt.step()
+        losses.append(float(loss))
+    print("losses", ["%.4f" % l for l in losses])
+    assert all(math.isfinite(l) for l in losses) and losses[-1] < 0.9 * losses[0]
