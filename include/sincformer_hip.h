@@ -159,6 +159,22 @@ int sfm_spec_sums(const float* pr, const float* pi, const float* tr, const float
                   void* stream);
 int sfm_enhancer_loss_finalize(const double* Sw, const double* Sm, const double* Sr, const long long* nr, int B,
                                int L, long long n_mag, int R, float* out, void* stream);
+/* Backward of the objective and of the bounded polar mask (training/conformer_pipeline.py:52-108, 283-295, 539-572).
+ * sisnr_bwd: dwave = scale * d(neg SI-SNR)/d est from the moments Sw of sfm_wave_moments.
+ * spec_loss_bwd: mode 0 spectral-convergence + log-magnitude of one resolution (S = its sfm_spec_sums), mode 1 the
+ *   L1 magnitude term; writes/accumulates d/d(real, imag) at dr/di[m*ld + f].
+ * stft_adjoint_ola: adjoint of the reflect-padded framing of torch.stft: frames [B,T,win] -> dwave [B,L]
+ *   (optionally accumulated, optionally multiplied by post[L] afterwards).
+ * polar_mask_bwd: (d enh_real, d enh_imag) -> d logits [M, ld_dlog >= 2F] (magnitude | phase columns). */
+int sfm_sisnr_bwd(const float* est, const float* tgt, const double* Sw, float* dwave, int B, int L, float scale,
+                  void* stream);
+int sfm_spec_loss_bwd(const float* pr, const float* pi, const float* tr, const float* ti, const double* S, float* dr,
+                      float* di, long long n, int F, long long ld, int mode, int accumulate, float scale, void* stream);
+int sfm_stft_adjoint_ola(const float* frames, float* dwave, const float* post, int B, int T, int L, int n_fft, int hop,
+                         int win, int accumulate, void* stream);
+int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* nr, const float* ni, const float* der,
+                       const float* dei, float* dlog, long long M, int F, float phase_scale, long long ld_logits,
+                       long long ld_dlog, void* stream);
 /* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
 /* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); bias grad */
 int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,

@@ -39,6 +39,8 @@ N_FREQ = FFT_SIZE // 2 + 1
 
 def _t(x):
     if isinstance(x, torch.Tensor):
+        if x.requires_grad:                      # keep the autograd graph (gradient references in tests/)
+            return x
         return x.detach().to(torch.float32).cpu()
     return torch.from_numpy(np.ascontiguousarray(x)).to(torch.float32)
 
@@ -452,14 +454,14 @@ def memory_forward(sd, emb, temperature=1.0):
 # ----------------------------------------------------------------------------
 # SpeechEnhancer (training/conformer_pipeline.py:260-298)
 # ----------------------------------------------------------------------------
-def speech_enhancer_forward(sd, noisy_real, noisy_imag, num_heads=4):
+def speech_enhancer_forward(sd, noisy_real, noisy_imag, num_heads=4, bn_train=False):
     sd = {k: _t(v) for k, v in sd.items()}
     nr, ni = _t(noisy_real), _t(noisy_imag)
     x = torch.cat([nr, ni], dim=-1)
     x = layer_norm(x, sd["input_norm.weight"], sd["input_norm.bias"])
     x = linear(x, sd["input_proj.weight"], sd["input_proj.bias"])
     for i in range(_num_blocks(sd)):
-        x = conformer_block(x, sub(sd, "blocks.%d" % i), num_heads)
+        x = conformer_block(x, sub(sd, "blocks.%d" % i), num_heads, bn_train)
     x = layer_norm(x, sd["output_norm.weight"], sd["output_norm.bias"])
     mmag = torch.sigmoid(linear(x, sd["mag_head.weight"], sd["mag_head.bias"]))
     mph = torch.tanh(linear(x, sd["phase_head.weight"], sd["phase_head.bias"])) * (math.pi / 6)
@@ -495,12 +497,12 @@ def mr_stft_loss(pred, tgt, fft_sizes=(256, 512, 1024), hop_sizes=(64, 128, 256)
     return loss / len(fft_sizes)
 
 
-def enhancer_loss(sd, noisy_wav, clean_wav, num_heads=4):
+def enhancer_loss(sd, noisy_wav, clean_wav, num_heads=4, bn_train=False):
     """ConformerPipeline._compute_loss — training/conformer_pipeline.py:539-572.
     Returns total, neg_sisnr, enh_wav."""
     nr, ni = stft(noisy_wav)
     cr, ci = stft(clean_wav)
-    er, ei, _ = speech_enhancer_forward(sd, nr, ni, num_heads)
+    er, ei, _ = speech_enhancer_forward(sd, nr, ni, num_heads, bn_train)
     enh = istft(er, ei, _t(clean_wav).shape[-1])
     l_si = si_snr_loss(enh, clean_wav)
     l_mag = (torch.sqrt(er ** 2 + ei ** 2 + 1e-8) - torch.sqrt(cr ** 2 + ci ** 2 + 1e-8)).abs().mean()

@@ -53,6 +53,10 @@ SIGNATURES = {
     "sfm_wave_moments": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "sfm_spec_sums": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
     "sfm_enhancer_loss_finalize": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_ll, c_i, c_vp, c_vp],
+    "sfm_sisnr_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp],
+    "sfm_spec_loss_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_ll, c_i, c_i, c_f, c_vp],
+    "sfm_stft_adjoint_ola": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_polar_mask_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_f, c_ll, c_ll, c_vp],
     "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],

@@ -435,9 +435,9 @@ def wave_moments(est, tgt):
     return S
 
 
-def spec_sums(pr, pi, tr, ti):
+def spec_sums(pr, pi, tr, ti, out=None):
     L = _lib.load()
-    S = torch.zeros(4, device=pr.device, dtype=torch.float64)
+    S = torch.zeros(4, device=pr.device, dtype=torch.float64) if out is None else out
     _call("loss_reduce", L.sfm_spec_sums, (_p(pr), _p(pi), _p(tr), _p(ti), _p(S), pr.numel(), _stream()), 0.0,
           16.0 * pr.numel())
     return S
@@ -449,6 +449,30 @@ def enhancer_loss_finalize(Sw, Sm, Sr, nr, B, Ln, n_mag):
     _call("loss_reduce", L.sfm_enhancer_loss_finalize, (_p(Sw), _p(Sm), _p(Sr), _p(nr), B, Ln, n_mag, Sr.shape[0], _p(out),
                                                         _stream()))
     return out
+
+
+def sisnr_bwd(est, tgt, Sw, dwave, scale=1.0):
+    L = _lib.load()
+    B, Ln = est.shape
+    _call("loss_bwd", L.sfm_sisnr_bwd, (_p(est), _p(tgt), _p(Sw), _p(dwave), B, Ln, float(scale), _stream()), 0.0, 12.0 * B * Ln)
+
+
+def spec_loss_bwd(pr, pi, tr, ti, S, dr, di, F, ld, mode, accumulate=False, scale=1.0):
+    L = _lib.load()
+    _call("loss_bwd", L.sfm_spec_loss_bwd, (_p(pr), _p(pi), _p(tr), _p(ti), _p(S), _p(dr), _p(di), pr.numel(), F, ld, mode,
+                                            1 if accumulate else 0, float(scale), _stream()), 0.0, 24.0 * pr.numel())
+
+
+def stft_adjoint_ola(frames, dwave, B, T, Ln, n_fft, hop, win, accumulate=True, post=None):
+    L = _lib.load()
+    _call("loss_bwd", L.sfm_stft_adjoint_ola, (_p(frames), _p(dwave), _p(post), B, T, Ln, n_fft, hop, win,
+                                               1 if accumulate else 0, _stream()), 0.0, 4.0 * (B * T * win + 2 * B * Ln))
+
+
+def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits):
+    L = _lib.load()
+    _call("loss_bwd", L.sfm_polar_mask_bwd, (_p(lm), _p(lp), _p(nr), _p(ni), _p(der), _p(dei), _p(dlog), M, F, float(phase_scale),
+                                             ld_logits, dlog.stride(0), _stream()), 0.0, 32.0 * M * F)
 
 
 # ---------------------------------------------------------------------------

@@ -252,3 +252,196 @@ class ConformerBlockFunction(torch.autograd.Function):
         grads = [G[k].to(dt_) for k, dt_ in zip(PARAM_NAMES, ctx.param_dtypes)]
         ctx.saved = None
         return (dx.reshape(B, T, D).to(ctx.in_dtype), None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------
+# LayerNorm -> Linear (input_norm + input_proj, output_norm + heads of SpeechEnhancer,
+# training/conformer_pipeline.py:273-284)
+# ---------------------------------------------------------------------------
+class LNLinearFunction(torch.autograd.Function):
+    """y[M, N] = LayerNorm(x[:, :K]) @ W^T + b, fp32 in / fp32 out, GEMMs on 16-bit operands."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, W, b):
+        M = x.shape[0]
+        N, K = W.shape
+        x32 = x.detach().float()
+        if x32.stride(1) != 1:
+            x32 = x32.contiguous()
+        lw, lb, w32 = _f32(ln_w), _f32(ln_b), _f32(W)
+        Kp = ops.round_up(K, 64)
+        fwd = ops.pack_linear(w32, _f32(b), k_pad_to=Kp)
+        h16 = torch.zeros(M, Kp, device=x.device, dtype=ops.compute_dtype()) if Kp != K else \
+            torch.empty(M, K, device=x.device, dtype=ops.compute_dtype())
+        ops.layernorm(x32, lw, lb, out16=h16)
+        Np = ops.round_up(N, 8)
+        ybuf = torch.empty(M, Np, device=x.device, dtype=torch.float32)
+        y = ybuf[:, :N]
+        ops.linear16(h16, fwd, out=y)
+        ctx.saved = (x32, lw, w32, h16)
+        ctx.dims = (M, N, K)
+        ctx.dtypes = (x.dtype, ln_w.dtype, ln_b.dtype, W.dtype, b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, lw, w32, h16 = ctx.saved
+        M, N, K = ctx.dims
+        dev = dy.device
+        dy = dy.float()
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        Np = ops.round_up(N, 64)
+        dy16 = torch.empty(M, Np, device=dev, dtype=ops.compute_dtype())
+        ops.convert_rows(dy, dy16, M, N, Np, dy.stride(0), Np)
+        dW = torch.zeros(N, K, device=dev, dtype=torch.float32)
+        db = torch.zeros(N, device=dev, dtype=torch.float32)
+        ops.gemm16_tn(dy16[:, :N], h16[:, :K], dW)
+        ops.colsum(dy16[:, :N], db)
+        bwd = ops.pack_linear(w32.t().contiguous(), k_pad_to=Np)
+        dh = ops.linear16(dy16, bwd, out_dtype=torch.float32)                  # [M, K]
+        dg = torch.zeros(K, device=dev, dtype=torch.float32)
+        dbt = torch.zeros(K, device=dev, dtype=torch.float32)
+        dx = ops.layernorm_bwd(x32, lw, dh, None, dg, dbt)
+        t = ctx.dtypes
+        ctx.saved = None
+        return dx.to(t[0]), dg.to(t[1]), dbt.to(t[2]), dW.to(t[3]), db.to(t[4])
+
+
+class PolarMaskFunction(torch.autograd.Function):
+    """bounded polar mask applied to the noisy STFT (training/conformer_pipeline.py:283-295):
+    logits [M, 2F] (magnitude | phase) -> enh_real, enh_imag, mask_mag (monitoring only, not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, logits, noisy_real, noisy_imag, phase_scale):
+        B, T, F = noisy_real.shape
+        lg = logits.detach()
+        nr, ni = noisy_real.detach().float().contiguous(), noisy_imag.detach().float().contiguous()
+        dev = lg.device
+        er = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+        ei = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+        mm = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+        ops.polar_mask(lg, lg[:, F:], B, T, F, phase_scale, lg.stride(0), nr=nr, ni=ni, er=er, ei=ei, mmag=mm, ld_enh=F)
+        ctx.saved = (lg, nr, ni)
+        ctx.ps = phase_scale
+        ctx.mark_non_differentiable(mm)
+        return er, ei, mm
+
+    @staticmethod
+    def backward(ctx, der, dei, _dmm):
+        lg, nr, ni = ctx.saved
+        B, T, F = nr.shape
+        M = B * T
+        dl = torch.zeros(M, ops.round_up(2 * F, 8), device=lg.device, dtype=torch.float32)
+        ops.polar_mask_bwd(lg, lg[:, F:], nr, ni, der.float().contiguous(), dei.float().contiguous(), dl, M, F, ctx.ps,
+                           lg.stride(0))
+        ctx.saved = None
+        return dl[:, :2 * F], None, None, None
+
+
+# ---------------------------------------------------------------------------
+# objective: SI-SNR + 0.5 L1 magnitude + multi-resolution STFT (training/conformer_pipeline.py:52-108, 539-572)
+# ---------------------------------------------------------------------------
+_adj_cache = {}
+
+
+def _adjoint_consts(n_fft, win, dev):
+    """transposed DFT operands of functional._stft_consts (adjoint GEMMs of stft / istft)."""
+    from . import functional as Fn
+    key = (n_fft, win, str(dev))
+    c = _adj_cache.get(key)
+    if c is None:
+        base = Fn._stft_consts(n_fft, win, dev)
+        F2 = n_fft + 2
+        c = {"fwdT": ops.pack_f32_matrix(base["fwd"][:win, :F2].t().contiguous()),      # [2F, win]
+             "invT": ops.pack_f32_matrix(base["inv"][:F2, :win].t().contiguous())}      # [win, 2F]
+        _adj_cache[key] = c
+    return c
+
+
+_env_cache = {}
+
+
+def _inv_envelope(L, T, n_fft, hop, win, dev):
+    """1 / (sum of squared windows) per output sample of torch.istft (0 where the envelope vanishes)."""
+    import numpy as np
+    key = (L, T, n_fft, hop, win, str(dev))
+    v = _env_cache.get(key)
+    if v is None:
+        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win, dtype=np.float64) / win)
+        woff = (n_fft - win) // 2
+        env = np.zeros(max(L + n_fft, (T - 1) * hop + n_fft) + n_fft, dtype=np.float64)
+        for t in range(T):
+            env[t * hop + woff: t * hop + woff + win] += w * w
+        env = env[n_fft // 2: n_fft // 2 + L]
+        inv = np.where(env > 1e-11, 1.0 / np.maximum(env, 1e-30), 0.0)
+        v = torch.from_numpy(inv.astype(np.float32)).to(dev)
+        _env_cache[key] = v
+    return v
+
+
+class EnhancerLossFunction(torch.autograd.Function):
+    """(enh_real, enh_imag, clean_wave, clean_real, clean_imag) -> total loss (0-dim, differentiable w.r.t. the enhanced
+    spectrum) and aux = [neg_sisnr, l1_mag, mr_stft] (monitoring).  The gradient is produced during the forward pass
+    (every reduction it needs is already on the device) and only scaled by the incoming grad in backward."""
+
+    @staticmethod
+    def forward(ctx, enh_real, enh_imag, clean_wave, clean_real, clean_imag, n_fft, hop, win):
+        from . import functional as Fn
+        er, ei = enh_real.detach().float().contiguous(), enh_imag.detach().float().contiguous()
+        cw = clean_wave.detach().float().contiguous()
+        cr, ci = clean_real.detach().float().contiguous(), clean_imag.detach().float().contiguous()
+        B, L = cw.shape
+        _, T, F = er.shape
+        dev = er.device
+        need_grad = enh_real.requires_grad or enh_imag.requires_grad
+        enh_wav = Fn.istft(er, ei, L, n_fft, hop, win)
+        Sw = ops.wave_moments(enh_wav, cw)
+        Sm = ops.spec_sums(er, ei, cr, ci)
+        R = len(Fn.MR_STFT)
+        Sr = torch.zeros(R, 4, device=dev, dtype=torch.float64)
+        counts = []
+        dwave = None
+        if need_grad:
+            dwave = torch.empty(B, L, device=dev, dtype=torch.float32)
+            ops.sisnr_bwd(enh_wav, cw, Sw, dwave)
+        inv_env = _inv_envelope(L, T, n_fft, hop, win, dev) if need_grad else None
+        for i, (nf, hp, wn) in enumerate(Fn.MR_STFT):
+            pr, pi = Fn.stft(enh_wav, nf, hp, wn)
+            tr, ti = Fn.stft(cw, nf, hp, wn)
+            ops.spec_sums(pr, pi, tr, ti, out=Sr[i])
+            counts.append(pr.numel())
+            if need_grad:
+                Tr, Fr = pr.shape[1], pr.shape[2]
+                Mr = B * Tr
+                ld = ops.round_up(2 * Fr, 8)
+                g = torch.zeros(Mr, ld, device=dev, dtype=torch.float32)
+                ops.spec_loss_bwd(pr, pi, tr, ti, Sr[i], g, g[:, Fr:], Fr, ld, 0, scale=1.0 / R)
+                del pr, pi, tr, ti
+                frames = torch.empty(Mr, wn, device=dev, dtype=torch.float32)
+                ops.framed_gemm(g, _adjoint_consts(nf, wn, dev)["fwdT"], frames, B=1, M=Mr, Ls=Mr * ld, sig_batch_stride=0,
+                                hop=ld, padl=0, K=2 * Fr, N=wn, o_batch_stride=0, ldm=wn, ldn=1, mode=0)
+                ops.stft_adjoint_ola(frames, dwave, B, Tr, L, nf, hp, wn, accumulate=True,
+                                     post=inv_env if i == R - 1 else None)
+                del g, frames
+        nr = torch.tensor(counts, device=dev, dtype=torch.int64)
+        losses = ops.enhancer_loss_finalize(Sw, Sm, Sr, nr, B, L, er.numel())
+        if need_grad:
+            d_er = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+            d_ei = torch.empty(B, T, F, device=dev, dtype=torch.float32)
+            ops.framed_gemm(dwave, _adjoint_consts(n_fft, win, dev)["invT"], d_er, B=B, M=T, Ls=L, sig_batch_stride=L, hop=hop,
+                            padl=n_fft // 2 - (n_fft - win) // 2, K=win, N=2 * F, o_batch_stride=T * F, ldm=F, ldn=1, mode=0,
+                            out2=d_ei, nsplit=F)
+            ops.spec_loss_bwd(er, ei, cr, ci, Sm, d_er, d_ei, F, F, 1, accumulate=True, scale=0.5)
+            ctx.grads = (d_er, d_ei)
+        aux = losses[1:].clone()
+        ctx.mark_non_differentiable(aux, enh_wav)
+        ctx.dtypes = (enh_real.dtype, enh_imag.dtype)
+        return losses[0].clone(), aux, enh_wav
+
+    @staticmethod
+    def backward(ctx, g_total, _g_aux, _g_wav):
+        d_er, d_ei = ctx.grads
+        ctx.grads = None
+        s = g_total.float()
+        return (d_er * s).to(ctx.dtypes[0]), (d_ei * s).to(ctx.dtypes[1]), None, None, None, None, None, None

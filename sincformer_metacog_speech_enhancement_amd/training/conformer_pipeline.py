@@ -60,9 +60,31 @@ class SpeechEnhancer(HipModule):
                 "on_w": sd["output_norm.weight"].float().contiguous(), "on_b": sd["output_norm.bias"].float().contiguous(),
                 "heads": ops.pack_linear(heads_w, heads_b)}
 
+    def _train_forward(self, noisy_real, noisy_imag):
+        """train() mode: same graph built from autograd nodes whose forward AND backward are HIP kernels
+        (train.LNLinearFunction, ConformerBlockFunction via ConformerBlock, PolarMaskFunction)."""
+        from .. import train
+        nr, ni = noisy_real.float().contiguous(), noisy_imag.float().contiguous()
+        B, T, F = nr.shape
+        M = B * T
+        ldc = ops.round_up(2 * F, 8)
+        cat = torch.empty(M, ldc, device=nr.device, dtype=torch.float32)
+        ops.pack_spec(nr, ni, cat, M, F, ldc, F)
+        x = train.LNLinearFunction.apply(cat, self.input_norm.weight, self.input_norm.bias, self.input_proj.weight,
+                                         self.input_proj.bias)
+        x = x.reshape(B, T, -1)
+        for block in self.blocks:
+            x = block(x)
+        heads_w = torch.cat([self.mag_head.weight, self.phase_head.weight], dim=0)
+        heads_b = torch.cat([self.mag_head.bias, self.phase_head.bias], dim=0)
+        logits = train.LNLinearFunction.apply(x.reshape(M, -1), self.output_norm.weight, self.output_norm.bias, heads_w,
+                                              heads_b)
+        return train.PolarMaskFunction.apply(logits, nr, ni, math.pi / 6)
+
     def forward(self, noisy_real, noisy_imag):
         self._require_device(noisy_real, noisy_imag)
-        self._require_inference()
+        if self.training:
+            return self._train_forward(noisy_real, noisy_imag)
         pk = self._packed(self._pack)
         nr, ni = noisy_real.float().contiguous(), noisy_imag.float().contiguous()
         B, T, F = nr.shape
@@ -88,6 +110,21 @@ class SpeechEnhancer(HipModule):
 
     # LayerNorm over 2F needs D passed explicitly: ops.layernorm infers D from x32.shape[1]
     # (cat has ldc >= 2F columns), so view the valid columns.
+
+
+def compute_loss(model, noisy_real, noisy_imag, clean_wav, clean_real, clean_imag, fft_size=None, hop_size=None,
+                 frame_size=None):
+    """ConformerPipeline._compute_loss (training/conformer_pipeline.py:539-572): model forward -> iSTFT ->
+    SI-SNR + 0.5 * L1 magnitude + multi-resolution STFT.  Returns (total, neg_sisnr) like the reference; `total` carries
+    the autograd graph (HIP backward kernels) when the model is in train() mode."""
+    from .. import train
+    fft_size, hop_size = fft_size or config.FFT_SIZE, hop_size or config.HOP_SIZE
+    frame_size = frame_size or config.FRAME_SIZE
+    enh_real, enh_imag, _ = model(noisy_real, noisy_imag)
+    T = min(enh_real.shape[1], clean_real.shape[1])
+    total, aux, _ = train.EnhancerLossFunction.apply(enh_real[:, :T], enh_imag[:, :T], clean_wav, clean_real[:, :T],
+                                                     clean_imag[:, :T], fft_size, hop_size, frame_size)
+    return total, aux[0]
 
 
 class EnhancementPath(HipModule):

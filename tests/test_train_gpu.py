@@ -159,3 +159,79 @@ def test_block_trains_under_autocast_and_gradscaler():
         losses.append(float(loss))
     print("losses", ["%.4f" % l for l in losses])
     assert all(math.isfinite(l) for l in losses) and losses[-1] < 0.9 * losses[0]
+
+
+# ---------------------------------------------------------------------------
+# SpeechEnhancer training step: model + objective (training/conformer_pipeline.py:260-298, 539-572)
+# ---------------------------------------------------------------------------
+def _waves(B, L, seed):
+    clean = arr("cw", (B, L), seed, 0.1)
+    noisy = clean + arr("nw", (B, L), seed + 1, 0.05)
+    return noisy, clean
+
+
+@pytest.mark.parametrize("L", [4000, 4321])
+def test_loss_backward_matches_autograd(L):
+    """objective alone: gradient w.r.t. the enhanced spectrum (iSTFT + SI-SNR + L1 magnitude + MR-STFT adjoints)."""
+    from sincformer_metacog_speech_enhancement_amd import train, functional as Fn
+    B = 3
+    noisy, clean = _waves(B, L, 70)
+    nr, ni = orc.stft(noisy)
+    cr, ci = orc.stft(clean)
+    er = (nr * 0.8 + 0.05 * arr("pe", tuple(nr.shape), 72)).requires_grad_(True)
+    ei = (ni * 0.8 + 0.05 * arr("pf", tuple(nr.shape), 73)).requires_grad_(True)
+    enh = orc.istft(er, ei, L)
+    l_si = orc.si_snr_loss(enh, clean)
+    l_mag = (torch.sqrt(er ** 2 + ei ** 2 + 1e-8) - torch.sqrt(cr ** 2 + ci ** 2 + 1e-8)).abs().mean()
+    l_st = orc.mr_stft_loss(enh, clean)
+    ref_total = l_si + 0.5 * l_mag + l_st
+    ref_total.backward()
+    ger, gei = er.detach().cuda().requires_grad_(True), ei.detach().cuda().requires_grad_(True)
+    total, aux, wav = train.EnhancerLossFunction.apply(ger, gei, clean.cuda(), cr.cuda(), ci.cuda(), 256, 80, 160)
+    (total * 3.0).backward()
+    print("loss %.6f ref %.6f  aux %s ref (%.5f %.5f %.5f)" % (float(total), float(ref_total), aux.tolist(), float(l_si),
+                                                              float(l_mag), float(l_st)))
+    assert abs(float(total) - float(ref_total)) < 2e-4 * max(1.0, abs(float(ref_total)))
+    assert maxerr(wav.cpu(), enh.detach()) < 1e-4
+    for name, g, r in (("d enh_real", ger.grad, er.grad), ("d enh_imag", gei.grad, ei.grad)):
+        rel = _rel(g.cpu() / 3.0, r)
+        print("  %s rel rmse %.3e (ref rms %.3e)" % (name, rel, float(r.pow(2).mean().sqrt())))
+        assert rel < 2e-3, name
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_speech_enhancer_train_step_matches_autograd(dt):
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
+    ops.set_compute_dtype(dt)
+    B, L = 2, 4000
+    sd = synth_sd("SpeechEnhancer", 23)
+    m = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    noisy, clean = _waves(B, L, 80)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    ref_total, ref_si, _ = orc.enhancer_loss(ref_sd, noisy, clean, 4, bn_train=True)
+    ref_total.backward()
+    nr, ni = batch_stft(noisy.cuda(), 256, 80, 160)
+    cr, ci = batch_stft(clean.cuda(), 256, 80, 160)
+    total, neg_sisnr = compute_loss(m, nr, ni, clean.cuda(), cr, ci)
+    total.backward()
+    print("SpeechEnhancer %s: loss %.5f ref %.5f; neg_sisnr %.5f ref %.5f" % (dt, float(total), float(ref_total),
+                                                                           float(neg_sisnr), float(ref_si)))
+    tol_l = 2e-3 if dt is torch.float16 else 2e-2
+    assert abs(float(total) - float(ref_total)) < tol_l * max(1.0, abs(float(ref_total)))
+    tol_g = 0.02 if dt is torch.float16 else 0.12
+    worst = ("", 0.0)
+    for k, p_ in m.named_parameters():
+        assert p_.grad is not None, k
+        rg = ref_sd[k].grad
+        rms = float(rg.pow(2).mean().sqrt())
+        if k.endswith("depthwise.bias"):
+            continue
+        rel = _rel(p_.grad.cpu(), rg)
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert rel < tol_g, "%s rel %.3e (ref rms %.3e)" % (k, rel, rms)
+    print("  worst parameter-gradient rel rmse: %s %.3e" % worst)
