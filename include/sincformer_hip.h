@@ -175,6 +175,12 @@ int sfm_stft_adjoint_ola(const float* frames, float* dwave, const float* post, i
 int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* nr, const float* ni, const float* der,
                        const float* dei, float* dlog, long long M, int F, float phase_scale, long long ld_logits,
                        long long ld_dlog, void* stream);
+/* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
+ * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
+ * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */
+int sfm_sumsq(const float* g, long long n, double* out, void* stream);
+int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
+                   float eps, float wd, float inv_scale, float max_norm, int write_back_grad, void* stream);
 /* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
 /* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); bias grad */
 int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,

@@ -20,37 +20,89 @@ def shard_range(n_items, rank, world):
 
 
 class FlatGradSynchronizer:
-    def __init__(self, params, bucket_bytes=16 << 20, group=None):
+    """Flat fp32 gradient buffer, preceded by a 64-float header whose first slot is the NaN/Inf flag: the flag rides
+    in bucket 0 (the first parameters, whose gradients are the LAST that backward produces) and costs no collective
+    of its own.  Gradients of the parameters are views of the buffer; buckets are runs of whole
+    parameters of about `bucket_bytes`.  With overlap=True every bucket is all-reduced (async, RCCL's own stream) as
+    soon as autograd has accumulated the gradient of its last parameter, so the exchange overlaps the rest of the
+    backward pass; finish() launches what is left and waits."""
+
+    HEADER = 64
+
+    def __init__(self, params, bucket_bytes=16 << 20, group=None, overlap=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = sum(p.numel() for p in self.params)
+        self.n = n
         dev = self.params[0].device
-        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        H = self.HEADER
+        self.buf = torch.zeros(H + n, device=dev, dtype=torch.float32)
+        self.flat = self.buf[H:]
+        self.flag = self.buf[:1]
         off = 0
-        for p in self.params:                      # gradients become views of the flat buffer
+        per = max(1, bucket_bytes // 4)
+        self.buckets, self._bucket_of, start = [], {}, 0
+        for i, p in enumerate(self.params):        # gradients become views of the flat buffer
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        per = max(1, bucket_bytes // 4)
-        self.buckets = [(s, min(s + per, n)) for s in range(0, n, per)]
-        self.flag = torch.zeros(1, device=dev, dtype=torch.float32)
+            self._bucket_of[id(p)] = len(self.buckets)
+            if off - start >= per or i == len(self.params) - 1:
+                self.buckets.append((start, off))
+                start = off
+        self.buckets = [(s + H, e + H) for s, e in self.buckets]
+        self.buckets[0] = (0, self.buckets[0][1])  # the header (flag) travels with bucket 0
+        self._members = [0] * len(self.buckets)
+        for p in self.params:
+            self._members[self._bucket_of[id(p)]] += 1
+        self._pending = list(self._members)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self.overlap = overlap and self.world > 1
+        if self.overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # -- overlap machinery ---------------------------------------------------------------------------------------
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        self._launched[b] = True
+        self._works.append(dist.all_reduce(self.buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and b != 0:       # bucket 0 carries the flag: launched by finish()
+            self._launch(b)
 
     def zero(self):
-        self.flat.zero_()
+        self.buf.zero_()
+        self._pending = list(self._members)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
 
+    def set_flag(self, loss):
+        """device-side: flag = 1 when the loss is NaN/Inf (no host sync)."""
+        if loss is not None:
+            self.flag.copy_((~torch.isfinite(loss.detach().float())).float().reshape(1))
+
+    def finish(self, loss=None):
+        """launch the remaining buckets and wait; the buffer then holds the SUM over ranks (callers fold 1/world into
+        their unscale factor, see optim.FlatAdamW)."""
+        self.set_flag(loss)
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
+            for w in self._works:
+                w.wait()
+        self._works = []
+
+    # -- host-synchronising convenience (tests, simple loops) --------------------------------------------------------
     def sync(self, loss=None, max_norm=None):
         """all-reduce the gradients (mean over ranks).  Returns dict(skip, grad_norm, clip_coef)."""
-        bad = 0.0
-        if loss is not None and not bool(torch.isfinite(loss.detach()).all()):
-            bad = 1.0
-        self.flag.fill_(bad)
-        works = []
+        self.finish(loss)
         if self.world > 1:
-            for s, e in self.buckets:
-                works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            works.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
-            for w in works:
-                w.wait()
             self.flat.div_(self.world)
         skip = bool(self.flag.item() > 0)
         norm = float(torch.linalg.vector_norm(self.flat))

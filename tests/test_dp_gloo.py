@@ -72,3 +72,56 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sincformer_metacog_speech_enhancement_amd import dp
+    torch.manual_seed(0)                                     # same weights on both ranks
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                torch.nn.Linear(16, 4))
+    sync = dp.FlatGradSynchronizer(model.parameters(), bucket_bytes=400, overlap=True)
+    nb = len(sync.buckets)
+    torch.manual_seed(100 + rank)                            # different data per rank (the utterance shard)
+    x, y = torch.randn(5, 8), torch.randn(5, 4)
+    ok = nb >= 3
+    for it in range(2):                                      # twice: zero() must re-arm the hooks' counters
+        sync.zero()
+        loss = (model(x) - y).pow(2).mean()
+        loss.backward()
+        launched_in_backward = sum(sync._launched)
+        ok = ok and launched_in_backward == nb - 1           # every bucket but the flag-carrying one went out from a hook
+        sync.finish(loss)
+        got = sync.flat.clone() / world
+        # reference: gather both ranks' local gradients computed without the synchronizer
+        ref_model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                        torch.nn.Linear(16, 4))
+        ref_model.load_state_dict(model.state_dict())
+        (ref_model(x) - y).pow(2).mean().backward()
+        local = torch.cat([p.grad.reshape(-1) for p in ref_model.parameters()])
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        ok = ok and torch.allclose(got, sum(gathered) / world, atol=1e-6)
+        ok = ok and float(sync.flag) == 0.0
+    # flag: NaN loss on one rank -> flag > 0 everywhere after finish()
+    sync.zero()
+    sync.finish(torch.tensor(float("inf")) if rank == 0 else torch.tensor(1.0))
+    ok = ok and float(sync.flag) > 0
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bucket_overlap_hooks_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
