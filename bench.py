@@ -25,10 +25,13 @@ WORKLOADS = {
     "c1": (1, 16000, "B1 x 1 s (L16000, T201) forward"),
     "c2": (64, 64000, "B64 x 4 s (L64000, T801) SincNet+Conformer forward (BASELINE configs[1])"),
     "c3p": (256, 40880, "B256 x 512-frame utterances (L40880, T512) forward"),
+    "c3se": (256, 64000, "B256 x 4 s (L64000, T801) SpeechEnhancer training step: STFT, forward, SI-SNR + L1 + multi-res "
+                         "STFT objective, backward, gradient all-reduce, clip, AdamW (BASELINE configs[2]/[3])"),
     "c5": (32, 480000, "B32 x 30 s (L480000, T6001) forward with episodic memory (BASELINE configs[4], fwd)"),
 }
 PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "hbm": 8000.0}      # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
-FAMILY_BOUND = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32"}
+FAMILY_BOUND = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32", "gemm16_tn": "mfma16",
+                "attention_bwd": "mfma16"}
 
 
 def build_path(dtype, seed=1234, use_memory=False):
@@ -86,6 +89,132 @@ def cpu_baseline(weights, L, batch=2, iters=3):
                       % (batch, L, iters, cores)}
 
 
+def cpu_baseline_train(sd, L, iters=3, batch=8):
+    """oracle forward + backward (torch autograd on the host cores) of the same training step, small batch."""
+    import torch
+    from oracle import sfm_oracle as orc
+    from sincformer_metacog_speech_enhancement_amd import synthetic as syn
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    noisy, clean = syn.synth_wave(batch, L, 77)
+    noisy, clean = torch.from_numpy(noisy), torch.from_numpy(clean)
+    ref = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    t0 = time.perf_counter()
+    for i in range(iters):
+        print("[bench] cpu baseline (training) iter %d/%d" % (i + 1, iters), file=sys.stderr, flush=True)
+        total, _, _ = orc.enhancer_loss(ref, noisy, clean, 4, bn_train=True)
+        total.backward()
+    dt = (time.perf_counter() - t0) / iters
+    T = 1 + L // 80
+    return {"value": batch * T / dt, "unit": "STFT frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (torch fp32 autograd restatement) forward+backward of the same step, batch %d x %d samples, %d "
+                      "iterations, %.1f s each; no optimiser step" % (batch, L, iters, dt)}
+
+
+def main_train(args):
+    """--workload c3se: one training step of training/conformer_pipeline.py (SpeechEnhancer) per bench step."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
+    ops.set_compute_dtype(args.dtype)
+    B, L, desc = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    T = 1 + L // 80
+    model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, 4321).items()}
+    model.load_state_dict(sd)                                       # same weights on every rank
+    model.cuda().train()
+    opt = FlatAdamW(model.parameters(), lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0)
+    noisy, clean = syn.synth_wave(B, L, 1234 + rank)                # each rank trains on its own utterance shard
+    noisy, clean = torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda()
+    torch.manual_seed(1000 + rank)                                  # dropout seeds
+
+    def step():
+        opt.zero_grad()
+        nr, ni = batch_stft(noisy, 256, 80, 160)
+        cr, ci = batch_stft(clean, 256, 80, 160)
+        total, _ = compute_loss(model, nr, ni, clean, cr, ci)
+        total.backward()
+        opt.step(loss=total)
+        return total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        print("[bench] %s, dtype %s, world %d, batch/GPU %d" % (desc, args.dtype, world, B), file=sys.stderr, flush=True)
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            ops.profiler.enable(None)
+        loss = step()
+    breakdown = ops.profiler.summary()
+    ops.profiler.disable()
+    dominant = max(breakdown, key=lambda k: breakdown[k]["ms_total"])
+    ops.profiler.enable({dominant})
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom = ops.profiler.summary()[dominant]
+    ops.profiler.disable()
+    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    frames = world * B * T * args.steps
+    if rank == 0:
+        kind = FAMILY_BOUND.get(dominant, "hbm")
+        secs = dom["ms_avg"] * 1e-3
+        if kind == "hbm":
+            ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
+        else:
+            ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
+        st = opt.stats()
+        line = {
+            "metric": "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref",
+            "value": frames / elapsed, "unit": "STFT frames/s trained (whole job)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
+                       "sharding": "utterances over ranks; one bucketed all-reduce (RCCL) of the flat fp32 gradient per step, "
+                                   "overlapped with backward", "optimizer": "AdamW lr 5e-4 betas (0.9, 0.98) wd 0.01, clip 5.0",
+                       "dropout": 0.15},
+            "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
+                         "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]},
+            "frames_per_s_per_gpu": frames / elapsed / world,
+            "final_loss": float(loss), "optimizer_state": st,
+            "breakdown_ms_per_step": {k: round(v["ms_total"], 4) for k, v in
+                                      sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
+        }
+        print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
+              (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_train(sd, L)
+        if args.breakdown:
+            with open(args.breakdown, "w") as fh:
+                json.dump(breakdown, fh, indent=1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +224,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel-family breakdown JSON here")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload")
     args = ap.parse_args()
+    if args.workload == "c3se":
+        return main_train(args)
 
     import torch
     import torch.distributed as dist

@@ -32,7 +32,7 @@ __device__ __forceinline__ float attn_keep_fwd(uint32_t seed, unsigned long long
   return ((x >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
 }
 
-template <class T>
+template <class T, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
                                                             int Tlen, int ldqkv, int ldo, int koff, int voff,
                                                             long long qkv_batch_stride, long long o_batch_stride,
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
         pf[2] = pack2<T>(s[kj][8 * s2 + 4], s[kj][8 * s2 + 5]);
         pf[3] = pack2<T>(s[kj][8 * s2 + 6], s[kj][8 * s2 + 7]);
         lacc = T::mfma(vones, pf, lacc);                  // row sums of the (rounded) P, all 32 rows equal
-        if (p_drop > 0.f) {                               // attention dropout (training): O uses keep/(1-p) * P, l does not
+        if (DROP) {                                       // attention dropout (training): O uses keep/(1-p) * P, l does not
           const float ik = 1.0f / (1.0f - p_drop);
           const unsigned long long rowbase = (((unsigned long long)b * nheads + h) * Tlen + (q0 + l31 < Tlen ? q0 + l31 : 0)) * Tlen;
           float pd[8];
@@ -273,6 +273,300 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
 }
 
 // ---------------------------------------------------------------------------
+// attn_fwd_hd64x2: the inference / no-dropout kernel.  Same math and operand layouts as attn_fwd_hd64 above, but a
+// wave owns 64 query rows = two independent 32-row sub-blocks that share every K fragment (ds_read_b128) and every
+// V^T fragment (ds_read_b64_tr_b16): LDS and L2 traffic per FLOP halve, there is one barrier per 2x the work, and
+// the two sub-blocks give the in-order wave independent MFMA / VALU streams to interleave (the softmax of one
+// sub-block issues in the gaps of the other's MFMAs).  Block = 4 waves = 256 query rows; the online softmax runs
+// per 32-key step (two steps per staged 64-key tile).  Row maxima cross the lane halves with v_permlane32_swap.
+// ---------------------------------------------------------------------------
+// v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of the second: fed two copies of x it
+// leaves [x.lo, x.lo] and [x.hi, x.hi].  The s_nop covers the 2 wait states a VALU write of an operand needs before
+// the swap reads it.  (Scalars in and out: this compiler reads element 0 for __builtin_bit_cast(float, vec[i]).)
+__device__ __forceinline__ void xhalf_swap(float v, float& lo, float& hi) {
+  uint32_t a = __builtin_bit_cast(uint32_t, v), c = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, c);
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+  float lo, hi;
+  xhalf_swap(v, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  float lo, hi;
+  xhalf_swap(v, lo, hi);
+  return lo + hi;
+}
+
+template <class T>
+__global__ __launch_bounds__(256, 1) void attn_fwd_hd64x2_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
+                                                                 int Tlen, int ldqkv, int ldo, int koff, int voff,
+                                                                 long long qkv_batch_stride, long long o_batch_stride,
+                                                                 float scale_log2e, int nqt, int nheads,
+                                                                 float* __restrict__ lse_out) {
+  constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int id = blockIdx.x;
+  {
+    const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int qt = id % nqt;
+  const int h = (id / nqt) % nheads, b = id / (nqt * nheads);
+  const int q0 = qt * 256 + wave * 64;
+  const int hl = lane >> 5, l31 = lane & 31;
+  const u16* base = qkv + (long long)b * qkv_batch_stride + h * 64;
+
+  u32x4 qf[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = q0 + 32 * u + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < Tlen) v = *reinterpret_cast<const u32x4*>(base + (long long)q * ldqkv + ks * 16 + hl * 8);
+      if (scale_log2e != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2<T>(T::to_f32((u16)(v[e] & 0xffffu)) * scale_log2e, T::to_f32((u16)(v[e] >> 16)) * scale_log2e);
+      }
+      qf[u][ks] = v;
+    }
+  }
+  // augmented k-step: K side (1, 1, pad, 0...) x Q side (-m_hi, -m_lo, -BIG, 0...) -> the matrix core subtracts the
+  // running max AND pushes the scores of padding keys (>= Tlen, only in the last tile) to -BIG: no masking on the VALU
+  const uint32_t one16 = T::from_f32(1.0f);
+  const uint32_t ones2 = one16 | (one16 << 16);
+  const uint32_t negbig = (uint32_t)T::from_f32(T::id == SFM_DT_F16 ? -60000.0f : -3.0e38f);
+  const u32x4 vones = {ones2, ones2, ones2, ones2};
+  uint32_t qaug[2] = {0u, 0u};
+  float m_run[2] = {0.f, 0.f};
+
+  f32x16 o[2][2], lacc[2], s[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[u][0][r] = 0.f;
+      o[u][1][r] = 0.f;
+      lacc[u][r] = 0.f;
+      s[u][r] = 0.f;
+    }
+  }
+
+  int srow[2], scol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    srow[i] = c >> 3;
+    scol[i] = (c & 7) * 8;
+  }
+  u32x4 rk[2], rv[2];
+  const int ntiles = (Tlen + 63) / 64;
+
+  auto load_kv = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = kt * 64 + srow[i];
+      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+      if (key < Tlen) {
+        const u16* rowp = base + (long long)key * ldqkv + scol[i];
+        a = *reinterpret_cast<const u32x4*>(rowp + koff);
+        c = *reinterpret_cast<const u32x4*>(rowp + voff);
+      }
+      rk[i] = a;
+      rv[i] = c;
+    }
+  };
+  auto store_kv = [&](int buf) {
+    u16* Kd = smem + buf * KV_BUF;
+    u16* Vd = Kd + 64 * KS_ROW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(&Kd[srow[i] * KS_ROW + scol[i]]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Vd[srow[i] * VS_ROW + scol[i]]) = rv[i];
+    }
+  };
+
+  // transposed V reads: 16-lane group g -> d block (g&1)*16, lane half = g>>1; lane 4q+p addresses row q, cols 4p..4p+3
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int vrow0 = 4 * (g16 >> 1) + (i16 >> 2);
+  const int vcol0 = (g16 & 1) * 16 + 4 * (i16 & 3);
+
+  u32x4 kf[4], vf[2][2];
+  auto load_kf = [&](int step) {                                   // K rows of 32-key step `step`
+    const u16* Ks = smem + ((step >> 1) & 1) * KV_BUF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      kf[ks] = *reinterpret_cast<const u32x4*>(&Ks[((step & 1) * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
+  };
+  auto load_vf = [&](int step) {                                   // V^T fragments of step `step`
+    const u16* Vs = smem + ((step >> 1) & 1) * KV_BUF + 64 * KS_ROW;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const u16* vp = &Vs[((step & 1) * 32 + s2 * 16 + vrow0) * VS_ROW + dj * 32 + vcol0];
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * VS_ROW));
+        const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
+        vf[s2][dj] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+      }
+  };
+
+  // Software pipeline over "items" (sub-block u of 32-key step i), order A(0) B(0) A(1) B(1) ...
+  //   item<u>(i):  S_u(i) MFMAs  ||  exp2 / pack of the PREVIOUS item's scores   (VALU in the MFMA gaps)
+  //                P.V MFMAs of the previous item  ||  row max of S_u(i)
+  //                rare wave-uniform branch: raise m_run[u] (rescales o[u], l[u], S_u(i))
+  // so every basic block carries 11 MFMAs and ~45 independent VALU instructions (sched_group_barrier spreads them).
+#define SFM_ATTN_ITEM(U, STEP, HAS_PREV, FIRST)                                                                       \
+  {                                                                                                                   \
+    constexpr int V_ = 1 - (U);                                                                                       \
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
+    const bool pad_ = (STEP) * 32 + l31 >= Tlen;                                                                      \
+    const u32x4 ka = {hl == 0 ? ones2 : 0u, (hl == 0 && pad_) ? one16 : 0u, 0u, 0u};                                  \
+    const u32x4 qa = {qaug[U], hl == 0 ? negbig : 0u, 0u, 0u};                                                        \
+    f32x16 sn = T::mfma(ka, qa, zero);                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) sn = T::mfma(kf[ks], qf[U][ks], sn);                             \
+    if (HAS_PREV) {                                                                                                   \
+      u32x4 pf[2];                                                                                                    \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+        float e_[8];                                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[V_][8 * s2 + r]);              \
+        pf[s2][0] = pack2<T>(e_[0], e_[1]);                                                                           \
+        pf[s2][1] = pack2<T>(e_[2], e_[3]);                                                                           \
+        pf[s2][2] = pack2<T>(e_[4], e_[5]);                                                                           \
+        pf[s2][3] = pack2<T>(e_[6], e_[7]);                                                                           \
+      }                                                                                                               \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+        lacc[V_] = T::mfma(vones, pf[s2], lacc[V_]);                                                                  \
+        o[V_][0] = T::mfma(vf[s2][0], pf[s2], o[V_][0]);                                                              \
+        o[V_][1] = T::mfma(vf[s2][1], pf[s2], o[V_][1]);                                                              \
+      }                                                                                                               \
+    }                                                                                                                 \
+    float mx = fmaxf(sn[0], sn[1]);                                                                                   \
+    _Pragma("unroll") for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sn[r]);                                             \
+    mx = xhalf_max(mx);                                                                                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < 11; ++g_) {                                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                              \
+    }                                                                                                                 \
+    if ((FIRST) || __any(mx > DEFER_THR)) {                                                                           \
+      const float want = m_run[U] + mx;                                                                               \
+      const float hi = T::to_f32(T::from_f32(want));                                                                  \
+      const float lo = T::to_f32(T::from_f32(want - hi));                                                             \
+      const float m_new = hi + lo;                                                                                    \
+      const float delta = m_new - m_run[U];                                                                           \
+      if (!(FIRST)) {                                                                                                 \
+        const float alpha = __builtin_amdgcn_exp2f(-delta);                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
+          o[U][0][r] *= alpha;                                                                                        \
+          o[U][1][r] *= alpha;                                                                                        \
+          lacc[U][r] *= alpha;                                                                                        \
+        }                                                                                                             \
+      }                                                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) sn[r] -= delta;                                                  \
+      m_run[U] = m_new;                                                                                               \
+      qaug[U] = (hl == 0) ? pack2<T>(-hi, -lo) : 0u;                                                                  \
+    }                                                                                                                 \
+    s[U] = sn;                                                                                                        \
+  }
+
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  load_kf(0);
+  // ---- first tile, peeled: the running maxima are initialised here and A(0) has no predecessor ----
+  {
+    const bool more = 1 < ntiles;
+    SFM_ATTN_ITEM(0, 0, false, true)
+    if (more) load_kv(1);
+    load_vf(0);
+    SFM_ATTN_ITEM(1, 0, true, true)
+    load_kf(1);
+    SFM_ATTN_ITEM(0, 1, true, false)
+    load_vf(1);
+    if (more) store_kv(1);
+    SFM_ATTN_ITEM(1, 1, true, false)
+    __syncthreads();
+    if (more) load_kf(2);
+  }
+  for (int kt = 1; kt < ntiles; ++kt) {
+    const int e = 2 * kt, od = 2 * kt + 1;
+    const bool more = kt + 1 < ntiles;
+    SFM_ATTN_ITEM(0, e, true, false)
+    if (more) load_kv(kt + 1);                                     // global -> registers, lands during this tile
+    load_vf(e);
+    SFM_ATTN_ITEM(1, e, true, false)
+    load_kf(od);
+    SFM_ATTN_ITEM(0, od, true, false)
+    load_vf(od);
+    if (more) store_kv((kt + 1) & 1);                              // readers of that buffer passed the previous barrier
+    SFM_ATTN_ITEM(1, od, true, false)
+    __syncthreads();                                               // tile kt fully consumed, tile kt+1 fully staged
+    if (more) load_kf(od + 1);
+  }
+  // drain: the last item B(last step) still has to be exponentiated and multiplied into O
+  {
+    u32x4 pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float e_[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[1][8 * s2 + r]);
+      pf[s2][0] = pack2<T>(e_[0], e_[1]);
+      pf[s2][1] = pack2<T>(e_[2], e_[3]);
+      pf[s2][2] = pack2<T>(e_[4], e_[5]);
+      pf[s2][3] = pack2<T>(e_[6], e_[7]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      lacc[1] = T::mfma(vones, pf[s2], lacc[1]);
+      o[1][0] = T::mfma(vf[s2][0], pf[s2], o[1][0]);
+      o[1][1] = T::mfma(vf[s2][1], pf[s2], o[1][1]);
+    }
+  }
+#undef SFM_ATTN_ITEM
+
+  // ---- epilogue: normalise, transpose through LDS (64 rows per wave), coalesced 16-byte stores ----
+  u16* Os = smem + wave * (64 * OS_ROW);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float l = lacc[u][0];
+    const float inv = 1.0f / l;
+    const int q = q0 + 32 * u + l31;
+    if (lse_out && hl == 0 && q < Tlen)
+      lse_out[((long long)b * nheads + h) * Tlen + q] = m_run[u] + __builtin_amdgcn_logf(l);
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = dj * 32 + 8 * rq + 4 * hl;
+        u32x2 w;
+        w[0] = pack2<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv);
+        w[1] = pack2<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv);
+        *reinterpret_cast<u32x2*>(&Os[(32 * u + l31) * OS_ROW + d0]) = w;
+      }
+  }
+  __syncthreads();
+  u16* ob = out + (long long)b * o_batch_stride + h * 64;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int row = c >> 3, ch = (c & 7) * 8;
+    const int q = q0 + row;
+    if (q < Tlen) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&Os[row * OS_ROW + ch]);
+      *reinterpret_cast<u32x4*>(ob + (long long)q * ldo + ch) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // generic small-shape attention: one wave per query row, lanes over head_dim
 // (<= 256 => up to 4 elements per lane), two passes over the keys in fp32.
 // ---------------------------------------------------------------------------
@@ -321,6 +615,16 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
   }
 }
 
+// kernel selection for the head_dim 64 no-dropout path: 0 = by sequence length (64 query rows per wave from T >= 1024,
+// where the software-pipelined kernel wins; 32 rows per wave below, where its shorter prologue does), 1 = always 32 rows
+// per wave, 2 = always 64 rows per wave
+static int sfm_attn_variant = 0;
+extern "C" int sfm_attention_set_variant(int v) {
+  if (v < 0 || v > 2) return SFM_ERR_ARG;
+  sfm_attn_variant = v;
+  return SFM_OK;
+}
+
 // qkv: [B, T, ldqkv] 16-bit with q at column h*hd, k at koff + h*hd, v at voff + h*hd.
 extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
                                        int ldo, int koff, int voff, long long qkv_batch_stride,
@@ -348,16 +652,27 @@ extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, i
   hipStream_t st = (hipStream_t)stream;
   if (hd == 64 && (ldqkv % 8) == 0 && (ldo % 8) == 0 && (koff % 8) == 0 && (voff % 8) == 0 &&
       (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
-    const int nqt = (T + 127) / 128;
-    dim3 grid(nqt * H * B), block(256);
     // scale <= 0: Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
     float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
-    if (dtype == SFM_DT_F16)
-      SFM_LAUNCH((attn_fwd_hd64_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
-                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed);
-    else
-      SFM_LAUNCH((attn_fwd_hd64_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo,
-                         koff, voff, qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed);
+    if (p_drop == 0.f && (sfm_attn_variant == 2 || (sfm_attn_variant == 0 && T >= 1024))) {   // 64 query rows per wave
+      const int nqt2 = (T + 255) / 256;
+      dim3 grid2(nqt2 * H * B), block2(256);
+      if (dtype == SFM_DT_F16)
+        SFM_LAUNCH((attn_fwd_hd64x2_kernel<F16>), grid2, block2, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
+                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse);
+      else
+        SFM_LAUNCH((attn_fwd_hd64x2_kernel<BF16>), grid2, block2, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
+                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse);
+      return SFM_OK;
+    }
+    const int nqt = (T + 127) / 128;
+    dim3 grid(nqt * H * B), block(256);
+#define ATTN_GO(TT, DD)                                                                                            \
+  SFM_LAUNCH((attn_fwd_hd64_kernel<TT, DD>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff, \
+             qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed)
+    if (dtype == SFM_DT_F16) { if (p_drop > 0.f) ATTN_GO(F16, true); else ATTN_GO(F16, false); }
+    else { if (p_drop > 0.f) ATTN_GO(BF16, true); else ATTN_GO(BF16, false); }
+#undef ATTN_GO
   } else {
     dim3 grid((T + 3) / 4, H, B), block(256);
     if (scale <= 0.f) scale = 0.69314718055994530942f;      // pre-scaled Q carries log2(e): exp(x ln2) = 2^x

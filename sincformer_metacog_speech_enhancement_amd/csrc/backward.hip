@@ -19,6 +19,7 @@ __device__ __forceinline__ float sfm_keep_scale(uint32_t seed, unsigned long lon
 // LayerNorm backward: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //                     dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy          (D <= 512)
 // ---------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ dy, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
@@ -26,6 +27,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float eps) {
   __shared__ float red[4][2][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // VEC: lane owns columns 4*lane..4*lane+3 of each 256-column half (16-byte loads); else column lane + 64*i
+#define LN_COL(i) (VEC ? (((i) >> 2) * 256 + 4 * lane + ((i) & 3)) : (lane + 64 * (i)))
   float pg[8], pb[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
@@ -34,18 +37,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float* gr = dy + (long long)row * ld;
     float v[8], g[8];
     float s = 0.f;
+    if (VEC) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int d = lane + 64 * i;
-      v[i] = (d < D) ? xr[d] : 0.f;
-      g[i] = (d < D) ? gr[d] : 0.f;
-      s += v[i];
+      for (int h = 0; h < 2; ++h) {
+        const int d = h * 256 + 4 * lane;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        if (d < D) {
+          a = *reinterpret_cast<const f32x4*>(xr + d);
+          c = *reinterpret_cast<const f32x4*>(gr + d);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[4 * h + j] = a[j]; g[4 * h + j] = c[j]; s += a[j]; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int d = LN_COL(i);
+        v[i] = (d < D) ? xr[d] : 0.f;
+        g[i] = (d < D) ? gr[d] : 0.f;
+        s += v[i];
+      }
     }
     const float mean = wave_sum_dpp(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int d = lane + 64 * i;
+      const int d = LN_COL(i);
       const float c = (d < D) ? v[i] - mean : 0.f;
       v[i] = c;
       q += c * c;
@@ -54,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float a = 0.f, bsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int d = lane + 64 * i;
+      const int d = LN_COL(i);
       const float xh = v[i] * rstd;
       v[i] = xh;
       pg[i] += g[i] * xh;
@@ -66,20 +83,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     a = wave_sum_dpp(a) / (float)D;
     bsum = wave_sum_dpp(bsum) / (float)D;
+    if (VEC) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int d = lane + 64 * i;
-      if (d < D) {
-        float o = rstd * (g[i] - a - v[i] * bsum);
-        if (dres) o += dres[(long long)row * ld + d];
-        dx[(long long)row * ld + d] = o;
+      for (int h = 0; h < 2; ++h) {
+        const int d = h * 256 + 4 * lane;
+        if (d < D) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = rstd * (g[4 * h + j] - a - v[4 * h + j] * bsum);
+          if (dres) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(dres + (long long)row * ld + d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += r[j];
+          }
+          *reinterpret_cast<f32x4*>(dx + (long long)row * ld + d) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int d = LN_COL(i);
+        if (d < D) {
+          float o = rstd * (g[i] - a - v[i] * bsum);
+          if (dres) o += dres[(long long)row * ld + d];
+          dx[(long long)row * ld + d] = o;
+        }
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    red[wave][0][lane + 64 * i] = pg[i];
-    red[wave][1][lane + 64 * i] = pb[i];
+    red[wave][0][LN_COL(i)] = pg[i];
+    red[wave][1][LN_COL(i)] = pb[i];
   }
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += 256) {
@@ -87,6 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     atomicAdd(&dbeta[d], red[0][1][d] + red[1][1][d] + red[2][1][d] + red[3][1][d]);
   }
 }
+#undef LN_COL
 
 extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                                  float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream) {
@@ -94,8 +130,14 @@ extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
   int nb = (M + 3) / 4;
   if (nb > 2048) nb = 2048;
-  SFM_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dres, dx, dgamma, dbeta, M, D,
-             ldx, ld, eps);
+  const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ld % 4 == 0) &&
+                   ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0);
+  if (vec)
+    SFM_LAUNCH(layernorm_bwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dres, dx, dgamma, dbeta,
+               M, D, ldx, ld, eps);
+  else
+    SFM_LAUNCH(layernorm_bwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dres, dx, dgamma, dbeta,
+               M, D, ldx, ld, eps);
   return SFM_OK;
 }
 
@@ -144,19 +186,127 @@ __global__ __launch_bounds__(256) void ew_train_kernel(const void* __restrict__ 
   }
 }
 
+// 8 consecutive elements per thread (N % 8 == 0, 16-byte aligned rows): 16-byte loads/stores of the 16-bit operands,
+// 2 x 16 bytes of the fp32 ones.  Same arithmetic and the same dropout counters as the scalar kernel above.
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void ew_train_vec_kernel(const void* __restrict__ z, const void* __restrict__ g,
+                                                           void* __restrict__ out, long long M, int N, int g_f32, int out_f32,
+                                                           float alpha, float p, uint32_t seed) {
+  const float inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  const long long chunks = M * N / 8;
+  const int cpr = N / 8;                                          // chunks per row
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (long long)gridDim.x * 256) {
+    const long long e0 = c * 8;
+    float gv[8], dr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      gv[i] = 1.0f;
+      dr[i] = (p > 0.f && MODE != 2 && MODE != 3) ? sfm_keep_scale(seed, (unsigned long long)(e0 + i), p, inv_keep) : 1.0f;
+    }
+    if (g) {
+      if (g_f32) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + e0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + e0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gv[i] = a[i]; gv[4 + i] = b[i]; }
+      } else {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(g) + e0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gv[2 * i] = T::to_f32((u16)(a[i] & 0xffffu)); gv[2 * i + 1] = T::to_f32((u16)(a[i] >> 16)); }
+      }
+    }
+    if (MODE == 0 || MODE == 1) {
+      const u32x4 zz = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(z) + e0);
+      float r[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float zv = T::to_f32((u16)((i & 1) ? (zz[i >> 1] >> 16) : (zz[i >> 1] & 0xffffu)));
+        const float sg = sigmoid_f(zv);
+        r[i] = (MODE == 0) ? zv * sg * dr[i] : gv[i] * dr[i] * sg * (1.0f + zv * (1.0f - sg));
+      }
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (uint32_t)T::from_f32(r[2 * i]) | ((uint32_t)T::from_f32(r[2 * i + 1]) << 16);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(out) + e0) = o;
+    } else if (MODE == 2 || MODE == 3) {
+      const long long m = c / cpr;
+      const int n0 = (int)(c - m * cpr) * 8;
+      const u16* zr = reinterpret_cast<const u16*>(z) + m * (2LL * N);
+      const u32x4 za = *reinterpret_cast<const u32x4*>(zr + n0);
+      const u32x4 zb = *reinterpret_cast<const u32x4*>(zr + N + n0);
+      float r0[8], r1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float a = T::to_f32((u16)((i & 1) ? (za[i >> 1] >> 16) : (za[i >> 1] & 0xffffu)));
+        const float b = T::to_f32((u16)((i & 1) ? (zb[i >> 1] >> 16) : (zb[i >> 1] & 0xffffu)));
+        const float sg = sigmoid_f(b);
+        if (MODE == 2) r0[i] = a * sg;
+        else { r0[i] = gv[i] * sg; r1[i] = gv[i] * a * sg * (1.0f - sg); }
+      }
+      u32x4 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o0[i] = (uint32_t)T::from_f32(r0[2 * i]) | ((uint32_t)T::from_f32(r0[2 * i + 1]) << 16);
+        if (MODE == 3) o1[i] = (uint32_t)T::from_f32(r1[2 * i]) | ((uint32_t)T::from_f32(r1[2 * i + 1]) << 16);
+      }
+      if (MODE == 2) *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(out) + e0) = o0;
+      else {
+        u16* orow = reinterpret_cast<u16*>(out) + m * (2LL * N);
+        *reinterpret_cast<u32x4*>(orow + n0) = o0;
+        *reinterpret_cast<u32x4*>(orow + N + n0) = o1;
+      }
+    } else {
+      float r[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = alpha * gv[i] * dr[i];
+      if (z) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(z) + e0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(z) + e0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[i] += a[i]; r[4 + i] += b[i]; }
+      }
+      if (out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + e0) = f32x4{r[0], r[1], r[2], r[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + e0 + 4) = f32x4{r[4], r[5], r[6], r[7]};
+      } else {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (uint32_t)T::from_f32(r[2 * i]) | ((uint32_t)T::from_f32(r[2 * i + 1]) << 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(out) + e0) = o;
+      }
+    }
+  }
+}
+
+template <class T>
+static int ew_train_launch(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
+                           float alpha, float p, unsigned int seed, hipStream_t st) {
+  const bool aligned = (N % 8 == 0) && (((uintptr_t)z | (uintptr_t)g | (uintptr_t)out) % 16 == 0);
+  if (!aligned) {
+    long long nb = (M * N + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    SFM_LAUNCH((ew_train_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed);
+    return SFM_OK;
+  }
+  long long nb = (M * N / 8 + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  const dim3 grid((unsigned)nb), block(256);
+  switch (mode) {
+    case 0: SFM_LAUNCH((ew_train_vec_kernel<T, 0>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+    case 1: SFM_LAUNCH((ew_train_vec_kernel<T, 1>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+    case 2: SFM_LAUNCH((ew_train_vec_kernel<T, 2>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+    case 3: SFM_LAUNCH((ew_train_vec_kernel<T, 3>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+    default: SFM_LAUNCH((ew_train_vec_kernel<T, 4>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+  }
+  return SFM_OK;
+}
+
 extern "C" int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                             float alpha, float p, unsigned int seed, int dtype, void* stream) {
   if (!out || (mode <= 3 && !z) || ((mode == 1 || mode == 3 || mode == 4) && !g)) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0 || mode < 0 || mode > 4 || p < 0.f || p >= 1.f) return SFM_ERR_SHAPE;
-  long long nb = (M * N + 255) / 256;
-  if (nb > 16384) nb = 16384;
-  if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((ew_train_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, z, g, out, M, N, mode, g_f32,
-               out_f32, alpha, p, seed);
-  else
-    SFM_LAUNCH((ew_train_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, z, g, out, M, N, mode, g_f32,
-               out_f32, alpha, p, seed);
-  return SFM_OK;
+  if (dtype == SFM_DT_F16) return ew_train_launch<F16>(z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed, (hipStream_t)stream);
+  return ew_train_launch<BF16>(z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -252,41 +402,74 @@ extern "C" int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean
 // one thread per channel, KS accumulators, a block covers a span of frames of one utterance
 // ---------------------------------------------------------------------------
 template <class T, int KS>
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const u16* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(128) void dwconv_wgrad_kernel(const u16* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dw, float* __restrict__ db, int Tlen,
                                                            int C, int span) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  // two adjacent channels per thread (one 4-byte load of x, one 8-byte load of dy per frame); the KS-frame window of x
+  // lives in registers and is indexed with compile-time (j + k) % KS, so sliding it costs no moves
+  const int c = (blockIdx.x * 128 + threadIdx.x) * 2;
   if (c >= C) return;
   const int b = blockIdx.z;
   const int t0 = blockIdx.y * span, t1 = min(Tlen, t0 + span);
   constexpr int pad = (KS - 1) / 2;
   const u16* xb = x + (long long)b * Tlen * C + c;
   const float* gb = dy + (long long)b * Tlen * C + c;
-  float acc[KS];
+  float acc0[KS], acc1[KS], w0[KS], w1[KS];
+  auto load_x = [&](int tt, float& a, float& bb) {
+    if (tt >= 0 && tt < Tlen) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + (long long)tt * C);
+      a = T::to_f32((u16)(v & 0xffffu));
+      bb = T::to_f32((u16)(v >> 16));
+    } else {
+      a = 0.f;
+      bb = 0.f;
+    }
+  };
 #pragma unroll
-  for (int k = 0; k < KS; ++k) acc[k] = 0.f;
-  float sb = 0.f;
-  for (int t = t0; t < t1; ++t) {
-    const float g = gb[(long long)t * C];
-    sb += g;
+  for (int k = 0; k < KS; ++k) {
+    acc0[k] = 0.f;
+    acc1[k] = 0.f;
+    load_x(t0 + k - pad, w0[k], w1[k]);
+  }
+  float sb0 = 0.f, sb1 = 0.f;
+  for (int tb = t0; tb < t1; tb += KS) {
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const int tt = t + k - pad;
-      const float xv = (tt >= 0 && tt < Tlen) ? T::to_f32(xb[(long long)tt * C]) : 0.f;
-      acc[k] += g * xv;
+    for (int j = 0; j < KS; ++j) {
+      const int t = tb + j;
+      float g0 = 0.f, g1 = 0.f;
+      if (t < t1) {
+        const f32x2 g = *reinterpret_cast<const f32x2*>(gb + (long long)t * C);
+        g0 = g[0];
+        g1 = g[1];
+      }
+      sb0 += g0;
+      sb1 += g1;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        acc0[k] += g0 * w0[(j + k) % KS];
+        acc1[k] += g1 * w1[(j + k) % KS];
+      }
+      load_x(t + pad + 1, w0[j], w1[j]);                     // slot j held x[t - pad]: no longer needed
     }
   }
 #pragma unroll
-  for (int k = 0; k < KS; ++k) atomicAdd(&dw[c * KS + k], acc[k]);
-  atomicAdd(&db[c], sb);
+  for (int k = 0; k < KS; ++k) {
+    atomicAdd(&dw[c * KS + k], acc0[k]);
+    atomicAdd(&dw[(c + 1) * KS + k], acc1[k]);
+  }
+  atomicAdd(&db[c], sb0);
+  atomicAdd(&db[c + 1], sb1);
 }
 
 extern "C" int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, int B, int T, int C, int KS,
                                 int dtype, void* stream) {
   if (!x || !dy || !dw || !db) return SFM_ERR_ARG;
-  if (B <= 0 || T <= 0 || C <= 0 || (KS != 31 && KS != 7)) return SFM_ERR_SHAPE;
-  const int span = 64;
-  dim3 grid((C + 255) / 256, (T + span - 1) / span, B), block(256);
+  if (B <= 0 || T <= 0 || C <= 0 || (C & 1) || (KS != 31 && KS != 7)) return SFM_ERR_SHAPE;
+  int nspan = (2048 + B - 1) / B;                              // enough workgroups to fill the chip, few atomics
+  if (nspan > (T + 63) / 64) nspan = (T + 63) / 64;
+  if (nspan < 1) nspan = 1;
+  const int span = (T + nspan - 1) / nspan;
+  dim3 grid((C + 255) / 256, (T + span - 1) / span, B), block(128);
   hipStream_t st = (hipStream_t)stream;
 #define GO(TT, KK) SFM_LAUNCH((dwconv_wgrad_kernel<TT, KK>), grid, block, 0, st, (const u16*)x, dy, dw, db, T, C, span)
   if (dtype == SFM_DT_F16) { if (KS == 31) GO(F16, 31); else GO(F16, 7); }

@@ -139,6 +139,48 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G,
   atomicAdd(&out[n], s);
 }
 
+// vector form: 256 columns x 256 rows per workgroup, 16-byte loads, LDS reduction over the row lanes
+template <class T, int F32>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const void* __restrict__ G, float* __restrict__ out, int M, int N,
+                                                         int ldg) {
+  constexpr int VW = F32 ? 4 : 8;                 // columns per 16-byte load
+  constexpr int TX = 256 / VW;                    // threads across the 256 columns
+  constexpr int TY = 256 / TX;                    // row lanes
+  __shared__ float red[TY][256];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int n0 = blockIdx.x * 256 + tx * VW;
+  const int m0 = blockIdx.y * 256, m1 = min(M, m0 + 256);
+  float acc[VW];
+#pragma unroll
+  for (int i = 0; i < VW; ++i) acc[i] = 0.f;
+  if (n0 < N) {
+    for (int m = m0 + ty; m < m1; m += TY) {
+      if (F32) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(G) + (long long)m * ldg + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += v[i];
+      } else {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(G) + (long long)m * ldg + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] += T::to_f32((u16)(v[i] & 0xffffu));
+          acc[2 * i + 1] += T::to_f32((u16)(v[i] >> 16));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VW; ++i) red[ty][tx * VW + i] = acc[i];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < TY; ++j) s += red[j][threadIdx.x];
+    atomicAdd(&out[n], s);
+  }
+}
+
 extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,
                              int dtype, void* stream) {
   if (!G || !X || !dW) return SFM_ERR_ARG;
@@ -164,6 +206,14 @@ extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int
 extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream) {
   if (!G || !out) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0) return SFM_ERR_SHAPE;
+  const int vw = g_f32 ? 4 : 8;
+  if (N % vw == 0 && ldg % vw == 0 && ((uintptr_t)G % 16) == 0) {
+    dim3 grid((N + 255) / 256, (M + 255) / 256), block(256);
+    if (g_f32) SFM_LAUNCH((colsum_vec_kernel<BF16, 1>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg);
+    else if (dtype == SFM_DT_F16) SFM_LAUNCH((colsum_vec_kernel<F16, 0>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg);
+    else SFM_LAUNCH((colsum_vec_kernel<BF16, 0>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg);
+    return SFM_OK;
+  }
   int rpb = 512;
   dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb), block(256);
   if (dtype == SFM_DT_F16)

@@ -265,6 +265,11 @@ def pack_f32_matrix(wt_kn):
 ATTN_QSCALE_LOG2E = 1.4426950408889634
 
 
+def set_attention_variant(v):
+    """0: chosen by sequence length (default), 1: 32 query rows per wave, 2: 64 query rows per wave (A/B measurements)."""
+    _lib.check(_lib.load().sfm_attention_set_variant(int(v)), "attention_set_variant")
+
+
 def attention(qkv16, B, T, H, hd, out=None, prescaled=False):
     """qkv16 [B*T, 3*H*hd] (q | k | v) -> [B*T, H*hd].  prescaled: q already multiplied by
     log2(e)/sqrt(hd) (functional.pack_mhsa folds it into W_q, b_q before the 16-bit rounding)."""

@@ -230,27 +230,37 @@ def _attn_ref(qkv, B, T, H, hd):
     return (p @ v).transpose(1, 2).reshape(B * T, D)
 
 
+@pytest.mark.parametrize("variant", [1, 2])          # both head_dim-64 kernels: 32 / 64 query rows per wave
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,T,H,hd", [(2, 200, 4, 64), (1, 64, 4, 64), (3, 1, 2, 64), (1, 801, 4, 64), (2, 129, 1, 64),
-                                      (2, 20, 4, 16), (1, 37, 2, 32)])
-def test_attention(ops, dt, B, T, H, hd):
+                                      (1, 1100, 2, 64), (2, 20, 4, 16), (1, 37, 2, 32)])
+def test_attention(ops, dt, B, T, H, hd, variant):
     ops.set_compute_dtype(dt)
-    qkv = arr("aq", (B * T, 3 * H * hd), 40 + T, 1.5)
-    out = ops.attention(dev(qkv).to(dt).contiguous(), B, T, H, hd)
+    ops.set_attention_variant(variant)
+    try:
+        qkv = arr("aq", (B * T, 3 * H * hd), 40 + T, 1.5)
+        out = ops.attention(dev(qkv).to(dt).contiguous(), B, T, H, hd)
+    finally:
+        ops.set_attention_variant(0)
     ref = _attn_ref(q16(qkv, dt), B, T, H, hd)
-    report("attention %s B%d T%d H%d hd%d" % (dt, B, T, H, hd), out.float().cpu(), ref, 6 * EPS[dt])
+    report("attention v%d %s B%d T%d H%d hd%d" % (variant, dt, B, T, H, hd), out.float().cpu(), ref, 6 * EPS[dt])
 
 
-def test_attention_online_softmax_rescale(ops):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_online_softmax_rescale(ops, variant):
     """a spiked key late in the sequence forces the running-max rescale branch"""
     ops.set_compute_dtype(torch.float16)
     B, T, H, hd = 1, 300, 1, 64
     qkv = arr("aq2", (B * T, 3 * hd), 77, 0.5)
     qkv[5, :hd] = 3.0
     qkv[250, hd:2 * hd] = 3.0          # key 250 aligned with query 5: score jumps in the 4th tile
-    out = ops.attention(dev(qkv).half().contiguous(), B, T, H, hd)
+    ops.set_attention_variant(variant)
+    try:
+        out = ops.attention(dev(qkv).half().contiguous(), B, T, H, hd)
+    finally:
+        ops.set_attention_variant(0)
     ref = _attn_ref(q16(qkv, torch.float16), B, T, H, hd)
-    report("attention rescale", out.float().cpu(), ref, 3e-3)
+    report("attention rescale v%d" % variant, out.float().cpu(), ref, 3e-3)
 
 
 # ---------------------------------------------------------------------------

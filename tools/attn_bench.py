@@ -12,8 +12,10 @@ ap.add_argument("--frames", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--variant", type=int, default=0, help="0: auto by T, 1: 32 q rows/wave, 2: 64 q rows/wave (pipelined)")
 a = ap.parse_args()
 ops.set_compute_dtype(a.dtype)
+ops.set_attention_variant(a.variant)
 B, T, H, hd = a.batch, a.frames, a.heads, 64
 g = torch.Generator(device="cuda").manual_seed(1)
 qkv = (torch.randn(B * T, 3 * H * hd, device="cuda", generator=g) * 1.0).to(ops.compute_dtype())
@@ -29,5 +31,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 fl = 4.0 * B * H * T * T * hd
-print(json.dumps({"kernel": "attn_fwd_hd64", "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
+print(json.dumps({"kernel": "attn_fwd_hd64x2" if (a.variant == 2 or (a.variant == 0 and a.frames >= 1024)) else "attn_fwd_hd64", "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
                   "tflops": fl / ms / 1e9, "frac_of_2.5PF": fl / ms / 1e9 / 2500.0}))
