@@ -205,5 +205,57 @@ def main():
     save("g9_path", mask_real=mr9, mask_imag=mi9, enhanced=wav9, mem_bias=m9["bias"], mem_gate=m9["gate"])
 
 
+def _pack_grads(named):
+    """small gradients whole; of the big weight matrices the first 4 rows + the Frobenius norm (fixtures stay small)."""
+    out = {}
+    for k, g in named:
+        g = g.detach()
+        if g.numel() <= 4096:
+            out["grad." + k] = g
+        else:
+            out["gradrows." + k] = g.reshape(g.shape[0], -1)[:4]
+            out["gradnorm." + k] = torch.linalg.vector_norm(g).reshape(1)
+    return out
+
+
+def main_train():
+    """training-mode fixtures: the reference's own modules in train() mode with dropout p = 0 (BatchNorm batch
+    statistics + running-stat update), outputs and autograd gradients."""
+    from models.conformer import ConformerBlock
+    from training import conformer_pipeline as cp
+
+    # --- G10: one full-size ConformerBlock, train mode, B2 T50
+    blk = load_synth(ConformerBlock(256, 4, 1024, 31, 0.0), 43)
+    blk.train()
+    x = torch.from_numpy(syn.synth_array("g10_x", (2, 50, 256), 101)).requires_grad_(True)
+    cot = torch.from_numpy(syn.synth_array("g10_c", (2, 50, 256), 102))
+    y = blk(x)
+    (y * cot).sum().backward()
+    save("g10_block_train", out=y, dx=x.grad, running_mean=blk.conv.batch_norm.running_mean,
+         running_var=blk.conv.batch_norm.running_var, num_batches_tracked=blk.conv.batch_norm.num_batches_tracked,
+         **_pack_grads((k, p.grad) for k, p in blk.named_parameters()))
+
+    # --- G11: SpeechEnhancer training step (model forward -> _compute_loss -> backward), B2 L2400
+    se = load_synth(cp.SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31,
+                                      dropout=0.0), 81)
+    se.train()
+    noisy, clean = syn.synth_wave(2, 2400, 111)
+    nw, cw = torch.from_numpy(noisy), torch.from_numpy(clean)
+    nr, ni = cp.batch_stft(nw, 256, 80, 160)
+    cr, ci = cp.batch_stft(cw, 256, 80, 160)
+    pipe = cp.ConformerPipeline.__new__(cp.ConformerPipeline)
+    pipe.model = se
+    pipe.fft_size, pipe.hop_size, pipe.frame_size = 256, 80, 160
+    tot, nsi = pipe._compute_loss(nr, ni, cw, cr, ci, cp.MultiResolutionSTFTLoss())
+    tot.backward()
+    save("g11_enhancer_train", loss=tot, neg_sisnr=nsi,
+         bn0_running_mean=se.blocks[0].conv.batch_norm.running_mean,
+         **_pack_grads((k, p.grad) for k, p in se.named_parameters()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--train-only" in sys.argv:
+        main_train()
+    else:
+        main()
+        main_train()

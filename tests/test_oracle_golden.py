@@ -154,3 +154,57 @@ def test_param_counts_match_survey():
     assert STATE_TABLES["PerceptionAgent"]["params"] == 1268865
     assert STATE_TABLES["MaskSynthesisAgent"]["params"] == 9665282
     assert STATE_TABLES["SpeechEnhancer"]["params"] == 6225414
+
+
+# ---------------------------------------------------------------------------
+# training-mode fixtures (reference modules in train(), dropout p = 0): pin the oracle's BatchNorm batch-statistics
+# branch and its autograd gradients — the reference for tests/test_train_gpu.py — to the reference itself
+# ---------------------------------------------------------------------------
+def _check_packed_grads(g, named_grads, tol_rel):
+    worst = 0.0
+    for k, got in named_grads:
+        if "grad." + k in g:
+            ref = torch.from_numpy(g["grad." + k])
+            scale = float(ref.abs().max()) + 1e-6
+            if k.endswith("depthwise.bias"):              # analytically zero behind BatchNorm: both are rounding noise
+                assert float(got.abs().max()) < 1e-3 and scale < 1e-3
+                continue
+            worst = max(worst, maxerr(got, ref) / scale)
+        else:
+            rows = torch.from_numpy(g["gradrows." + k])
+            scale = float(rows.abs().max()) + 1e-6
+            worst = max(worst, maxerr(got.reshape(got.shape[0], -1)[:4], rows) / scale)
+            nrm = float(g["gradnorm." + k][0])
+            assert abs(float(torch.linalg.vector_norm(got)) - nrm) < tol_rel * nrm, k
+        assert worst < tol_rel, (k, worst)
+    return worst
+
+
+def test_conformer_block_train_mode_and_gradients():
+    g = gold("g10_block_train")
+    sd = synth_sd("ConformerBlock", 43)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    x = arr("g10_x", (2, 50, 256), 101).requires_grad_(True)
+    cot = arr("g10_c", (2, 50, 256), 102)
+    y = orc.conformer_block(x, ref_sd, 4, bn_train=True)
+    assert maxerr(y.detach(), g["out"]) < TOL
+    (y * cot).sum().backward()
+    assert maxerr(x.grad, g["dx"]) < 2e-4 * float(np.abs(g["dx"]).max())
+    w = _check_packed_grads(g, ((k, v.grad) for k, v in ref_sd.items() if v.dtype.is_floating_point and v.requires_grad), 5e-4)
+    print("worst relative gradient error vs the reference's autograd: %.2e" % w)
+
+
+def test_speech_enhancer_training_loss_and_gradients():
+    g = gold("g11_enhancer_train")
+    sd = synth_sd("SpeechEnhancer", 81)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    noisy, clean = syn.synth_wave(2, 2400, 111)
+    tot, nsi, _ = orc.enhancer_loss(ref_sd, torch.from_numpy(noisy), torch.from_numpy(clean), 4, bn_train=True)
+    assert abs(float(tot) - float(g["loss"])) < 2e-4
+    assert abs(float(nsi) - float(g["neg_sisnr"])) < 2e-4
+    tot.backward()
+    # the objective has |.| and 1/|P| terms: fp32 summation-order differences move a few gradient entries by ~1e-3
+    w = _check_packed_grads(g, ((k, v.grad) for k, v in ref_sd.items() if v.dtype.is_floating_point and v.requires_grad), 2e-2)
+    print("worst relative gradient error vs the reference's autograd: %.2e" % w)

@@ -324,3 +324,81 @@ def test_speech_enhancer_learns_with_flat_adamw():
     with torch.no_grad():
         e2 = m(nr, ni)[0]
     assert not torch.equal(e1, e2)
+
+
+# ---------------------------------------------------------------------------
+# HIP training path directly against the fixtures captured from the reference in train() mode (tests/golden/g10, g11)
+# ---------------------------------------------------------------------------
+from helpers import gold  # noqa: E402
+
+
+def _packed_rel(g, k, got):
+    got = got.detach().float().cpu()
+    if "grad." + k in g:
+        ref = torch.from_numpy(g["grad." + k])
+        return _rel(got, ref), float(ref.pow(2).mean().sqrt())
+    rows = torch.from_numpy(g["gradrows." + k])
+    nrm = float(g["gradnorm." + k][0])
+    r = _rel(got.reshape(got.shape[0], -1)[:4], rows)
+    return max(r, abs(float(torch.linalg.vector_norm(got)) - nrm) / nrm), float(rows.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_block_train_vs_reference_fixture(dt):
+    from sincformer_metacog_speech_enhancement_amd import ops, train
+    ops.set_compute_dtype(dt)
+    g = gold("g10_block_train")
+    m, sd = _block(0.0, seed=43)
+    m.train()
+    x = arr("g10_x", (2, 50, 256), 101).cuda().requires_grad_(True)
+    cot = arr("g10_c", (2, 50, 256), 102).cuda()
+    y = m(x)
+    (y * cot).sum().backward()
+    e = rmse(y.detach().cpu(), g["out"])
+    print("block train vs reference fixture %s: out rmse %.3e" % (dt, e))
+    assert e < (1e-3 if dt is torch.float16 else 6e-3)
+    tol = 0.01 if dt is torch.float16 else 0.05
+    assert _rel(x.grad.cpu(), g["dx"]) < tol
+    named = dict(m.named_parameters())
+    for k in train.PARAM_NAMES:
+        if k == "conv.depthwise.bias":
+            continue
+        r, rms = _packed_rel(g, k, named[k].grad)
+        assert r < tol, (k, r, rms)
+    bn = m.conv.batch_norm
+    assert maxerr(bn.running_mean.cpu(), g["running_mean"]) < 2e-3
+    assert maxerr(bn.running_var.cpu(), g["running_var"]) < 2e-3 * float(np.abs(g["running_var"]).max())
+    assert int(bn.num_batches_tracked) == int(g["num_batches_tracked"])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_speech_enhancer_train_step_vs_reference_fixture(dt):
+    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
+    ops.set_compute_dtype(dt)
+    g = gold("g11_enhancer_train")
+    m = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.0)
+    m.load_state_dict(synth_sd("SpeechEnhancer", 81), strict=True)
+    m.cuda().train()
+    noisy, clean = syn.synth_wave(2, 2400, 111)
+    noisy, clean = torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda()
+    nr, ni = batch_stft(noisy, 256, 80, 160)
+    cr, ci = batch_stft(clean, 256, 80, 160)
+    total, neg_sisnr = compute_loss(m, nr, ni, clean, cr, ci)
+    total.backward()
+    print("SpeechEnhancer step vs reference fixture %s: loss %.5f (ref %.5f) neg_sisnr %.5f (ref %.5f)" %
+          (dt, float(total), float(g["loss"]), float(neg_sisnr), float(g["neg_sisnr"])))
+    tol_l = 2e-3 if dt is torch.float16 else 2e-2
+    assert abs(float(total) - float(g["loss"])) < tol_l * max(1.0, abs(float(g["loss"])))
+    assert abs(float(neg_sisnr) - float(g["neg_sisnr"])) < tol_l * max(1.0, abs(float(g["neg_sisnr"])))
+    tol_g = 0.06 if dt is torch.float16 else 0.25        # non-smooth objective: see test_speech_enhancer_train_step_matches_autograd
+    worst = ("", 0.0)
+    for k, p_ in m.named_parameters():
+        if k.endswith("depthwise.bias"):
+            continue
+        r, _ = _packed_rel(g, k, p_.grad)
+        if r > worst[1]:
+            worst = (k, r)
+    print("  worst parameter-gradient error vs the reference's autograd: %s %.3e" % worst)
+    assert worst[1] < tol_g, worst
+    assert maxerr(m.blocks[0].conv.batch_norm.running_mean.cpu(), g["bn0_running_mean"]) < 3e-3
