@@ -178,6 +178,11 @@ int sfm_stft_adjoint_ola(const float* frames, float* dwave, const float* post, i
 int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* nr, const float* ni, const float* der,
                        const float* dei, float* dlog, long long M, int F, float phase_scale, long long ld_logits,
                        long long ld_dlog, void* stream);
+/* small-shape attention backward (any head_dim <= 256; the MFMA kernels of sfm_attention_bwd need head_dim 64):
+ * dkv32 = zero-filled fp32 scratch [B*T, 2*H*hd]; dqkv gets dQ' | dK | dV like sfm_attention_bwd. */
+int sfm_attention_bwd_generic(const void* qkv, const void* O, const void* dO, const float* lse, float* dkv32, void* dqkv,
+                              int B, int T, int H, int hd, int ldqkv, int ldo, int koff, int voff, float p_drop,
+                              unsigned int seed, int dtype, void* stream);
 /* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
  * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
  * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */

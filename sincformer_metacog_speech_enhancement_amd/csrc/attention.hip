@@ -574,11 +574,15 @@ template <class T>
 __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
                                                                int Tlen, int hd, int ldqkv, int ldo, int koff,
                                                                int voff, long long qkv_batch_stride,
-                                                               long long o_batch_stride, float scale) {
+                                                               long long o_batch_stride, float scale,
+                                                               float* __restrict__ lse_out, float p_drop, uint32_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave;
   const int h = blockIdx.y, b = blockIdx.z;
+  const int nheads = gridDim.y;
   if (q >= Tlen) return;
+  const float inv_keep = (p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned long long rowbase = (((unsigned long long)b * nheads + h) * Tlen + q) * Tlen;
   const u16* base = qkv + (long long)b * qkv_batch_stride + h * hd;
   float qv[4], acc[4];
 #pragma unroll
@@ -601,12 +605,15 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
     float al = expf(m - mn), pv = expf(sc - mn);
     l = l * al + pv;
     m = mn;
+    const float pd = (p_drop > 0.f) ? pv * attn_keep_fwd(seed, rowbase + key, p_drop, inv_keep) : pv;   // O only, not l
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int d = lane + 64 * i;
-      if (d < hd) acc[i] = acc[i] * al + pv * T::to_f32(kr[voff + d]);
+      if (d < hd) acc[i] = acc[i] * al + pd * T::to_f32(kr[voff + d]);
     }
   }
+  if (lse_out && lane == 0)                        // log2-domain log-sum-exp of the scaled scores, as the MFMA kernels write it
+    lse_out[((long long)b * nheads + h) * Tlen + q] = (m + logf(l)) * 1.44269504088896340736f;
   u16* ob = out + (long long)b * o_batch_stride + h * hd;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -638,14 +645,12 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
                                  scale, 0.f, 0u, dtype, stream);
 }
 
-// training-mode forward: also writes lse [B,H,T] (log2 domain) and applies attention dropout (head_dim 64 only
-// when lse != NULL or p_drop > 0)
+// training-mode forward: also writes lse [B,H,T] (log2 domain) and applies attention dropout
 extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
                                        int ldo, int koff, int voff, long long qkv_batch_stride,
                                        long long o_batch_stride, float scale, float p_drop, unsigned int seed,
                                        int dtype, void* stream) {
   if (!qkv || !out) return SFM_ERR_ARG;
-  if ((lse || p_drop > 0.f) && hd != 64) return SFM_ERR_SHAPE;
   if (p_drop < 0.f || p_drop >= 1.f) return SFM_ERR_SHAPE;
   if ((lse || p_drop > 0.f) && (qkv_batch_stride != (long long)T * ldqkv)) return SFM_ERR_SHAPE;
   if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 256) return SFM_ERR_SHAPE;
@@ -678,10 +683,10 @@ extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, i
     if (scale <= 0.f) scale = 0.69314718055994530942f;      // pre-scaled Q carries log2(e): exp(x ln2) = 2^x
     if (dtype == SFM_DT_F16)
       SFM_LAUNCH((attn_fwd_generic_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd, ldqkv,
-                         ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);
+                         ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale, lse, p_drop, seed);
     else
       SFM_LAUNCH((attn_fwd_generic_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, hd,
-                         ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale);
+                         ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale, lse, p_drop, seed);
   }
   SFM_CHECK_LAUNCH();
   return SFM_OK;

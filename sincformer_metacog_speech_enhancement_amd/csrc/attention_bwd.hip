@@ -327,6 +327,108 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const u16* __restrict
 
 // qkv [B,T,ldqkv] (q' | k | v, q' pre-scaled), O / dO [B,T,ldo] 16-bit, lse [B,H,T] fp32 (log2 domain, from
 // sfm_attention_fwd_train), dqkv [B,T,ldqkv] 16-bit out, delta = workspace [B,H,T] fp32.  head_dim 64 only.
+// ---------------------------------------------------------------------------
+// generic small-shape backward (any head_dim <= 256, e.g. the reference's test config d_model 64 / 4 heads = 16):
+// one wave per query row, lanes over head_dim, fp32 VALU; dQ is written directly, dK / dV are accumulated with
+// float atomics into a zero-filled fp32 scratch [B*T, 2*H*hd] that the caller converts afterwards.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const u16* __restrict__ qkv, const u16* __restrict__ O,
+                                                               const u16* __restrict__ dO, const float* __restrict__ lse,
+                                                               u16* __restrict__ dqkv, float* __restrict__ dkv32, int Tlen,
+                                                               int hd, int ldqkv, int ldo, int koff, int voff,
+                                                               float p_drop, uint32_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
+  const int h = blockIdx.y, b = blockIdx.z, nheads = gridDim.y;
+  if (q >= Tlen) return;
+  const int D = nheads * hd;
+  const u16* base = qkv + (long long)b * Tlen * ldqkv + h * hd;
+  const long long orow = ((long long)b * Tlen + q) * ldo + h * hd;
+  float qv[4], dov[4], dq[4];
+  float part = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    qv[i] = (d < hd) ? T::to_f32(base[(long long)q * ldqkv + d]) : 0.f;
+    dov[i] = (d < hd) ? T::to_f32(dO[orow + d]) : 0.f;
+    const float ov = (d < hd) ? T::to_f32(O[orow + d]) : 0.f;
+    part += dov[i] * ov;
+    dq[i] = 0.f;
+  }
+  const float delta = wave_sum(part);
+  const float lse_q = lse[((long long)b * nheads + h) * Tlen + q];
+  const float inv_keep = (p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned long long rowbase = (((unsigned long long)b * nheads + h) * Tlen + q) * Tlen;
+  for (int key = 0; key < Tlen; ++key) {
+    const u16* kr = base + (long long)key * ldqkv;
+    float kv[4], vv[4];
+    float ps = 0.f, pd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane + 64 * i;
+      kv[i] = (d < hd) ? T::to_f32(kr[koff + d]) : 0.f;
+      vv[i] = (d < hd) ? T::to_f32(kr[voff + d]) : 0.f;
+      ps += qv[i] * kv[i];
+      pd += dov[i] * vv[i];
+    }
+    const float s2 = wave_sum(ps), dp = wave_sum(pd);
+    const float pv = exp2f(s2 - lse_q);
+    const float keep = (p_drop > 0.f) ? attn_keep(seed, rowbase + key, p_drop, inv_keep) : 1.0f;
+    const float ds = 0.69314718056f * pv * (dp * keep - delta);
+    float* dkr = dkv32 + ((long long)b * Tlen + key) * (2LL * D) + h * hd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane + 64 * i;
+      if (d < hd) {
+        dq[i] += ds * kv[i];
+        atomicAdd(&dkr[d], ds * qv[i]);
+        atomicAdd(&dkr[D + d], pv * keep * dov[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    if (d < hd) dqkv[((long long)b * Tlen + q) * ldqkv + h * hd + d] = T::from_f32(dq[i]);
+  }
+}
+
+// scratch -> 16-bit dK | dV columns of dqkv
+template <class T>
+__global__ __launch_bounds__(256) void attn_bwd_pack_kv_kernel(const float* __restrict__ dkv32, u16* __restrict__ dqkv,
+                                                               long long M, int D, int ldqkv, int koff) {
+  const long long total = M * 2LL * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long m = e / (2LL * D);
+    const int c = (int)(e - m * 2LL * D);
+    dqkv[m * ldqkv + koff + c] = T::from_f32(dkv32[e]);
+  }
+}
+
+extern "C" int sfm_attention_bwd_generic(const void* qkv, const void* O, const void* dO, const float* lse, float* dkv32,
+                                         void* dqkv, int B, int T, int H, int hd, int ldqkv, int ldo, int koff, int voff,
+                                         float p_drop, unsigned int seed, int dtype, void* stream) {
+  if (!qkv || !O || !dO || !lse || !dkv32 || !dqkv) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 256 || voff != koff + H * hd) return SFM_ERR_SHAPE;
+  if (p_drop < 0.f || p_drop >= 1.f) return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((T + 3) / 4, H, B), block(256);
+  const long long M = (long long)B * T;
+  long long nb = (M * 2 * H * hd + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (dtype == SFM_DT_F16) {
+    SFM_LAUNCH((attn_bwd_generic_kernel<F16>), grid, block, 0, st, (const u16*)qkv, (const u16*)O, (const u16*)dO, lse,
+               (u16*)dqkv, dkv32, T, hd, ldqkv, ldo, koff, voff, p_drop, seed);
+    SFM_LAUNCH((attn_bwd_pack_kv_kernel<F16>), dim3((unsigned)nb), block, 0, st, dkv32, (u16*)dqkv, M, H * hd, ldqkv, koff);
+  } else {
+    SFM_LAUNCH((attn_bwd_generic_kernel<BF16>), grid, block, 0, st, (const u16*)qkv, (const u16*)O, (const u16*)dO, lse,
+               (u16*)dqkv, dkv32, T, hd, ldqkv, ldo, koff, voff, p_drop, seed);
+    SFM_LAUNCH((attn_bwd_pack_kv_kernel<BF16>), dim3((unsigned)nb), block, 0, st, dkv32, (u16*)dqkv, M, H * hd, ldqkv, koff);
+  }
+  return SFM_OK;
+}
+
 extern "C" int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv,
                                  int B, int T, int H, int hd, int ldqkv, int ldo, int koff, int voff, float p_drop,
                                  unsigned int seed, int dtype, void* stream) {

@@ -128,9 +128,27 @@ class ComplexConformer(HipModule):
             [ConformerBlock(self.d_model, num_heads, d_ff, kernel_size, dropout) for _ in range(num_blocks)])
         self.output_proj = nn.Linear(self.d_model, 2 * self.n_freq)
 
+    def _train_forward(self, stft_real, stft_imag):
+        """train() mode (the mode the reference's tests/test_conformer.py runs in): HIP autograd nodes throughout —
+        Linear(2F -> d) -> N x ConformerBlock (dropout, BatchNorm batch statistics) -> + skip -> Linear(d -> 2F)."""
+        from .. import train, ops
+        B, T, F = stft_real.shape
+        M = B * T
+        x = torch.cat([stft_real.float(), stft_imag.float()], dim=-1).reshape(M, 2 * F)
+        x = train.LNLinearFunction.apply(x, None, None, self.input_proj.weight, self.input_proj.bias)
+        skip = x
+        h = x.reshape(B, T, -1)
+        for block in self.blocks:
+            h = block(h)
+        x = h.reshape(M, -1) + skip
+        y = train.LNLinearFunction.apply(x, None, None, self.output_proj.weight, self.output_proj.bias)
+        y = y.reshape(B, T, 2 * F)
+        return y[..., :F], y[..., F:]
+
     def forward(self, stft_real, stft_imag):
         self._require_device(stft_real, stft_imag)
-        self._require_inference()
+        if self.training:
+            return self._train_forward(stft_real, stft_imag)
         pk = self._packed(lambda sd: Fn.pack_complex_conformer(sd, self.num_blocks, self.num_heads))
         return Fn.complex_conformer_forward(stft_real.float(), stft_imag.float(), pk, self.num_heads)
 
@@ -138,6 +156,9 @@ class ComplexConformer(HipModule):
         """models/conformer.py:230-245 complex multiply."""
         self._require_device(stft_real, stft_imag, mask_real, mask_imag)
         from .. import ops
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (stft_real, stft_imag, mask_real, mask_imag)):
+            from .. import train
+            return train.ComplexMulFunction.apply(stft_real, stft_imag, mask_real, mask_imag)
         shp = stft_real.shape
         er, ei = ops.complex_mul(stft_real.float().contiguous(), stft_imag.float().contiguous(),
                                  mask_real.float().contiguous(), mask_imag.float().contiguous())

@@ -566,6 +566,13 @@ def attention_bwd(qkv16, O16, dO16, lse, B, T, H, hd, p_drop=0.0, seed=0):
     L = _lib.load()
     D = H * hd
     dqkv = torch.empty_like(qkv16)
+    if hd != 64:                                   # small-shape path (e.g. the reference's test config: 4 heads x 16)
+        scratch = torch.zeros(B * T, 2 * D, device=qkv16.device, dtype=torch.float32)
+        _call("attention_bwd", L.sfm_attention_bwd_generic, (_p(qkv16), _p(O16), _p(dO16), _p(lse), _p(scratch), _p(dqkv), B, T, H,
+                                                             hd, qkv16.stride(0), O16.stride(0), D, 2 * D, float(p_drop),
+                                                             int(seed) & 0xffffffff, _dt(), _stream()),
+              10.0 * B * H * T * T * hd, 8.0 * B * T * D * 2)
+        return dqkv
     delta = torch.empty(B, H, T, device=qkv16.device, dtype=torch.float32)
     _call("attention_bwd", L.sfm_attention_bwd, (_p(qkv16), _p(O16), _p(dO16), _p(lse), _p(delta), _p(dqkv), B, T, H, hd,
                                                  qkv16.stride(0), O16.stride(0), D, 2 * D, float(p_drop), int(seed) & 0xffffffff,

@@ -259,7 +259,8 @@ class ConformerBlockFunction(torch.autograd.Function):
 # training/conformer_pipeline.py:273-284)
 # ---------------------------------------------------------------------------
 class LNLinearFunction(torch.autograd.Function):
-    """y[M, N] = LayerNorm(x[:, :K]) @ W^T + b, fp32 in / fp32 out, GEMMs on 16-bit operands."""
+    """y[M, N] = LayerNorm(x[:, :K]) @ W^T + b, fp32 in / fp32 out, GEMMs on 16-bit operands.
+    ln_w = ln_b = None: plain Linear (input_proj / output_proj of ComplexConformer, models/conformer.py:211,222)."""
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, W, b):
@@ -268,19 +269,23 @@ class LNLinearFunction(torch.autograd.Function):
         x32 = x.detach().float()
         if x32.stride(1) != 1:
             x32 = x32.contiguous()
-        lw, lb, w32 = _f32(ln_w), _f32(ln_b), _f32(W)
+        has_ln = ln_w is not None
+        lw, lb, w32 = (_f32(ln_w), _f32(ln_b), _f32(W)) if has_ln else (None, None, _f32(W))
         Kp = ops.round_up(K, 64)
         fwd = ops.pack_linear(w32, _f32(b), k_pad_to=Kp)
         h16 = torch.zeros(M, Kp, device=x.device, dtype=ops.compute_dtype()) if Kp != K else \
             torch.empty(M, K, device=x.device, dtype=ops.compute_dtype())
-        ops.layernorm(x32, lw, lb, out16=h16)
+        if has_ln:
+            ops.layernorm(x32, lw, lb, out16=h16)
+        else:
+            ops.convert_rows(x32, h16, M, K, Kp, x32.stride(0), Kp)
         Np = ops.round_up(N, 8)
         ybuf = torch.empty(M, Np, device=x.device, dtype=torch.float32)
         y = ybuf[:, :N]
         ops.linear16(h16, fwd, out=y)
         ctx.saved = (x32, lw, w32, h16)
         ctx.dims = (M, N, K)
-        ctx.dtypes = (x.dtype, ln_w.dtype, ln_b.dtype, W.dtype, b.dtype)
+        ctx.dtypes = (x.dtype, ln_w.dtype if has_ln else None, ln_b.dtype if has_ln else None, W.dtype, b.dtype)
         return y
 
     @staticmethod
@@ -300,11 +305,13 @@ class LNLinearFunction(torch.autograd.Function):
         ops.colsum(dy16[:, :N], db)
         bwd = ops.pack_linear(w32.t().contiguous(), k_pad_to=Np)
         dh = ops.linear16(dy16, bwd, out_dtype=torch.float32)                  # [M, K]
+        t = ctx.dtypes
+        ctx.saved = None
+        if lw is None:
+            return dh.to(t[0]), None, None, dW.to(t[3]), db.to(t[4])
         dg = torch.zeros(K, device=dev, dtype=torch.float32)
         dbt = torch.zeros(K, device=dev, dtype=torch.float32)
         dx = ops.layernorm_bwd(x32, lw, dh, None, dg, dbt)
-        t = ctx.dtypes
-        ctx.saved = None
         return dx.to(t[0]), dg.to(t[1]), dbt.to(t[2]), dW.to(t[3]), db.to(t[4])
 
 
@@ -445,3 +452,27 @@ class EnhancerLossFunction(torch.autograd.Function):
         ctx.grads = None
         s = g_total.float()
         return (d_er * s).to(ctx.dtypes[0]), (d_ei * s).to(ctx.dtypes[1]), None, None, None, None, None, None
+
+
+class ComplexMulFunction(torch.autograd.Function):
+    """ComplexConformer.apply_mask (models/conformer.py:230-245) with its backward: the gradient of a complex product
+    is the incoming gradient times the conjugate of the other factor — the same HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, sr, si, mr, mi):
+        a = [t.detach().float().contiguous() for t in (sr, si, mr, mi)]
+        ctx.saved = a
+        ctx.dtypes = [t.dtype for t in (sr, si, mr, mi)]
+        er, ei = ops.complex_mul(*a)
+        return er.reshape(sr.shape), ei.reshape(sr.shape)
+
+    @staticmethod
+    def backward(ctx, ger, gei):
+        sr, si, mr, mi = ctx.saved
+        ger, gei = ger.float().contiguous(), gei.float().contiguous()
+        dsr, dsi = ops.complex_mul(ger, gei, mr, -mi)
+        dmr, dmi = ops.complex_mul(ger, gei, sr, -si)
+        t = ctx.dtypes
+        ctx.saved = None
+        return (dsr.reshape(sr.shape).to(t[0]), dsi.reshape(sr.shape).to(t[1]), dmr.reshape(sr.shape).to(t[2]),
+                dmi.reshape(sr.shape).to(t[3]))
