@@ -205,7 +205,10 @@ int sfm_col_stats(const float* y, const float* aux, const float* mean, const flo
 int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float* S, float* dy, int M, int C, int g_f32, int pass, int dtype,
                      void* stream);
-int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, int B, int T, int C, int KS,
+/* depthwise-conv weight/bias gradient: per-(utterance, span) partial sums go to `scratch`
+ * (sfm_dwconv_wgrad_scratch_floats floats, need not be zeroed) and are reduced into dw [C, KS] / db [C] (accumulated). */
+long long sfm_dwconv_wgrad_scratch_floats(int B, int T, int C, int KS);
+int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, float* scratch, int B, int T, int C, int KS,
                      int dtype, void* stream);
 /* attention forward for training (writes log2-domain LSE [B,H,T], applies attention dropout) and its backward */
 int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,

@@ -403,8 +403,7 @@ extern "C" int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean
 // ---------------------------------------------------------------------------
 template <class T, int KS>
 __global__ __launch_bounds__(128) void dwconv_wgrad_kernel(const u16* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dw, float* __restrict__ db, int Tlen,
-                                                           int C, int span) {
+                                                           float* __restrict__ part, int Tlen, int C, int span) {
   // two adjacent channels per thread (one 4-byte load of x, one 8-byte load of dy per frame); the KS-frame window of x
   // lives in registers and is indexed with compile-time (j + k) % KS, so sliding it costs no moves
   const int c = (blockIdx.x * 128 + threadIdx.x) * 2;
@@ -432,16 +431,27 @@ __global__ __launch_bounds__(128) void dwconv_wgrad_kernel(const u16* __restrict
     load_x(t0 + k - pad, w0[k], w1[k]);
   }
   float sb0 = 0.f, sb1 = 0.f;
+  auto load_g = [&](int t, float& a, float& bb) {
+    a = 0.f;
+    bb = 0.f;
+    if (t < t1) {
+      const f32x2 g = *reinterpret_cast<const f32x2*>(gb + (long long)t * C);
+      a = g[0];
+      bb = g[1];
+    }
+  };
+  // software pipeline of depth 1: the loads of frame t+1 are issued before the 2 x KS FMAs of frame t; the
+  // sched_barrier keeps the scheduler from hoisting a whole chunk's loads (that spilled the register window)
+  float gn0, gn1, xn0, xn1;
+  load_g(t0, gn0, gn1);
+  load_x(t0 + pad + 1, xn0, xn1);
   for (int tb = t0; tb < t1; tb += KS) {
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int t = tb + j;
-      float g0 = 0.f, g1 = 0.f;
-      if (t < t1) {
-        const f32x2 g = *reinterpret_cast<const f32x2*>(gb + (long long)t * C);
-        g0 = g[0];
-        g1 = g[1];
-      }
+      const float g0 = gn0, g1 = gn1, xa = xn0, xb = xn1;
+      load_g(t + 1, gn0, gn1);
+      load_x(t + pad + 2, xn0, xn1);
       sb0 += g0;
       sb1 += g1;
 #pragma unroll
@@ -449,31 +459,61 @@ __global__ __launch_bounds__(128) void dwconv_wgrad_kernel(const u16* __restrict
         acc0[k] += g0 * w0[(j + k) % KS];
         acc1[k] += g1 * w1[(j + k) % KS];
       }
-      load_x(t + pad + 1, w0[j], w1[j]);                     // slot j held x[t - pad]: no longer needed
+      w0[j] = xa;                                            // slot j held x[t - pad]: no longer needed
+      w1[j] = xb;
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // partial sums of this (utterance, span): every workgroup adding into the same C*KS addresses serialises the
+  // memory-side atomics (MI355X_MICROARCH.md, "Global float atomics": one row shared by all = 14x slower), so the
+  // partials go to a scratch [nparts][KS + 1][C] (coalesced over channels) and dwconv_wgrad_reduce sums them
+  float* pp = part + ((long long)(blockIdx.z * gridDim.y + blockIdx.y) * (KS + 1)) * C + c;
 #pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    atomicAdd(&dw[c * KS + k], acc0[k]);
-    atomicAdd(&dw[(c + 1) * KS + k], acc1[k]);
-  }
-  atomicAdd(&db[c], sb0);
-  atomicAdd(&db[c + 1], sb1);
+  for (int k = 0; k < KS; ++k) *reinterpret_cast<f32x2*>(pp + (long long)k * C) = f32x2{acc0[k], acc1[k]};
+  *reinterpret_cast<f32x2*>(pp + (long long)KS * C) = f32x2{sb0, sb1};
 }
 
-extern "C" int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, int B, int T, int C, int KS,
-                                int dtype, void* stream) {
-  if (!x || !dy || !dw || !db) return SFM_ERR_ARG;
-  if (B <= 0 || T <= 0 || C <= 0 || (C & 1) || (KS != 31 && KS != 7)) return SFM_ERR_SHAPE;
-  int nspan = (2048 + B - 1) / B;                              // enough workgroups to fill the chip, few atomics
-  if (nspan > (T + 63) / 64) nspan = (T + 63) / 64;
+// dw[c][k] += sum_parts part[p][k][c] ; db[c] += sum_parts part[p][KS][c]
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                  float* __restrict__ db, int nparts, int C, int KS,
+                                                                  int parts_per_block) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                 // e = k * C + c
+  if (e >= (KS + 1) * C) return;
+  const int p0 = blockIdx.y * parts_per_block, p1 = min(nparts, p0 + parts_per_block);
+  float s = 0.f;
+  for (int p = p0; p < p1; ++p) s += part[(long long)p * (KS + 1) * C + e];
+  const int k = e / C, c = e - k * C;
+  if (k < KS) atomicAdd(&dw[c * KS + k], s);
+  else atomicAdd(&db[c], s);
+}
+
+extern "C" long long sfm_dwconv_wgrad_scratch_floats(int B, int T, int C, int KS) {
+  int nspan = (2048 + B - 1) / B;
+  if (nspan > (T + 31) / 32) nspan = (T + 31) / 32;
   if (nspan < 1) nspan = 1;
   const int span = (T + nspan - 1) / nspan;
-  dim3 grid((C + 255) / 256, (T + span - 1) / span, B), block(128);
+  const long long parts = (long long)B * ((T + span - 1) / span);
+  return parts * (KS + 1) * C;
+}
+
+extern "C" int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float* db, float* scratch, int B, int T, int C,
+                                int KS, int dtype, void* stream) {
+  if (!x || !dy || !dw || !db || !scratch) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || C <= 0 || (C & 1) || (KS != 31 && KS != 7)) return SFM_ERR_SHAPE;
+  int nspan = (2048 + B - 1) / B;                              // enough workgroups to fill the chip
+  if (nspan > (T + 31) / 32) nspan = (T + 31) / 32;
+  if (nspan < 1) nspan = 1;
+  const int span = (T + nspan - 1) / nspan;
+  const int ny = (T + span - 1) / span;
+  dim3 grid((C + 255) / 256, ny, B), block(128);
   hipStream_t st = (hipStream_t)stream;
-#define GO(TT, KK) SFM_LAUNCH((dwconv_wgrad_kernel<TT, KK>), grid, block, 0, st, (const u16*)x, dy, dw, db, T, C, span)
+#define GO(TT, KK) SFM_LAUNCH((dwconv_wgrad_kernel<TT, KK>), grid, block, 0, st, (const u16*)x, dy, scratch, T, C, span)
   if (dtype == SFM_DT_F16) { if (KS == 31) GO(F16, 31); else GO(F16, 7); }
   else { if (KS == 31) GO(BF16, 31); else GO(BF16, 7); }
 #undef GO
+  const int nparts = B * ny;
+  const int ppb = 64;
+  dim3 g2(((KS + 1) * C + 255) / 256, (nparts + ppb - 1) / ppb);
+  SFM_LAUNCH(dwconv_wgrad_reduce_kernel, g2, dim3(256), 0, st, scratch, dw, db, nparts, C, KS, ppb);
   return SFM_OK;
 }

@@ -68,7 +68,8 @@ SIGNATURES = {
     "sfm_ew_train": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_uint, c_i, c_vp],
     "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "sfm_bn_swish_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "sfm_dwconv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_dwconv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_dwconv_wgrad_scratch_floats": [c_i, c_i, c_i, c_i],
     "sfm_attention_fwd_train": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_f,
                                 ctypes.c_uint, c_i, c_vp],
     "sfm_attention_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
@@ -100,7 +101,7 @@ def load():
         except AttributeError as e:
             raise HipExtensionMissing("symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.argtypes = args
-        fn.restype = c_i
+        fn.restype = c_ll if name.endswith("_scratch_floats") else c_i
     _lib = lib
     return lib
 

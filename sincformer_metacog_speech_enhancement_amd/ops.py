@@ -545,7 +545,8 @@ def dwconv_wgrad(x16, dy32, B, T, C, KS):
     L = _lib.load()
     dw = torch.zeros(C, KS, device=x16.device, dtype=torch.float32)
     db = torch.zeros(C, device=x16.device, dtype=torch.float32)
-    _call("dwconv_wgrad", L.sfm_dwconv_wgrad, (_p(x16), _p(dy32), _p(dw), _p(db), B, T, C, KS, _dt(), _stream()))
+    scratch = torch.empty(int(L.sfm_dwconv_wgrad_scratch_floats(B, T, C, KS)), device=x16.device, dtype=torch.float32)
+    _call("dwconv_wgrad", L.sfm_dwconv_wgrad, (_p(x16), _p(dy32), _p(dw), _p(db), _p(scratch), B, T, C, KS, _dt(), _stream()))
     return dw, db
 
 

@@ -169,10 +169,11 @@ def _keep_mask(seed, B, H, T, p):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,T,H,p", [(2, 200, 4, 0.0), (1, 64, 2, 0.0), (2, 129, 1, 0.0), (1, 150, 2, 0.15)])
-def test_attention_train_fwd_bwd(ops, dt, B, T, H, p):
+@pytest.mark.parametrize("B,T,H,p,hd", [(2, 200, 4, 0.0, 64), (1, 64, 2, 0.0, 64), (2, 129, 1, 0.0, 64), (1, 150, 2, 0.15, 64),
+                                        (2, 37, 4, 0.0, 16), (1, 50, 2, 0.2, 32)])       # hd != 64: generic kernels
+def test_attention_train_fwd_bwd(ops, dt, B, T, H, p, hd):
     ops.set_compute_dtype(dt)
-    hd, seed = 64, 77
+    seed = 77
     D = H * hd
     qkv = arr("aq", (B * T, 3 * D), 40 + T, 1.0)
     qkv[:, :D] *= 0.35                       # q' ~ pre-scaled magnitude

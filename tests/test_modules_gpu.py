@@ -280,3 +280,41 @@ def test_mrstft_sizes_vs_golden(pkg):
         r, i = pkg.Fn.stft(w, nf, hp, nf)
         mag = torch.sqrt(r ** 2 + i ** 2).transpose(1, 2)
         assert maxerr(mag.cpu(), g["mag%d" % nf]) < 2e-4
+
+
+# ---------------------------------------------------------------------------
+# edge shapes of the whole path against the (golden-pinned) oracle: single utterance, odd batch, sample counts that are
+# multiples of neither the hop (80) nor the encoder stride (16), the shortest signal the reflect padding admits
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("B,L", [(1, 1237), (3, 4001), (1, 400), (5, 2000)])
+def test_end_to_end_path_ragged_shapes_vs_oracle(pkg, B, L):
+    dt = torch.float16
+    pkg.ops.set_compute_dtype(dt)
+    sds = {"pa": synth_sd("PerceptionAgent", 191, sinc_scale=2000.0),
+           "cpea": synth_sd("CorrelationPhaseEstimationAgent", 192),
+           "msa": synth_sd("MaskSynthesisAgent", 193),
+           "memory": synth_sd("EpisodicMemory", 194)}
+    path = pkg.cp.EnhancementPath(sample_rate=16000, use_memory=True)
+    path.perception.load_state_dict(sds["pa"])
+    path.cpea.load_state_dict(sds["cpea"])
+    path.msa.load_state_dict(sds["msa"])
+    path.memory.load_state_dict(sds["memory"])
+    path = path.cuda().eval()
+    noisy, _ = syn.synth_wave(B, L, 195 + L)
+    ref = orc.enhance_path(sds, noisy, 16000, use_memory=True)
+    out = path(torch.from_numpy(noisy).cuda())
+    T = 1 + L // 80
+    assert tuple(out["mask_real"].shape) == (B, T, 129) and tuple(out["enhanced"].shape) == (B, L)
+    got = torch.cat([out["mask_real"], out["mask_imag"]], dim=-1)
+    want = torch.cat([ref["mask_real"], ref["mask_imag"]], dim=-1)
+    r, _ = show("ragged path B%d L%d mask" % (B, L), got, want)
+    _, rlw = show("ragged path B%d L%d wave" % (B, L), out["enhanced"], ref["enhanced"])
+    assert r <= HARD_BOUND[dt], "mask RMSE %.3e" % r
+    assert rlw < 3e-3
+
+
+def test_path_rejects_signals_shorter_than_the_reflect_padding(pkg):
+    """torch.stft(center=True) raises for L <= n_fft/2 (reflect padding); so does the HIP STFT"""
+    path = pkg.cp.EnhancementPath(sample_rate=16000).cuda().eval()
+    with pytest.raises(RuntimeError):
+        path(torch.zeros(1, 100, device="cuda"))
