@@ -155,6 +155,13 @@ int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb, const void
 int sfm_sinc_fir16_tiles(int L);
 int sfm_sinc_fir16(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B,
                    int L, int C, int K, int out_f32, int dtype, void* stream);
+/* The same frames-x-matrix product on the 16-bit matrix cores with split bf16 operands (hi + lo, 3 MFMAs per k-step,
+ * ~4e-6 relative error): the STFTs of the training objective (training/conformer_pipeline.py:74-108) and their adjoints.
+ * Whi / Wlo: the constant matrix pre-split and n-major, [Npad (x256)][Kpad (x32)] uint16; out fp32 [b][m][n] with row
+ * stride ldm; columns >= nsplit go to out2 at column n - nsplit + col2_off (when out2 != NULL). */
+int sfm_framed_gemm_split16(const float* sig, const void* Whi, const void* Wlo, float* out, float* out2, int B, int M,
+                            int Ls, long long sig_batch_stride, int hop, int padl, int K, int Kpad, int N, int Npad,
+                            int nsplit, int col2_off, long long o_batch_stride, long long ldm, int mode, void* stream);
 /* Forward of the training objective (training/conformer_pipeline.py:52-108, 539-572): reductions in fp64.
  * S buffers must be zero-filled by the caller (kernels accumulate with f64 atomics). */
 int sfm_wave_moments(const float* est, const float* tgt, double* S, int B, int L, void* stream);

@@ -50,6 +50,8 @@ SIGNATURES = {
     "sfm_ffn_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_i, c_vp],
     "sfm_sinc_fir16_tiles": [c_i],
     "sfm_sinc_fir16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_framed_gemm_split16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll,
+                                c_ll, c_i, c_vp],
     "sfm_wave_moments": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "sfm_spec_sums": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
     "sfm_enhancer_loss_finalize": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_ll, c_i, c_vp, c_vp],

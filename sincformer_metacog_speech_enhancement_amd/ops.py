@@ -254,6 +254,30 @@ def framed_gemm(sig, Wt, out, *, B, M, Ls, sig_batch_stride, hop, padl, K, N, o_
     return out
 
 
+def pack_split16_matrix(wt_kn):
+    """[K, N] fp32 -> (hi, lo) bf16 pair, n-major [round256(N), round32(K)], operand of framed_gemm_split16."""
+    K, N = wt_kn.shape
+    w = torch.zeros(round_up(N, 256), round_up(K, 32), device=wt_kn.device, dtype=torch.float32)
+    w[:N, :K] = wt_kn.t()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous(), K, N
+
+
+def framed_gemm_split16(sig, W, out, *, B, M, Ls, sig_batch_stride, hop, padl, o_batch_stride, ldm, mode=0, out2=None, nsplit=0,
+                        col2_off=0):
+    """W = pack_split16_matrix(...)"""
+    _need_dev(sig, out)
+    L = _lib.load()
+    hi, lo, K, N = W
+    Npad, Kpad = hi.shape
+    _call("framed_gemm_split16", L.sfm_framed_gemm_split16, (_p(sig), _p(hi), _p(lo), _p(out), _p(out2), B, M, Ls, sig_batch_stride,
+                                                             hop, padl, K, Kpad, N, Npad, nsplit, col2_off, o_batch_stride, ldm,
+                                                             mode, _stream()),
+          2.0 * B * M * K * N, 4.0 * (B * M * hop + B * M * N))
+    return out
+
+
 def pack_f32_matrix(wt_kn):
     """[K, N] fp32 -> zero padded [round32(K), round64(N)] operand of framed_gemm."""
     K, N = wt_kn.shape

@@ -440,3 +440,17 @@ def test_dwconv_folded(ops, dt, C, KS, T):
     h = F.conv1d(q16(x, dt).transpose(1, 2), w, b, padding=(KS - 1) // 2, groups=C)
     ref = orc.swish(orc.batch_norm_eval(h, bw, bb, rm, rv)).transpose(1, 2)
     report("dwconv folded C%d k%d T%d" % (C, KS, T), out.float().cpu(), ref, 8 * EPS[dt])
+
+
+@pytest.mark.parametrize("n_fft,hop,win,L", [(256, 64, 256, 4000), (512, 128, 512, 4321), (1024, 256, 1024, 9000),
+                                             (256, 80, 160, 1637)])
+def test_stft_split16_vs_oracle(ops, n_fft, hop, win, L):
+    """STFT on the 16-bit matrix cores with split bf16 operands (the objective's STFTs): error budget 2e-5 of the rms"""
+    from sincformer_metacog_speech_enhancement_amd import functional as Fn
+    w = arr("sw", (3, L), 300 + L, 0.2)
+    rr, ri = orc.stft(w, n_fft, hop, win)
+    gr, gi = Fn.stft_split16(dev(w), n_fft, hop, win)
+    rms = float(torch.cat([rr, ri], -1).pow(2).mean().sqrt())
+    report("stft split16 re n%d" % n_fft, gr.cpu(), rr, 2e-5 * rms * 8)
+    report("stft split16 im n%d" % n_fft, gi.cpu(), ri, 2e-5 * rms * 8)
+    assert rmse(torch.cat([gr, gi], -1).cpu(), torch.cat([rr, ri], -1)) < 2e-5 * rms
