@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const u16* __restrict_
     scol[i] = (c & 7) * 8;
   }
   const int ntiles = (Tlen + 63) / 64;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
+  u32x4 rk[2], rv[2];                                 // next key tile, global -> registers under the current tile's math
+  auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = kt * 64 + srow[i];
@@ -116,11 +116,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const u16* __restrict_
         a = *reinterpret_cast<const u32x4*>(rp + koff);
         c = *reinterpret_cast<const u32x4*>(rp + voff);
       }
-      *reinterpret_cast<u32x4*>(&Kr[srow[i] * RS_ROW + scol[i]]) = a;
-      *reinterpret_cast<u32x4*>(&Kt[srow[i] * TS_ROW + scol[i]]) = a;
-      *reinterpret_cast<u32x4*>(&Vr[srow[i] * RS_ROW + scol[i]]) = c;
+      rk[i] = a;
+      rv[i] = c;
+    }
+  };
+  load_tile(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(&Kr[srow[i] * RS_ROW + scol[i]]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Kt[srow[i] * TS_ROW + scol[i]]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Vr[srow[i] * RS_ROW + scol[i]]) = rv[i];
     }
     __syncthreads();
+    if (kt + 1 < ntiles) load_tile(kt + 1);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -183,8 +193,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const u16* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const u16* __restrict__ qkv, const u16* __restrict__ dO,
+template <class T, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restrict__ qkv, const u16* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            u16* __restrict__ dqkv, int Tlen, int H, int ldqkv, int ldo,
                                                            int koff, int voff, int nkt, float p_drop, uint32_t seed) {
@@ -230,8 +240,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const u16* __restrict
   }
   const long long bh = (long long)b * H + h;
   const int nqtiles = (Tlen + 63) / 64;
-  for (int qt = 0; qt < nqtiles; ++qt) {
-    __syncthreads();
+  u32x4 rq[2], rd[2];                                 // next query tile, global -> registers under the current tile's math
+  float rl = 1e30f, rdl = 0.f;
+  auto load_tile = [&](int qt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = qt * 64 + srow[i];
@@ -240,54 +251,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const u16* __restrict
         a = *reinterpret_cast<const u32x4*>(base + (long long)q * ldqkv + scol[i]);
         c = *reinterpret_cast<const u32x4*>(dO + ((long long)b * Tlen + q) * ldo + h * 64 + scol[i]);
       }
-      *reinterpret_cast<u32x4*>(&Qr[srow[i] * RS_ROW + scol[i]]) = a;
-      *reinterpret_cast<u32x4*>(&Qt[srow[i] * TS_ROW + scol[i]]) = a;
-      *reinterpret_cast<u32x4*>(&Dr[srow[i] * RS_ROW + scol[i]]) = c;
-      *reinterpret_cast<u32x4*>(&Dt[srow[i] * TS_ROW + scol[i]]) = c;
+      rq[i] = a;
+      rd[i] = c;
     }
     if (tid < 64) {
       const int q = qt * 64 + tid;
-      sl[tid] = (q < Tlen) ? lse[bh * Tlen + q] : 1e30f;        // rows past T get P = 0
-      sd[tid] = (q < Tlen) ? delta[bh * Tlen + q] : 0.f;
+      rl = (q < Tlen) ? lse[bh * Tlen + q] : 1e30f;             // rows past T get P = 0
+      rdl = (q < Tlen) ? delta[bh * Tlen + q] : 0.f;
+    }
+  };
+  load_tile(0);
+  for (int qt = 0; qt < nqtiles; ++qt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(&Qr[srow[i] * RS_ROW + scol[i]]) = rq[i];
+      *reinterpret_cast<u32x4*>(&Qt[srow[i] * TS_ROW + scol[i]]) = rq[i];
+      *reinterpret_cast<u32x4*>(&Dr[srow[i] * RS_ROW + scol[i]]) = rd[i];
+      *reinterpret_cast<u32x4*>(&Dt[srow[i] * TS_ROW + scol[i]]) = rd[i];
+    }
+    if (tid < 64) {
+      sl[tid] = rl;
+      sd[tid] = rdl;
     }
     __syncthreads();
+    if (qt + 1 < nqtiles) load_tile(qt + 1);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 s[2], dp[2];
+    // one 32-query sub-tile at a time: S, dP (32 accumulator registers live instead of 64)
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-      s[qi] = zero;
-      dp[qi] = zero;
+      f32x16 s = zero, dp = zero;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const u32x4 qfr = *reinterpret_cast<const u32x4*>(&Qr[(qi * 32 + l31) * RS_ROW + ks * 16 + hl * 8]);
         const u32x4 dfr = *reinterpret_cast<const u32x4*>(&Dr[(qi * 32 + l31) * RS_ROW + ks * 16 + hl * 8]);
-        s[qi] = T::mfma(qfr, kf[ks], s[qi]);
-        dp[qi] = T::mfma(dfr, vf[ks], dp[qi]);
+        s = T::mfma(qfr, kf[ks], s);
+        dp = T::mfma(dfr, vf[ks], dp);
       }
-    }
-    // rows = queries (registers), column = this lane's key
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+      // rows = queries (registers), column = this lane's key
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = qi * 32 + mfma_row(r, lane);
-        const int q = qt * 64 + ql;
-        const float pv = __builtin_amdgcn_exp2f(s[qi][r] - sl[ql]);
+        const float pv = __builtin_amdgcn_exp2f(s[r] - sl[ql]);
         float keep = 1.0f;
-        if (p_drop > 0.f) keep = attn_keep(seed, (unsigned long long)(bh * Tlen + (q < Tlen ? q : 0)) * Tlen + key, p_drop, inv_keep);
-        const float dsv = 0.69314718056f * pv * (dp[qi][r] * keep - sd[ql]);
-        s[qi][r] = pv * keep;              // P~ (dropped, rescaled) for dV
-        dp[qi][r] = dsv;                   // dS2 for dK
+        if (DROP) {
+          const int q = qt * 64 + ql;
+          keep = attn_keep(seed, (unsigned long long)(bh * Tlen + (q < Tlen ? q : 0)) * Tlen + key, p_drop, inv_keep);
+        }
+        const float dsv = 0.69314718056f * pv * (dp[r] * keep - sd[ql]);
+        s[r] = pv * keep;                // P~ (dropped, rescaled) for dV
+        dp[r] = dsv;                     // dS2 for dK
       }
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         u32x4 pf, df;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          pf[e] = pack2<T>(s[qi][8 * s2 + 2 * e], s[qi][8 * s2 + 2 * e + 1]);
-          df[e] = pack2<T>(dp[qi][8 * s2 + 2 * e], dp[qi][8 * s2 + 2 * e + 1]);
+          pf[e] = pack2<T>(s[8 * s2 + 2 * e], s[8 * s2 + 2 * e + 1]);
+          df[e] = pack2<T>(dp[8 * s2 + 2 * e], dp[8 * s2 + 2 * e + 1]);
         }
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
@@ -295,6 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const u16* __restrict
           dk[dj] = T::mfma(tr_frag(Qt, qi * 32 + s2 * 16, dj * 32, lane), df, dk[dj]);
         }
       }
+    }
   }
   // dK^T, dV^T -> LDS transpose -> rows
   __syncthreads();
@@ -444,14 +466,22 @@ extern "C" int sfm_attention_bwd(const void* qkv, const void* O, const void* dO,
     SFM_LAUNCH((attn_delta_kernel<F16>), g1, blk, 0, st, (const u16*)dO, (const u16*)O, delta, T, H, ldo, total);
     SFM_LAUNCH((attn_bwd_dq_kernel<F16>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv, T, H, ldqkv,
                ldo, koff, voff, nq, p_drop, seed);
-    SFM_LAUNCH((attn_bwd_dkv_kernel<F16>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv, T, H,
-               ldqkv, ldo, koff, voff, nq, p_drop, seed);
+    if (p_drop > 0.f)
+      SFM_LAUNCH((attn_bwd_dkv_kernel<F16, true>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv, T,
+                 H, ldqkv, ldo, koff, voff, nq, p_drop, seed);
+    else
+      SFM_LAUNCH((attn_bwd_dkv_kernel<F16, false>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv,
+                 T, H, ldqkv, ldo, koff, voff, nq, p_drop, seed);
   } else {
     SFM_LAUNCH((attn_delta_kernel<BF16>), g1, blk, 0, st, (const u16*)dO, (const u16*)O, delta, T, H, ldo, total);
     SFM_LAUNCH((attn_bwd_dq_kernel<BF16>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv, T, H,
                ldqkv, ldo, koff, voff, nq, p_drop, seed);
-    SFM_LAUNCH((attn_bwd_dkv_kernel<BF16>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv, T, H,
-               ldqkv, ldo, koff, voff, nq, p_drop, seed);
+    if (p_drop > 0.f)
+      SFM_LAUNCH((attn_bwd_dkv_kernel<BF16, true>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv, T,
+                 H, ldqkv, ldo, koff, voff, nq, p_drop, seed);
+    else
+      SFM_LAUNCH((attn_bwd_dkv_kernel<BF16, false>), g2, blk, 0, st, (const u16*)qkv, (const u16*)dO, lse, delta, (u16*)dqkv,
+                 T, H, ldqkv, ldo, koff, voff, nq, p_drop, seed);
   }
   return SFM_OK;
 }
