@@ -199,7 +199,7 @@ def main_train(args):
                          "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
                          "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]},
             "frames_per_s_per_gpu": frames / elapsed / world,
-            "final_loss": float(loss), "optimizer_state": st,
+            "final_loss": float(loss.detach()), "optimizer_state": st,
             "breakdown_ms_per_step": {k: round(v["ms_total"], 4) for k, v in
                                       sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
         }
