@@ -172,6 +172,8 @@ class ConformerPipeline:
             raise RuntimeError("ConformerPipeline (HIP build) needs an MI355X; there is no CPU fallback")
         self.device = torch.device(device or "cuda")
         self.model = None
+        self.use_graph = False        # True: enhance_signal replays one hipGraph per signal length (graph.GraphedForward)
+        self._graphed = None
 
     def load_model(self, path):
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
@@ -186,7 +188,16 @@ class ConformerPipeline:
             raise RuntimeError("No model loaded.")
         self.model.eval()
         x = torch.from_numpy(np.asarray(noisy_signal, dtype=np.float32)).unsqueeze(0).to(self.device)
+        if self.use_graph:
+            if self._graphed is None:
+                from ..graph import GraphedForward
+                self._graphed = GraphedForward(self._enhance_device)
+            y = self._graphed(x)
+        else:
+            y = self._enhance_device(x)
+        return y.squeeze(0).cpu().numpy()
+
+    def _enhance_device(self, x):
         nr, ni = batch_stft(x, self.fft_size, self.hop_size, self.frame_size)
         er, ei, _ = self.model(nr, ni)
-        y = batch_istft(er, ei, self.fft_size, self.hop_size, self.frame_size, length=len(noisy_signal))
-        return y.squeeze(0).cpu().numpy()
+        return batch_istft(er, ei, self.fft_size, self.hop_size, self.frame_size, length=x.shape[-1])

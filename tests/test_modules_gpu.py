@@ -318,3 +318,27 @@ def test_path_rejects_signals_shorter_than_the_reflect_padding(pkg):
     path = pkg.cp.EnhancementPath(sample_rate=16000).cuda().eval()
     with pytest.raises(RuntimeError):
         path(torch.zeros(1, 100, device="cuda"))
+
+
+def test_hipgraph_replay_equals_eager(pkg):
+    """graph.GraphedForward: the whole path captured into one hipGraph gives the eager result bit for bit, also after the
+    input changes (static input buffer) and for a second shape (second graph)."""
+    from sincformer_metacog_speech_enhancement_amd.graph import GraphedForward
+    pkg.ops.set_compute_dtype(torch.bfloat16)
+    path = pkg.cp.EnhancementPath(sample_rate=16000, use_memory=True)
+    path.perception.load_state_dict(synth_sd("PerceptionAgent", 191, sinc_scale=2000.0))
+    path.cpea.load_state_dict(synth_sd("CorrelationPhaseEstimationAgent", 192))
+    path.msa.load_state_dict(synth_sd("MaskSynthesisAgent", 193))
+    path.memory.load_state_dict(synth_sd("EpisodicMemory", 194))
+    path = path.cuda().eval()
+    graphed = GraphedForward(lambda w: path(w))
+    for seed, (B, L) in enumerate([(1, 16000), (1, 16000), (2, 4000)]):
+        noisy, _ = syn.synth_wave(B, L, 400 + seed)
+        w = torch.from_numpy(noisy).cuda()
+        with torch.no_grad():
+            eager = {k: v.clone() for k, v in path(w).items() if isinstance(v, torch.Tensor)}
+        out = graphed(w)
+        torch.cuda.synchronize()
+        for k in ("mask_real", "mask_imag", "enhanced"):
+            assert torch.equal(out[k], eager[k]), k
+    assert len(graphed._cache) == 2
