@@ -190,6 +190,14 @@ int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* nr, const 
 int sfm_attention_bwd_generic(const void* qkv, const void* O, const void* dO, const float* lse, float* dkv32, void* dqkv,
                               int B, int T, int H, int hd, int ldqkv, int ldo, int koff, int voff, float p_drop,
                               unsigned int seed, int dtype, void* stream);
+/* Batched quality metrics (evaluation/ssnr.py:26-92, fallback STOI evaluation/stoi.py:53-99).
+ * ssnr_frames: acc [B][2] fp64 (zero-filled) += { sum of clipped frame SNRs over non-silent frames, their count }.
+ * stoi_frames: spectra [B, nframes, F] of the raw signals, sc / se [B] fp64 = 1/(rms + 1e-10) of clean / enhanced,
+ *   acc [B] fp64 (zero-filled) += sum over frames of the clipped spectral correlation. */
+int sfm_ssnr_frames(const float* clean, const float* enh, double* acc, int B, int L, int frame, int hop, float upper,
+                    float lower, void* stream);
+int sfm_stoi_frames(const float* cr, const float* ci, const float* er, const float* ei, const double* sc, const double* se,
+                    double* acc, int B, int nframes, int F, void* stream);
 /* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
  * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
  * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */

@@ -548,3 +548,50 @@ def enhance_path(sds, wave, sample_rate, use_memory=False, num_heads=4):
     return {"mask_real": mr, "mask_imag": mi, "enh_real": er, "enh_imag": ei, "enhanced": wav,
             "z_real": zr, "z_imag": zi, "sigma": sigma, "noisy_real": nr, "noisy_imag": ni,
             "cpea": cpea, "memory": mem}
+
+
+# ----------------------------------------------------------------------------
+# Quality metrics right after the path: evaluation/ssnr.py:26-92, evaluation/stoi.py:53-99
+# (numpy float64, one utterance at a time, like the reference)
+# ----------------------------------------------------------------------------
+def ssnr(clean, enhanced, frame_size=FRAME_SIZE, hop_size=HOP_SIZE, upper_bound=35.0, lower_bound=-10.0):
+    n = min(len(clean), len(enhanced))
+    c = np.asarray(clean[:n], dtype=np.float64)
+    e = np.asarray(enhanced[:n], dtype=np.float64)
+    num_frames = (n - frame_size) // hop_size + 1
+    if num_frames < 1:
+        return 0.0
+    vals = []
+    for k in range(num_frames):
+        cf = c[k * hop_size:k * hop_size + frame_size]
+        ef = e[k * hop_size:k * hop_size + frame_size]
+        sp = float(np.sum(cf ** 2))
+        ep = float(np.sum((cf - ef) ** 2))
+        if sp < 1e-10:
+            continue
+        v = upper_bound if ep < 1e-10 else 10.0 * math.log10(sp / ep)
+        vals.append(min(max(v, lower_bound), upper_bound))
+    return float(np.mean(vals)) if vals else 0.0
+
+
+def stoi_simplified(clean, enhanced, fs):
+    n = min(len(clean), len(enhanced))
+    c = np.asarray(clean[:n], dtype=np.float64)
+    e = np.asarray(enhanced[:n], dtype=np.float64)
+    frame_len = int(0.0256 * fs)
+    hop = frame_len // 2
+    c = c / (np.sqrt(np.mean(c ** 2)) + 1e-10)
+    e = e / (np.sqrt(np.mean(e ** 2)) + 1e-10)
+    num_frames = (len(c) - frame_len) // hop + 1
+    if num_frames < 1:
+        return 0.0
+    w = np.hanning(frame_len)
+    corrs = []
+    for k in range(num_frames):
+        cs = np.abs(np.fft.rfft(c[k * hop:k * hop + frame_len] * w))
+        es = np.abs(np.fft.rfft(e[k * hop:k * hop + frame_len] * w))
+        ce = np.sqrt(np.sum(cs ** 2) + 1e-10)
+        en = es / (np.sqrt(np.sum(es ** 2)) + 1e-10) * ce
+        corr = np.sum(cs * en) / (np.sqrt(np.sum(cs ** 2) * np.sum(en ** 2)) + 1e-10)
+        corrs.append(min(max(corr, -1.0), 1.0))
+    return float(min(max(np.mean(corrs), 0.0), 1.0))

@@ -253,9 +253,27 @@ def main_train():
          **_pack_grads((k, p.grad) for k, p in se.named_parameters()))
 
 
+def main_metrics():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import metric_cases
+    from evaluation.ssnr import compute_ssnr, compute_ssnr_improvement
+    from evaluation.stoi import compute_stoi
+    out = {}
+    for name, fs, c, e in metric_cases():
+        out["ssnr." + name] = np.float64(compute_ssnr(c, e, fs))
+        out["stoi." + name] = np.float64(compute_stoi(c, e, fs))
+    name, fs, c, e = metric_cases()[0]
+    noisy, _ = syn.synth_wave(1, 8000, 120)
+    out["ssnr_improvement.pair0"] = np.float64(compute_ssnr_improvement(c, noisy[0], e, fs))
+    save("g12_metrics", **out)
+
+
 if __name__ == "__main__":
     if "--train-only" in sys.argv:
         main_train()
+    elif "--metrics-only" in sys.argv:
+        main_metrics()
     else:
         main()
         main_train()
+        main_metrics()

@@ -46,3 +46,19 @@ def rmse(a, b):
     a = torch.as_tensor(np.asarray(a)).double()
     b = torch.as_tensor(np.asarray(b)).double()
     return float(((a - b) ** 2).mean().sqrt())
+
+
+def metric_cases():
+    """(name, fs, clean, enhanced) pairs shared by the generator and the tests: plain noisy pairs at both sample rates,
+    a silent stretch (skipped frames), identical signals (upper bound), ragged length, shorter-than-a-frame."""
+    cases = []
+    for i, (fs, L) in enumerate(((8000, 8000), (16000, 12345), (8000, 3001))):
+        noisy, clean = syn.synth_wave(1, L, 120 + i)
+        cases.append(("pair%d" % i, fs, clean[0], (0.7 * noisy[0] + 0.3 * clean[0]).astype(np.float32)))
+    noisy, clean = syn.synth_wave(1, 6000, 125)
+    c = clean[0].copy()
+    c[2000:3500] = 0.0
+    cases.append(("silence", 8000, c, noisy[0]))
+    cases.append(("identical", 8000, clean[0], clean[0].copy()))
+    cases.append(("short", 8000, clean[0][:100], noisy[0][:100]))
+    return cases

@@ -208,3 +208,15 @@ def test_speech_enhancer_training_loss_and_gradients():
     # the objective has |.| and 1/|P| terms: fp32 summation-order differences move a few gradient entries by ~1e-3
     w = _check_packed_grads(g, ((k, v.grad) for k, v in ref_sd.items() if v.dtype.is_floating_point and v.requires_grad), 2e-2)
     print("worst relative gradient error vs the reference's autograd: %.2e" % w)
+
+
+def test_quality_metrics_ssnr_stoi():
+    """evaluation/ssnr.py and the fallback STOI of evaluation/stoi.py vs the reference's values"""
+    from helpers import metric_cases
+    g = gold("g12_metrics")
+    for name, fs, c, e in metric_cases():
+        assert abs(orc.ssnr(c, e) - float(g["ssnr." + name])) < 1e-9, name
+        assert abs(orc.stoi_simplified(c, e, fs) - float(g["stoi." + name])) < 1e-9, name
+    name, fs, c, e = metric_cases()[0]
+    noisy, _ = syn.synth_wave(1, 8000, 120)
+    assert abs((orc.ssnr(c, e) - orc.ssnr(c, noisy[0])) - float(g["ssnr_improvement.pair0"])) < 1e-9
