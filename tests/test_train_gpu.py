@@ -171,7 +171,7 @@ def _waves(B, L, seed):
 
 
 @pytest.mark.parametrize("split16", [False, True])
-@pytest.mark.parametrize("L", [4000, 4321])
+@pytest.mark.parametrize("L", [4000, 4321, 1600])
 def test_loss_backward_matches_autograd(L, split16, monkeypatch):
     """objective alone: gradient w.r.t. the enhanced spectrum (iSTFT + SI-SNR + L1 magnitude + MR-STFT adjoints), with
     the objective's STFTs on the exact fp32 matrix instruction and on split bf16 operands (the default)."""
@@ -408,3 +408,37 @@ def test_speech_enhancer_train_step_vs_reference_fixture(dt):
     print("  worst parameter-gradient error vs the reference's autograd: %s %.3e" % worst)
     assert worst[1] < tol_g, worst
     assert maxerr(m.blocks[0].conv.batch_norm.running_mean.cpu(), g["bn0_running_mean"]) < 3e-3
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_speech_enhancer_model_backward_fixed_cotangent(dt):
+    """SpeechEnhancer forward + backward alone (input LN/proj, 4 blocks, heads, polar mask) for a FIXED cotangent on the
+    enhanced spectrum: without the objective's ill-conditioned 1/|STFT bin| terms the whole backward chain can be held
+    to a tight tolerance against torch autograd of the oracle."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft
+    ops.set_compute_dtype(dt)
+    sd = synth_sd("SpeechEnhancer", 29)
+    m = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.0)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    noisy, _ = _waves(3, 2960, 84)
+    cot_r, cot_i = arr("mcr", (3, 38, 129), 85), arr("mci", (3, 38, 129), 86)
+    nr, ni = batch_stft(noisy.cuda(), 256, 80, 160)
+    er, ei, _ = m(nr, ni)
+    (er * cot_r.cuda() + ei * cot_i.cuda()).sum().backward()
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    onr, oni = orc.stft(noisy)
+    oer, oei, _ = orc.speech_enhancer_forward(ref_sd, onr, oni, 4, bn_train=True)
+    (oer * cot_r + oei * cot_i).sum().backward()
+    worst = ("", 0.0)
+    for k, p_ in m.named_parameters():
+        if k.endswith("depthwise.bias"):
+            continue
+        r = _rel(p_.grad.cpu(), ref_sd[k].grad)
+        if r > worst[1]:
+            worst = (k, r)
+    print("SpeechEnhancer model backward %s: enhanced-spectrum rmse %.3e, worst parameter-gradient rel rmse %s %.3e" %
+          (dt, rmse(er.detach().cpu(), oer.detach()), worst[0], worst[1]))
+    assert worst[1] < (5e-3 if dt is torch.float16 else 4e-2), worst
