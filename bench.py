@@ -65,8 +65,9 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(weights, L, batch=2, iters=3):
-    """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample."""
+def cpu_baseline(weights, L, batch=None, iters=4):
+    """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample (about 10 s of CPU work)."""
+    batch = batch or max(1, min(8, 512000 // L))
     import torch
     from oracle import sfm_oracle as orc
     from sincformer_metacog_speech_enhancement_amd import synthetic as syn
@@ -89,7 +90,7 @@ def cpu_baseline(weights, L, batch=2, iters=3):
                       % (batch, L, iters, cores)}
 
 
-def cpu_baseline_train(sd, L, iters=3, batch=8):
+def cpu_baseline_train(sd, L, iters=8, batch=8):
     """oracle forward + backward (torch autograd on the host cores) of the same training step, small batch."""
     import torch
     from oracle import sfm_oracle as orc
