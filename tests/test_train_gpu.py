@@ -442,3 +442,33 @@ def test_speech_enhancer_model_backward_fixed_cotangent(dt):
     print("SpeechEnhancer model backward %s: enhanced-spectrum rmse %.3e, worst parameter-gradient rel rmse %s %.3e" %
           (dt, rmse(er.detach().cpu(), oer.detach()), worst[0], worst[1]))
     assert worst[1] < (5e-3 if dt is torch.float16 else 4e-2), worst
+
+
+def test_speech_enhancer_fp16_with_torch_gradscaler():
+    """the reference's use_amp branch (training/conformer_pipeline.py:505-517): fp16 compute, torch.amp.GradScaler scaling
+    the loss, unscale_ + clip_grad_norm_ + scaler.step(torch AdamW) on the gradients the HIP backward produced."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
+    ops.set_compute_dtype(torch.float16)
+    torch.manual_seed(2)
+    m = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=2, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.1).cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14)
+    noisy, clean = _waves(4, 8000, 92)
+    noisy, clean = noisy.cuda(), clean.cuda()
+    nr, ni = batch_stft(noisy, 256, 80, 160)
+    cr, ci = batch_stft(clean, 256, 80, 160)
+    hist = []
+    for it in range(12):
+        opt.zero_grad(set_to_none=True)
+        with torch.amp.autocast("cuda"):
+            loss, neg_sisnr = compute_loss(m, nr, ni, clean, cr, ci)
+        assert bool(torch.isfinite(loss))
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        scaler.step(opt)
+        scaler.update()
+        hist.append(float(loss.detach()))
+    print("fp16 + GradScaler loss history", ["%.3f" % h for h in hist], "scale", scaler.get_scale())
+    assert hist[-1] < hist[0] - 0.2
