@@ -31,14 +31,18 @@ __device__ __forceinline__ float dpp_get(float v) {
 #define DPP_Q2 0xAA
 #define DPP_Q3 0xFF
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// 1 / (1 + 2^(-x log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp each), no division sequence on the per-step critical path
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
 
 template <int H>
 __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __restrict__ xg,
                                                              const float* __restrict__ whh,
                                                              float* __restrict__ out, int T) {
-  __shared__ __attribute__((aligned(16))) float hs[2][H];
   constexpr int KS = H / 8;                                  // k-slice length per lane
+  constexpr int SL = KS + 4;                                 // slice stride in LDS: slices ks and ks+4 on different banks
+  __shared__ __attribute__((aligned(16))) float hs[2][8 * SL];
   const int tid = threadIdx.x;
   const int j = tid >> 3, ks = tid & 7;
   const int dir = blockIdx.x, b = blockIdx.y;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < KS; ++i) w[g][i] = wr[i];
   }
-  if (tid < H) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; }
+  if (tid < 8 * SL) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; }
   __syncthreads();
   float c = 0.f;
   const int mygate = ks & 3;                                  // lanes 0-3 (and 4-7) carry gate i,f,g,o
@@ -58,11 +62,12 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
   int t = dir ? (T - 1) : 0;
   const int dt = dir ? -1 : 1;
   const float gsc = (mygate == 2) ? 2.0f : 1.0f, gof = (mygate == 2) ? -1.0f : 0.0f;
-  float xnext = (ks < 4) ? xb[(long long)t * (8 * H)] : 0.f;
+  const int hslot = (j / KS) * SL + (j % KS);                // where unit j's h lives
+  float xnext = xb[(long long)t * (8 * H)];                   // every lane loads the input projection of ITS gate
   for (int s = 0; s < T; ++s, t += dt) {
     const float xcur = xnext;
-    if (s + 1 < T && ks < 4) xnext = xb[(long long)(t + dt) * (8 * H)];
-    const float* hc = hs[s & 1] + ks * KS;
+    if (s + 1 < T) xnext = xb[(long long)(t + dt) * (8 * H)];
+    const float* hc = hs[s & 1] + ks * SL;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KS; i += 4) {
@@ -75,11 +80,6 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
         a[g] += w[g][i + 3] * hv[3];
       }
     }
-    // the input projection of gate `mygate` enters through lanes 0..3 (xcur = 0 on lanes 4..7)
-    a[0] += (mygate == 0) ? xcur : 0.f;
-    a[1] += (mygate == 1) ? xcur : 0.f;
-    a[2] += (mygate == 2) ? xcur : 0.f;
-    a[3] += (mygate == 3) ? xcur : 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       a[g] = dpp_add<DPP_XOR1>(a[g]);
@@ -87,17 +87,18 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
       a[g] = dpp_add<DPP_HALF_MIRROR>(a[g]);
     }
     // every lane now holds the 4 complete pre-activations of its unit; lane q of each quad activates gate q
-    const float pre = (mygate == 0) ? a[0] : (mygate == 1) ? a[1] : (mygate == 2) ? a[2] : a[3];
+    const float pre = ((mygate == 0) ? a[0] : (mygate == 1) ? a[1] : (mygate == 2) ? a[2] : a[3]) + xcur;
     const float act = gsc * fast_sigmoid(gsc * pre) + gof;
     const float ig = dpp_get<DPP_Q0>(act), fg = dpp_get<DPP_Q1>(act);
     const float cg = dpp_get<DPP_Q2>(act), og = dpp_get<DPP_Q3>(act);
     c = fg * c + ig * cg;
     const float h = og * (2.0f * fast_sigmoid(2.0f * c) - 1.0f);
     if (ks == 0) {
-      hs[(s + 1) & 1][j] = h;
+      hs[(s + 1) & 1][hslot] = h;
       ob[(long long)t * (2 * H)] = h;
     }
-    __syncthreads();
+    // LDS-only barrier (__syncthreads() would also drain vmcnt: the global store of h and the x prefetch)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
