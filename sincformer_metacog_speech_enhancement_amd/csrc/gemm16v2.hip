@@ -34,7 +34,7 @@ struct Gemm2Params {
   int K, Kpad, N, Npad, ldo, ldr;
   float alpha;
   int epi, out_f32, gn_group, nsplit;
-  int nMt, nNt, a_records, w_records, vec_ok;
+  int nMt, nNt, a_records, w_records, vec_ok, gn_slots;
 };
 
 template <int N>
@@ -44,13 +44,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <class T, int BN, int STAGES>
+// BM = 128: wave tile 64 x WN, 2 workgroups/CU.  BM = 256: wave tile 128 x WN - every B fragment read from LDS feeds
+// 4 MFMAs instead of 2 (0.75 instead of 1 ds_read_b128 per MFMA: the 128-row kernel needs the full 128 B/clk of the LDS
+// at the matrix cores' rate), at 1 workgroup/CU.
+template <class T, int BN, int STAGES, int BM>
 __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
-  constexpr int BM = 128, BKB = 128;                 // k-tile: 64 elements = 128 bytes per row
+  constexpr int BKB = 128;                           // k-tile: 64 elements = 128 bytes per row
   constexpr int WN = BN / 2;                         // wave tile columns
   constexpr int NJ = WN / 32;
+  constexpr int MI = BM / 64;                        // 32-row blocks per wave
   constexpr int A_STAGE = BM * BKB, B_STAGE = BN * BKB, STAGE = A_STAGE + B_STAGE;
-  constexpr int NA = 4, NB = BN / 32;                // LDS-DMA instructions per wave per tile
+  constexpr int NA = BM / 32, NB = BN / 32;          // LDS-DMA instructions per wave per tile
   constexpr int NLD = NA + NB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -113,9 +117,9 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     }
   };
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -128,10 +132,10 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     if (s < nt) issue(s, s);
 
   // fragment read offsets (bytes) inside a stage
-  int fa_off[2][4], fb_off[NJ][4];
+  int fa_off[MI][4], fb_off[NJ][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * (BM / 2) + i * 32 + l31;
 #pragma unroll
     for (int s = 0; s < 4; ++s) fa_off[i][s] = row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
   }
@@ -158,13 +162,13 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     const unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      u32x4 fa[2], fb[NJ];
+      u32x4 fa[MI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sbase + fa_off[i][s]);
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sbase + fa_off[i][s]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sbase + fb_off[j][s]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
     }
@@ -176,13 +180,20 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
   constexpr int IMG_LD = WN + 4;                       // floats per image row
   float* img = reinterpret_cast<float*>(smem) + wave * (64 * IMG_LD);
 #pragma unroll
+  for (int hp = 0; hp < MI / 2; ++hp) {                // 64 rows of the wave tile per pass
+  if (hp > 0) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // the previous pass has finished reading the image
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) img[(i * 32 + mfma_row(r, lane)) * IMG_LD + j * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) img[(i * 32 + mfma_row(r, lane)) * IMG_LD + j * 32 + l31] = acc[2 * hp + i][j][r];
   __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the wave's own image is complete
   __builtin_amdgcn_wave_barrier();
+  const int row_base = l0 + wm * (BM / 2) + hp * 64;   // first output row of this pass
 
   const bool glu = (p.epi == EPI_GLU);
   const int ecols = glu ? 32 : WN;                     // image columns that produce outputs
@@ -197,11 +208,11 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;     // bias is padded to Npad
     big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
   }
-  float gsum = 0.f, gsq = 0.f;
   const long long obase = (long long)b * p.o_batch_stride;
+  float gsum = 0.f, gsq = 0.f;
   for (int r0 = 0; r0 < 64; r0 += rpp) {
     const int row = r0 + rsub;
-    const int m = l0 + wm * 64 + row;
+    const int m = row_base + row;
     float v[8];
     {
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8]);
@@ -298,27 +309,28 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
       gsum += __shfl_xor(gsum, o, 64);
       gsq += __shfl_xor(gsq, o, 64);
     }
-    if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N) {
-      const int ngroups = p.N / p.gn_group;
-      const long long slot = ((long long)b * (p.nMt * 2) + mtile * 2 + wm) * ngroups + ncol0 / p.gn_group;
+    if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N && (row_base >> 6) < p.gn_slots) {
+      const int ngroups = p.N / p.gn_group;             // one partial per 64-row block of the output, whatever BM is
+      const long long slot = ((long long)b * p.gn_slots + (row_base >> 6)) * ngroups + ncol0 / p.gn_group;
       p.gn_partial[slot * 2 + 0] = gsum;
       p.gn_partial[slot * 2 + 1] = gsq;
     }
   }
+  }
 }
 
-template <class T, int BN, int STAGES>
+template <class T, int BN, int STAGES, int BM>
 static int launch_v2(const Gemm2Params& p, hipStream_t stream) {
-  constexpr int ring = STAGES * (128 + BN) * 128, image = 4 * 64 * (BN / 2 + 4) * 4;
+  constexpr int ring = STAGES * (BM + BN) * 128, image = 4 * 64 * (BN / 2 + 4) * 4;
   constexpr int lds = ring > image ? ring : image;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm16v2_kernel<T, BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm16v2_kernel<T, BN, STAGES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SFM_ERR_LAUNCH;
     attr_set = true;
   }
   dim3 grid(p.nMt * p.nNt * p.B), block(256);
-  SFM_LAUNCH((gemm16v2_kernel<T, BN, STAGES>), grid, block, lds, stream, p);
+  SFM_LAUNCH((gemm16v2_kernel<T, BN, STAGES, BM>), grid, block, lds, stream, p);
   return SFM_OK;
 }
 
@@ -329,7 +341,7 @@ extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, vo
                              int nsplit, int dtype, void* stream);
 
 // same contract as sfm_gemm16_v1 (include/sincformer_hip.h); `variant`: 0 = auto, 1 = v1 register-staged kernel,
-// 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU)
+// 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU), 4 / 5 = 256-row tiles with 2 / 3 stages
 extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,
                              float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
                              long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
@@ -371,13 +383,18 @@ extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, vo
   p.vec_ok = (o_al && r_al) ? 1 : 0;
   const bool bn128 = (Npad % 128 == 0);
   const int BNv = bn128 ? 128 : 64;
-  p.nMt = (Lout + 127) / 128;
+  // variants 4 / 5: 256-row tiles (wave tile 128 x 64), 2 / 3 stages, 128-column tiles only
+  const bool big = (variant == 4 || variant == 5) && bn128;
+  const int BMv = big ? 256 : 128;
+  p.nMt = (Lout + BMv - 1) / BMv;
   p.nNt = Npad / BNv;
+  p.gn_slots = 2 * ((Lout + 127) / 128);               // partial slots per batch entry: one per 64 output rows (padded to 128)
   hipStream_t st = (hipStream_t)stream;
-  const bool s3 = (variant == 3);
-#define GO(TT)                                                         \
-  if (bn128) return s3 ? launch_v2<TT, 128, 3>(p, st) : launch_v2<TT, 128, 2>(p, st); \
-  else return s3 ? launch_v2<TT, 64, 3>(p, st) : launch_v2<TT, 64, 2>(p, st);
+  const bool s3 = (variant == 3 || variant == 5);
+#define GO(TT)                                                                                            \
+  if (big) return s3 ? launch_v2<TT, 128, 3, 256>(p, st) : launch_v2<TT, 128, 2, 256>(p, st);           \
+  if (bn128) return s3 ? launch_v2<TT, 128, 3, 128>(p, st) : launch_v2<TT, 128, 2, 128>(p, st);          \
+  else return s3 ? launch_v2<TT, 64, 3, 128>(p, st) : launch_v2<TT, 64, 2, 128>(p, st);
   if (dtype == SFM_DT_BF16) { GO(BF16) }
   if (dtype == SFM_DT_F16) { GO(F16) }
 #undef GO
