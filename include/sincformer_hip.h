@@ -65,6 +65,14 @@ int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, co
                   long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
                   int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
                   int nsplit, int dtype, int variant, void* stream);
+/* sfm_gemm16_ex + residual-branch dropout in the EPI_RESID epilogue (training forward of models/conformer.py:48,70,127):
+ * out = resid + alpha * keep(seed, m*N + n)/(1 - p_drop) * (A W^T + bias), the same counter-based keep as sfm_ew_train. */
+int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                  float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                  long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                  int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                  int nsplit, int dtype, int variant, float p_drop, unsigned int seed,
+                     void* stream);
 int sfm_gemm16_v1(const void* A, const void* W, const float* bias, void* out, const float* resid,
                   float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
                   long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
@@ -205,8 +213,9 @@ int sfm_sumsq(const float* g, long long n, double* out, void* stream);
 int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
                    float eps, float wd, float inv_scale, float max_norm, int write_back_grad, void* stream);
 /* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
-/* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); bias grad */
-int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,
+/* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); db (optional):
+ * db[n] += sum_m G[m,n] in the same launch; sfm_colsum = the stand-alone bias gradient */
+int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw,
                   int dtype, void* stream);
 int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream);
 int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,

@@ -3,18 +3,6 @@
 // training statistics and backward, depthwise-conv weight gradient.  All HBM-bound streaming kernels.
 #include "sfm_common.h"
 
-// ---- counter-based dropout: keep(seed, idx) is a pure function, so forward and backward agree and no
-//      mask is stored.  (Statistically equivalent to, not bit-identical with, torch's Philox stream.)
-__device__ __forceinline__ uint32_t sfm_hash(uint32_t seed, unsigned long long idx) {
-  uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ float sfm_keep_scale(uint32_t seed, unsigned long long idx, float p, float inv_keep) {
-  // 0 if dropped, 1/(1-p) if kept
-  return ((sfm_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
-}
-
 // ---------------------------------------------------------------------------
 // LayerNorm backward: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //                     dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy          (D <= 512)

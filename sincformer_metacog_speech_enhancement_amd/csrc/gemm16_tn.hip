@@ -12,8 +12,8 @@
 
 template <class T>
 __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
-                                                        float* __restrict__ dW, int M, int N, int K, int ldg, int ldx,
-                                                        int ldw, int rows_per_split) {
+                                                        float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                        int K, int ldg, int ldx, int ldw, int rows_per_split) {
   __shared__ __attribute__((aligned(16))) u16 Gs[64 * TN_ROW];
   __shared__ __attribute__((aligned(16))) u16 Xs[64 * TN_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
   const int trow = 4 * (g16 >> 1) + qq;
   const int tcol = (g16 & 1) * 16 + 4 * pp;
 
+  // bias gradient (column sums of G): the k-tile-0 workgroups already stage every G tile in LDS
+  const bool do_bias = (db != nullptr) && (blockIdx.y == 0);
+  float bsum = 0.f;
   load_tile(m_begin);
   for (int mt = m_begin; mt < m_end; mt += 64) {
 #pragma unroll
@@ -81,6 +84,11 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
     }
     __syncthreads();
     if (mt + 64 < m_end) load_tile(mt + 64);
+    if (do_bias) {                                             // thread (column c, row half): 32 rows of the 64-row tile
+      const int c = tid & 127, r0 = (tid >> 7) * 32;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) bsum += T::to_f32(Gs[(r0 + r) * TN_ROW + c]);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       u32x4 fa[2], fb[2];
@@ -119,6 +127,10 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
         if (n < N && k < K) atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
       }
     }
+  if (do_bias) {
+    const int n = n0 + (tid & 127);
+    if (n < N) atomicAdd(&db[n], bsum);
+  }
 }
 
 // out[n] += sum_m G[m, n]   (bias gradient); G fp32 or 16-bit
@@ -181,8 +193,9 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const void* __restrict_
   }
 }
 
-extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int N, int K, int ldg, int ldx, int ldw,
-                             int dtype, void* stream) {
+// db (optional): bias gradient out[n] += sum_m G[m, n], computed from the G tiles the k-tile-0 workgroups stage anyway
+extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx,
+                             int ldw, int dtype, void* stream) {
   if (!G || !X || !dW) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (ldx % 8) != 0) return SFM_ERR_SHAPE;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
@@ -195,10 +208,10 @@ extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, int M, int
   splits = (M + rows - 1) / rows;
   dim3 grid((N + 127) / 128, (K + 127) / 128, splits), block(256);
   if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((gemm16_tn_kernel<F16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, M, N, K, ldg,
-               ldx, ldw, rows);
+    SFM_LAUNCH((gemm16_tn_kernel<F16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
+               ldg, ldx, ldw, rows);
   else
-    SFM_LAUNCH((gemm16_tn_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, M, N, K,
+    SFM_LAUNCH((gemm16_tn_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
                ldg, ldx, ldw, rows);
   return SFM_OK;
 }

@@ -35,6 +35,8 @@ struct Gemm2Params {
   float alpha;
   int epi, out_f32, gn_group, nsplit;
   int nMt, nNt, a_records, w_records, vec_ok, gn_slots;
+  float p_drop;                                   // EPI_RESID only: out = resid + alpha * keep(m*N + n) * v  (training)
+  unsigned int seed;
 };
 
 template <int N>
@@ -266,6 +268,12 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     const long long orow = obase + (long long)m * p.ldo + ncol0;
     if (p.vec_ok && ncol0 + 8 <= p.N) {
       if (p.epi == EPI_RESID) {
+        if (p.p_drop > 0.f) {                           // residual-branch dropout, same counters as sfm_ew_train mode 4
+          const float ik = 1.0f / (1.0f - p.p_drop);
+          const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik);
+        }
         const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
         const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
         const f32x4 r1v = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -290,8 +298,11 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
       for (int e = 0; e < 8; ++e) {
         if (ncol0 + e < p.N) {
           float y = v[e];
-          if (p.epi == EPI_RESID)
+          if (p.epi == EPI_RESID) {
+            if (p.p_drop > 0.f)
+              y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
             y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
+          }
           if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
           else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
         }
@@ -342,18 +353,22 @@ extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, vo
 
 // same contract as sfm_gemm16_v1 (include/sincformer_hip.h); `variant`: 0 = auto, 1 = v1 register-staged kernel,
 // 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU), 4 / 5 = 256-row tiles with 2 / 3 stages
-extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,
-                             float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
-                             long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
-                             int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
-                             int nsplit, int dtype, int variant, void* stream) {
+// sfm_gemm16_train = sfm_gemm16_ex + residual-branch dropout in the EPI_RESID epilogue (training forward):
+// out = resid + alpha * keep(seed, m*N + n) / (1 - p_drop) * (A W^T + bias)
+extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                                float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                                long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                                int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                                int nsplit, int dtype, int variant, float p_drop, unsigned int seed, void* stream) {
   if (!A || !W || !out) return SFM_ERR_ARG;
+  if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && epi != EPI_RESID)) return SFM_ERR_SHAPE;
   if (B <= 0 || Lout <= 0 || N <= 0) return SFM_ERR_SHAPE;
   const long long a_rec = ((long long)(Lin - 1) * lda + Cin) * 2;
   const long long w_rec = (long long)Npad * Kpad * 2;
   const bool v2_ok = (Kpad % 64 == 0) && (Npad % 64 == 0) && a_rec < (1LL << 31) && w_rec < (1LL << 31) &&
                      (!gn_partial || gn_group == 8 || gn_group == 16 || gn_group == 32) &&
                      ((long long)Lout * stride * lda * 2 < (1LL << 31)) && (epi != EPI_GLU || Npad % 128 == 0);
+  if ((variant == 1 || !v2_ok) && p_drop > 0.f) return SFM_ERR_SHAPE;
   if (variant == 1 || !v2_ok)
     return sfm_gemm16_v1(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
                          Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
@@ -375,7 +390,7 @@ extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, vo
   p.a_batch_stride = a_batch_stride; p.o_batch_stride = o_batch_stride; p.r_batch_stride = r_batch_stride;
   p.B = B; p.Lout = Lout; p.Lin = Lin; p.Cin = Cin; p.lda = lda; p.stride = stride; p.pad = pad; p.cin_shift = shift;
   p.K = K; p.Kpad = Kpad; p.N = N; p.Npad = Npad; p.ldo = ldo; p.ldr = ldr; p.alpha = alpha; p.epi = epi;
-  p.out_f32 = out_f32; p.gn_group = gn_group; p.nsplit = nsplit;
+  p.out_f32 = out_f32; p.gn_group = gn_group; p.nsplit = nsplit; p.p_drop = p_drop; p.seed = seed;
   p.a_records = (int)a_rec; p.w_records = (int)w_rec;
   const int osz = out_f32 ? 4 : 2;
   const bool o_al = (((uintptr_t)out) % 16 == 0) && ((ldo * osz) % 16 == 0) && ((o_batch_stride * osz) % 16 == 0);
@@ -399,6 +414,16 @@ extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, vo
   if (dtype == SFM_DT_F16) { GO(F16) }
 #undef GO
   return SFM_ERR_ARG;
+}
+
+extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                             float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                             long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                             int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                             int nsplit, int dtype, int variant, void* stream) {
+  return sfm_gemm16_train(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
+                          Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
+                          dtype, variant, 0.f, 0u, stream);
 }
 
 extern "C" int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const float* resid,

@@ -71,6 +71,19 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return T::pack(lo, hi);
 }
 
+// ---- counter-based dropout: keep(seed, idx) is a pure function, so forward and backward agree and no
+//      mask is stored.  (Statistically equivalent to, not bit-identical with, torch's Philox stream.)
+__device__ __forceinline__ uint32_t sfm_hash(uint32_t seed, unsigned long long idx) {
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float sfm_keep_scale(uint32_t seed, unsigned long long idx, float p, float inv_keep) {
+  // 0 if dropped, 1/(1-p) if kept
+  return ((sfm_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
+
 // row of C/D register r for lane l (32x32 tiles)
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

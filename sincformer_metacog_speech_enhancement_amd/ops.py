@@ -216,13 +216,21 @@ def pack_linear(weight, bias=None, glu=False, k_pad_to=None, dtype=None):
 
 
 def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda=None, stride=1, pad=0,
-           epi=EPI_NONE, resid=None, ldr=0, r_batch_stride=0, alpha=1.0, gn_partial=None, gn_group=0, nsplit=0):
+           epi=EPI_NONE, resid=None, ldr=0, r_batch_stride=0, alpha=1.0, gn_partial=None, gn_group=0, nsplit=0,
+           p_drop=0.0, seed=0):
     """A: [B, Lin, cin] 16-bit with position stride lda (default cin) -> out rows (b, l)."""
     _need_dev(A, out)
     L = _lib.load()
     cin = pw.cin
     lda = cin if lda is None else lda
     out_f32 = 1 if out.dtype == torch.float32 else 0
+    if p_drop > 0.0:                                   # training forward: residual-branch dropout in the epilogue
+        _call("gemm16", L.sfm_gemm16_train, (_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin,
+                                             lda, pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo,
+                                             o_batch_stride, ldr, r_batch_stride, float(alpha), epi, out_f32, gn_group, nsplit,
+                                             _dt(), _state["gemm_variant"], float(p_drop), int(seed) & 0xffffffff, _stream()),
+              *_cost_of("gemm16", locals()))
+        return out
     _call("gemm16", L.sfm_gemm16_ex, (_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin, lda,
                       pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo, o_batch_stride, ldr, r_batch_stride,
                       float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _state["gemm_variant"], _stream()),
@@ -230,14 +238,15 @@ def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda
     return out
 
 
-def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=None, nsplit=0):
+def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=None, nsplit=0, p_drop=0.0, seed=0):
     """x16 [M, K(>=pw.K)] 16-bit contiguous rows -> [M, N]."""
     M, ld = x16.shape[0], x16.stride(0)
     if out is None:
         odt = out_dtype or (torch.float32 if epi == EPI_RESID else _state["dtype"])
         out = torch.empty(M, pw.N, device=x16.device, dtype=odt)
     gemm16(x16, pw, out, B=1, Lout=M, Lin=M, a_batch_stride=0, lda=ld, ldo=out.stride(0), o_batch_stride=0, epi=epi,
-           resid=resid, ldr=(resid.stride(0) if resid is not None else 0), alpha=alpha, nsplit=nsplit)
+           resid=resid, ldr=(resid.stride(0) if resid is not None else 0), alpha=alpha, nsplit=nsplit, p_drop=p_drop,
+           seed=seed)
     return out
 
 
@@ -507,13 +516,13 @@ def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits)
 # ---------------------------------------------------------------------------
 # training path (ConformerBlock backward)
 # ---------------------------------------------------------------------------
-def gemm16_tn(G16, X16, dW):
-    """dW[n,k] += sum_m G16[m,n] * X16[m,k]   (dW fp32, accumulated)."""
+def gemm16_tn(G16, X16, dW, db=None):
+    """dW[n,k] += sum_m G16[m,n] * X16[m,k]   (dW fp32, accumulated); db[n] += sum_m G16[m,n] when given."""
     L = _lib.load()
     M, N = G16.shape
     K = X16.shape[1]
-    _call("gemm16_tn", L.sfm_gemm16_tn, (_p(G16), _p(X16), _p(dW), M, N, K, G16.stride(0), X16.stride(0), dW.stride(0), _dt(),
-                                         _stream()), 2.0 * M * N * K, M * (N + K) * 2.0)
+    _call("gemm16_tn", L.sfm_gemm16_tn, (_p(G16), _p(X16), _p(dW), _p(db), M, N, K, G16.stride(0), X16.stride(0), dW.stride(0),
+                                         _dt(), _stream()), 2.0 * M * N * K, M * (N + K) * 2.0)
 
 
 def colsum(G, out):

@@ -43,6 +43,12 @@ def _ln16(x32, w, b):
     return out
 
 
+def _resid_gemm(a16, pw, x32, alpha, p, seed):
+    """x + alpha * dropout(a16 @ W^T + b): the residual add and the branch dropout ride in the GEMM epilogue (same
+    counter-based keep(seed, m*N + n) that the backward's ew_train(EW_SCALE_DROP) evaluates)."""
+    return ops.linear16(a16, pw, epi=ops.EPI_RESID, resid=x32, alpha=alpha, out_dtype=torch.float32, p_drop=p, seed=seed)
+
+
 class _Seeds:
     def __init__(self, base):
         self.base, self.i = int(base) & 0x7FFFFFFF, 0
@@ -66,9 +72,7 @@ def _ffn_fwd(x, P, pre, p, seeds):
     s1, s2 = seeds.next(), seeds.next()
     u = torch.empty_like(z1)
     ops.ew_train(ops.EW_SWISH_FWD, u, z=z1, p=p, seed=s1)
-    o = ops.linear16(u, f2, out_dtype=torch.float32)
-    y = torch.empty_like(x)
-    ops.ew_train(ops.EW_SCALE_DROP, y, z=x, g=o, alpha=0.5, p=p, seed=s2)
+    y = _resid_gemm(u, f2, x, 0.5, p, s2)                                 # x + 0.5 * dropout(linear2(u)), one launch
     return y, dict(x=x, lw=lw, h16=h16, z1=z1, u=u, b1=b1, b2=b2, s1=s1, s2=s2, p=p)
 
 
@@ -78,13 +82,11 @@ def _ffn_bwd(dy, c, G, pre):
     FF = c["z1"].shape[1]
     do = torch.empty(M, D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=0.5, p=c["p"], seed=c["s2"])
-    ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"])
-    ops.colsum(do, G[pre + "linear2.bias"])
+    ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"], G[pre + "linear2.bias"])
     du = ops.linear16(do, c["b2"], out_dtype=torch.float32)                 # [M, FF]
     dz = torch.empty(M, FF, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_SWISH_BWD, dz, z=c["z1"], g=du, p=c["p"], seed=c["s1"])
-    ops.gemm16_tn(dz, c["h16"], G[pre + "linear1.weight"])
-    ops.colsum(dz, G[pre + "linear1.bias"])
+    ops.gemm16_tn(dz, c["h16"], G[pre + "linear1.weight"], G[pre + "linear1.bias"])
     dh = ops.linear16(dz, c["b1"], out_dtype=torch.float32)                 # [M, D]
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G[pre + "layer_norm.weight"], G[pre + "layer_norm.bias"])
 
@@ -106,9 +108,7 @@ def _mhsa_fwd(x, P, B, T, H, p, seeds):
     qkv = ops.linear16(h16, fin)
     sa, sd = seeds.next(), seeds.next()
     O, lse = ops.attention_train(qkv, B, T, H, hd, p_drop=p, seed=sa)
-    o = ops.linear16(O, fout, out_dtype=torch.float32)
-    y = torch.empty_like(x)
-    ops.ew_train(ops.EW_SCALE_DROP, y, z=x, g=o, alpha=1.0, p=p, seed=sd)
+    y = _resid_gemm(O, fout, x, 1.0, p, sd)
     return y, dict(x=x, lw=lw, h16=h16, qkv=qkv, O=O, lse=lse, bin=bin_, bout=bout, sa=sa, sd=sd, p=p, qs=qs, B=B, T=T, H=H)
 
 
@@ -117,16 +117,14 @@ def _mhsa_bwd(dy, c, G):
     M, D = dy.shape
     do = torch.empty(M, D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=1.0, p=c["p"], seed=c["sd"])
-    ops.gemm16_tn(do, c["O"], G["mhsa.attention.out_proj.weight"])
-    ops.colsum(do, G["mhsa.attention.out_proj.bias"])
+    ops.gemm16_tn(do, c["O"], G["mhsa.attention.out_proj.weight"], G["mhsa.attention.out_proj.bias"])
     dO = ops.linear16(do, c["bout"])                                         # 16-bit [M, D]
     dqkv = ops.attention_bwd(c["qkv"], c["O"], dO, c["lse"], c["B"], c["T"], c["H"], D // c["H"], p_drop=c["p"], seed=c["sa"])
     gw, gb = G["mhsa.attention.in_proj_weight"], G["mhsa.attention.in_proj_bias"]
     # the Q rows of W were multiplied by qs in the forward: accumulate into scratch, then scale those rows
     tw = torch.zeros_like(gw)
     tb = torch.zeros_like(gb)
-    ops.gemm16_tn(dqkv, c["h16"], tw)
-    ops.colsum(dqkv, tb)
+    ops.gemm16_tn(dqkv, c["h16"], tw, tb)
     tw[:D] *= c["qs"]
     tb[:D] *= c["qs"]
     gw += tw
@@ -169,10 +167,8 @@ def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5):
     sh = (bet - mean * gam * rstd).reshape(1, D).contiguous()
     s16 = torch.empty(M, D, device=x.device, dtype=dt)
     ops.gn_apply(yc, sc, sh, s16, 1, M, D, act=2)                            # BatchNorm + Swish
-    o = ops.linear16(s16, f2, out_dtype=torch.float32)
     sd = seeds.next()
-    y = torch.empty_like(x)
-    ops.ew_train(ops.EW_SCALE_DROP, y, z=x, g=o, alpha=1.0, p=p, seed=sd)
+    y = _resid_gemm(s16, f2, x, 1.0, p, sd)
     return y, dict(x=x, lw=lw, h16=h16, pre=pre, g16=g16, yc=yc, mean=mean, rstd=rstd, gam=gam, bet=bet, s16=s16, b1=b1, b2=b2,
                    wdw=wdw, KS=KS, sd=sd, p=p, B=B, T=T)
 
@@ -183,8 +179,7 @@ def _conv_bwd(dy, c, G):
     B, T, KS = c["B"], c["T"], c["KS"]
     do = torch.empty(M, D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=1.0, p=c["p"], seed=c["sd"])
-    ops.gemm16_tn(do, c["s16"], G["conv.pointwise2.weight"].view(D, D))
-    ops.colsum(do, G["conv.pointwise2.bias"])
+    ops.gemm16_tn(do, c["s16"], G["conv.pointwise2.weight"].view(D, D), G["conv.pointwise2.bias"])
     ds = ops.linear16(do, c["b2"], out_dtype=torch.float32)
     dyc, dgam, dbet = ops.bn_swish_bwd(ds, c["yc"], c["mean"], c["rstd"], c["gam"], c["bet"])
     G["conv.batch_norm.weight"] += dgam
@@ -200,8 +195,7 @@ def _conv_bwd(dy, c, G):
     dg = ops.dwconv_folded(dyc16, wflipT, ones, zeros, B, T, D, act=0)
     dpre = torch.empty(M, 2 * D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_GLU_BWD, dpre, z=c["pre"], g=dg, N=D)
-    ops.gemm16_tn(dpre, c["h16"], G["conv.pointwise1.weight"].view(2 * D, D))
-    ops.colsum(dpre, G["conv.pointwise1.bias"])
+    ops.gemm16_tn(dpre, c["h16"], G["conv.pointwise1.weight"].view(2 * D, D), G["conv.pointwise1.bias"])
     dh = ops.linear16(dpre, c["b1"], out_dtype=torch.float32)
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G["conv.layer_norm.weight"], G["conv.layer_norm.bias"])
 
@@ -301,8 +295,7 @@ class LNLinearFunction(torch.autograd.Function):
         ops.convert_rows(dy, dy16, M, N, Np, dy.stride(0), Np)
         dW = torch.zeros(N, K, device=dev, dtype=torch.float32)
         db = torch.zeros(N, device=dev, dtype=torch.float32)
-        ops.gemm16_tn(dy16[:, :N], h16[:, :K], dW)
-        ops.colsum(dy16[:, :N], db)
+        ops.gemm16_tn(dy16[:, :N], h16[:, :K], dW, db)
         bwd = ops.pack_linear(w32.t().contiguous(), k_pad_to=Np)
         dh = ops.linear16(dy16, bwd, out_dtype=torch.float32)                  # [M, K]
         t = ctx.dtypes

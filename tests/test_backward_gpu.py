@@ -38,9 +38,11 @@ def test_gemm16_tn_and_colsum(ops, dt, M, N, K):
     dW = torch.zeros(N, K, device="cuda")
     gbuf = torch.zeros(M, (N + 7) // 8 * 8, device="cuda", dtype=dt)       # row stride must be a multiple of 8 elements
     gbuf[:, :N] = g.cuda().to(dt)
-    ops.gemm16_tn(gbuf[:, :N], x.cuda().to(dt).contiguous(), dW)
+    dbf = torch.zeros(N, device="cuda")
+    ops.gemm16_tn(gbuf[:, :N], x.cuda().to(dt).contiguous(), dW, dbf)
     ref = q16(g, dt).t() @ q16(x, dt)
     report("wgrad %dx%dx%d %s" % (M, N, K, dt), dW.cpu(), ref, 2e-3 * math.sqrt(M / 1000.0))
+    report("wgrad fused bias grad", dbf.cpu(), q16(g, dt).sum(0), 1e-3)
     db = torch.zeros(N, device="cuda")
     ops.colsum(g.cuda(), db)
     report("colsum fp32", db.cpu(), g.sum(0), 1e-3)
