@@ -286,7 +286,7 @@ def test_mrstft_sizes_vs_golden(pkg):
 # edge shapes of the whole path against the (golden-pinned) oracle: single utterance, odd batch, sample counts that are
 # multiples of neither the hop (80) nor the encoder stride (16), the shortest signal the reflect padding admits
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("B,L", [(1, 1237), (3, 4001), (1, 400), (5, 2000)])
+@pytest.mark.parametrize("B,L", [(1, 1237), (3, 4001), (1, 400), (5, 2000), (1, 96080)])   # last: T 1202 -> 64-row attention kernel
 def test_end_to_end_path_ragged_shapes_vs_oracle(pkg, B, L):
     dt = torch.float16
     pkg.ops.set_compute_dtype(dt)
