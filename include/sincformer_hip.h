@@ -156,6 +156,12 @@ int sfm_sinc_filters(const float* low_hz, const float* band_hz, const float* win
 int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb, const void* W1, const float* b1,
                   const void* W2, const float* b2, float* out, int M, int D, int FF, float alpha, float eps,
                   int dtype, void* stream);
+/* sfm_ffn_fused + the LayerNorm that follows the module inside the block (mhsa.layer_norm after ff1, final_norm after ff2;
+ * models/conformer.py:66,151) applied to y in the epilogue: ln_out [M, 256] 16-bit (ln_out_f32 = 0) or fp32; out (y) may be
+ * NULL when only the normalised rows are needed. */
+int sfm_ffn_fused_ln(const float* x, const float* lnw, const float* lnb, const void* W1, const float* b1, const void* W2,
+                     const float* b2, float* out, int M, int D, int FF, float alpha, float eps, const float* ln2w,
+                     const float* ln2b, void* ln_out, int ln_out_f32, int dtype, void* stream);
 /* SincConv1d FIR (agents/perception.py:117) on the 16-bit matrix cores with hi/lo split operands
  * (3 MFMA passes, ~fp32 accuracy).  filt [64,K] fp32 from sfm_sinc_filters; wsh = workspace of
  * 8*2*64*272 uint16; out [B,L,64] channels-last; gn_partial [B][sfm_sinc_fir16_tiles(L)][8][2],

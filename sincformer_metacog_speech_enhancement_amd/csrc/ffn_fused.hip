@@ -32,7 +32,9 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ lnb, const u16* __restrict__ W1,
                                                         const float* __restrict__ b1, const u16* __restrict__ W2,
                                                         const float* __restrict__ b2, float* __restrict__ out, int M,
-                                                        int FF, float alpha, float eps, int w1_bytes, int w2_bytes) {
+                                                        int FF, float alpha, float eps, int w1_bytes, int w2_bytes,
+                                                        const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+                                                        void* __restrict__ ln_out, int ln_out_f32) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS map: two weight stages, each [W1 chunk 64 x 512 B | W2 chunk 256 x 128 B] = 64 KB, then U [128][128 B].
   // During the prologue the first 64 KB (the two W1 slots are NOT yet in use) hold LN(x) as [128][512 B].
@@ -195,37 +197,100 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   const int ncol = wn2 * 64 + c8;
   const f32x4 bb0 = *reinterpret_cast<const f32x4*>(b2 + ncol);
   const f32x4 bb1 = *reinterpret_cast<const f32x4*>(b2 + ncol + 4);
+  float ov[8][8];                                        // this lane's 8 rows x 8 columns of y = x + alpha * ffn(x)
 #pragma unroll
-  for (int r0 = 0; r0 < 64; r0 += 8) {
-    const int row = r0 + rsub;
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + rsub;
     const int m = m0 + wm2 * 64 + row;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(&img[row * 68 + c8]);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(&img[row * 68 + c8 + 4]);
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
     if (m < M) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&img[row * 68 + c8]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&img[row * 68 + c8 + 4]);
       const float* xp = x + (long long)m * FF_D + ncol;
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-      f32x4 o0, o1;
+      x0 = *reinterpret_cast<const f32x4*>(xp);
+      x1 = *reinterpret_cast<const f32x4*>(xp + 4);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o0[e] = x0[e] + alpha * (a0[e] + bb0[e]);
-        o1[e] = x1[e] + alpha * (a1[e] + bb1[e]);
-      }
+    for (int e = 0; e < 4; ++e) {
+      ov[it][e] = x0[e] + alpha * (a0[e] + bb0[e]);
+      ov[it][4 + e] = x1[e] + alpha * (a1[e] + bb1[e]);
+    }
+    if (out && m < M) {
       float* op = out + (long long)m * FF_D + ncol;
-      *reinterpret_cast<f32x4*>(op) = o0;
-      *reinterpret_cast<f32x4*>(op + 4) = o1;
+      *reinterpret_cast<f32x4*>(op) = f32x4{ov[it][0], ov[it][1], ov[it][2], ov[it][3]};
+      *reinterpret_cast<f32x4*>(op + 4) = f32x4{ov[it][4], ov[it][5], ov[it][6], ov[it][7]};
+    }
+  }
+  if (ln2w == nullptr) return;                           // block-uniform
+
+  // ---- fused LayerNorm of the NEXT sub-layer on y (mhsa.layer_norm after ff1, final_norm after ff2; models/conformer.py:
+  // 66, 151): a row's 256 columns live in the 4 waves wn2 = 0..3, so the row statistics cross the waves through LDS ----
+  float* red = reinterpret_cast<float*>(smem + 8 * 64 * 68 * 4);   // [128 rows][4] behind the images
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      float v = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = pass ? (ov[it][e] - mean[it]) : ov[it][e];
+        v += pass ? d * d : d;
+      }
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if ((lane & 7) == 0) red[(wm2 * 64 + it * 8 + rsub) * 4 + wn2] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(&red[(wm2 * 64 + it * 8 + rsub) * 4]);
+      const float t = (q[0] + q[1] + q[2] + q[3]) * (1.0f / FF_D);
+      if (pass == 0) mean[it] = t;
+      else rstd[it] = rsqrtf(t + eps);
+    }
+    __syncthreads();
+  }
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln2w + ncol), g1 = *reinterpret_cast<const f32x4*>(ln2w + ncol + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(ln2b + ncol), h1 = *reinterpret_cast<const f32x4*>(ln2b + ncol + 4);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int m = m0 + wm2 * 64 + it * 8 + rsub;
+    if (m >= M) continue;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y[e] = (ov[it][e] - mean[it]) * rstd[it] * g0[e] + h0[e];
+      y[4 + e] = (ov[it][4 + e] - mean[it]) * rstd[it] * g1[e] + h1[e];
+    }
+    if (ln_out_f32) {
+      float* op = reinterpret_cast<float*>(ln_out) + (long long)m * FF_D + ncol;
+      *reinterpret_cast<f32x4*>(op) = f32x4{y[0], y[1], y[2], y[3]};
+      *reinterpret_cast<f32x4*>(op + 4) = f32x4{y[4], y[5], y[6], y[7]};
+    } else {
+      u32x4 pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(y[2 * e], y[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(ln_out) + (long long)m * FF_D + ncol) = pk;
     }
   }
 }
 
 // x, out [M, 256] fp32 contiguous rows; W1 [FF, 256], W2 [256, FF] 16-bit row-major (nn.Linear layout); fp32 biases.
-extern "C" int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb, const void* W1, const float* b1,
-                             const void* W2, const float* b2, float* out, int M, int D, int FF, float alpha, float eps,
-                             int dtype, void* stream) {
-  if (!x || !lnw || !lnb || !W1 || !b1 || !W2 || !b2 || !out) return SFM_ERR_ARG;
+// sfm_ffn_fused_ln: as sfm_ffn_fused, plus the LayerNorm that follows the module in the block (ln2w / ln2b) applied to
+// y in the epilogue: ln_out [M, 256] 16-bit (feeds the next GEMM) or fp32; `out` (y itself) may be NULL when only the
+// normalised rows are needed (ff2 -> final_norm).
+extern "C" int sfm_ffn_fused_ln(const float* x, const float* lnw, const float* lnb, const void* W1, const float* b1,
+                                const void* W2, const float* b2, float* out, int M, int D, int FF, float alpha, float eps,
+                                const float* ln2w, const float* ln2b, void* ln_out, int ln_out_f32, int dtype,
+                                void* stream) {
+  if (!x || !lnw || !lnb || !W1 || !b1 || !W2 || !b2) return SFM_ERR_ARG;
+  if (!out && !ln_out) return SFM_ERR_ARG;
+  if ((ln2w || ln2b || ln_out) && !(ln2w && ln2b && ln_out)) return SFM_ERR_ARG;
   if (D != FF_D || FF <= 0 || FF % FF_CH != 0 || FF > 2048 || M <= 0) return SFM_ERR_SHAPE;
   const int lds_ring = 2 * (FF_CH * 512 + FF_D * 128) + FF_BM * 128 + FF * 4;
-  const int lds_img = 8 * 64 * 68 * 4;
+  const int lds_img = 8 * 64 * 68 * 4 + 128 * 4 * 4;       // images + the row-statistics exchange of the fused LayerNorm
   const int lds = lds_ring > lds_img ? lds_ring : lds_img;
   const int wbytes = FF * FF_D * 2;
   dim3 grid((M + FF_BM - 1) / FF_BM), block(512);
@@ -238,7 +303,7 @@ extern "C" int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb,
       s16 = true;
     }
     SFM_LAUNCH((ffn_fused_kernel<F16>), grid, block, lds, st, x, lnw, lnb, (const u16*)W1, b1, (const u16*)W2, b2, out, M,
-               FF, alpha, eps, wbytes, wbytes);
+               FF, alpha, eps, wbytes, wbytes, ln2w, ln2b, ln_out, ln_out_f32);
   } else {
     static bool sb = false;
     if (!sb) {
@@ -247,7 +312,14 @@ extern "C" int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb,
       sb = true;
     }
     SFM_LAUNCH((ffn_fused_kernel<BF16>), grid, block, lds, st, x, lnw, lnb, (const u16*)W1, b1, (const u16*)W2, b2, out, M,
-               FF, alpha, eps, wbytes, wbytes);
+               FF, alpha, eps, wbytes, wbytes, ln2w, ln2b, ln_out, ln_out_f32);
   }
   return SFM_OK;
+}
+
+extern "C" int sfm_ffn_fused(const float* x, const float* lnw, const float* lnb, const void* W1, const float* b1,
+                             const void* W2, const float* b2, float* out, int M, int D, int FF, float alpha, float eps,
+                             int dtype, void* stream) {
+  if (!out) return SFM_ERR_ARG;
+  return sfm_ffn_fused_ln(x, lnw, lnb, W1, b1, W2, b2, out, M, D, FF, alpha, eps, nullptr, nullptr, nullptr, 0, dtype, stream);
 }

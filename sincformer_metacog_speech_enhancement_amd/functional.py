@@ -189,6 +189,16 @@ def _ln16(x32, w, b, act=0):
     return out
 
 
+def _ffn_fusable(x32, pk):
+    return FUSED_FFN and "fused" in pk and x32.is_contiguous()
+
+
+def ffn_forward_ln(x32, pk, ln_w, ln_b, ln_f32, want_y):
+    """FeedForwardModule + the LayerNorm that follows it in the block, one launch: (y or None, LN(y))."""
+    w1, b1, w2, b2 = pk["fused"]
+    return ops.ffn_fused_ln(x32, pk["ln_w"], pk["ln_b"], w1, b1, w2, b2, ln_w, ln_b, ln_f32, want_y=want_y, alpha=0.5)
+
+
 def ffn_forward(x32, pk):
     """FeedForwardModule.forward (eval): x + 0.5 * W2 swish(W1 LN(x))   [M, D] fp32 -> fp32"""
     if FUSED_FFN and "fused" in pk and x32.is_contiguous():
@@ -199,9 +209,11 @@ def ffn_forward(x32, pk):
     return ops.linear16(u, pk["w2"], epi=ops.EPI_RESID, resid=x32, alpha=0.5)
 
 
-def mhsa_forward(x32, pk, B, T, H):
+def mhsa_forward(x32, pk, B, T, H, h=None):
+    """h: LN(x32) in 16-bit when the producer already normalised (fused into the preceding FFN's epilogue)"""
     D = x32.shape[1]
-    h = _ln16(x32, pk["ln_w"], pk["ln_b"])
+    if h is None:
+        h = _ln16(x32, pk["ln_w"], pk["ln_b"])
     qkv = ops.linear16(h, pk["win"])
     if pk["heads"] != H:
         raise RuntimeError("packed attention weights were scaled for %d heads, got %d" % (pk["heads"], H))
@@ -222,10 +234,19 @@ def convmod_forward(x32, pk, B, T):
 
 def block_forward(x32, pk, B, T, H, want16=False):
     """ConformerBlock.forward (eval) on the flattened [B*T, D] fp32 stream."""
-    x = ffn_forward(x32, pk["ff1"])
-    x = mhsa_forward(x, pk["mhsa"], B, T, H)
-    x = convmod_forward(x, pk["conv"], B, T)
-    x = ffn_forward(x, pk["ff2"])
+    if _ffn_fusable(x32, pk["ff1"]) and x32.shape[1] == 256:
+        # ff1 and mhsa.layer_norm in one launch; likewise ff2 and final_norm below (the sum ff2 produces is not kept)
+        x, h = ffn_forward_ln(x32, pk["ff1"], pk["mhsa"]["ln_w"], pk["mhsa"]["ln_b"], False, True)
+        x = mhsa_forward(x, pk["mhsa"], B, T, H, h=h)
+        x = convmod_forward(x, pk["conv"], B, T)
+        if not want16 and _ffn_fusable(x, pk["ff2"]):
+            return ffn_forward_ln(x, pk["ff2"], pk["fn_w"], pk["fn_b"], True, False)[1]
+        x = ffn_forward(x, pk["ff2"])
+    else:
+        x = ffn_forward(x32, pk["ff1"])
+        x = mhsa_forward(x, pk["mhsa"], B, T, H)
+        x = convmod_forward(x, pk["conv"], B, T)
+        x = ffn_forward(x, pk["ff2"])
     out = torch.empty_like(x)
     out16 = torch.empty(x.shape, device=x.device, dtype=ops.compute_dtype()) if want16 else None
     ops.layernorm(x, pk["fn_w"], pk["fn_b"], out16=out16, out32=out)

@@ -50,6 +50,8 @@ SIGNATURES = {
     "sfm_pack_spec": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_vp],
     "sfm_sinc_filters": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_f, c_vp],
     "sfm_ffn_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_i, c_vp],
+    "sfm_ffn_fused_ln": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_f, c_vp, c_vp, c_vp, c_i, c_i,
+                         c_vp],
     "sfm_sinc_fir16_tiles": [c_i],
     "sfm_sinc_fir16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_framed_gemm_split16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll,

@@ -451,6 +451,21 @@ def ffn_fused(x32, lnw, lnb, w1_16, b1, w2_16, b2, alpha=0.5, eps=1e-5, out=None
     return out
 
 
+def ffn_fused_ln(x32, lnw, lnb, w1_16, b1, w2_16, b2, ln2w, ln2b, ln_f32, want_y=True, alpha=0.5, eps=1e-5):
+    """ffn_fused + the LayerNorm that follows the module (ln2w / ln2b) applied in the epilogue.
+    Returns (y fp32 or None, LN(y) as fp32 or 16-bit)."""
+    _need_dev(x32)
+    Lb = _lib.load()
+    M, D = x32.shape
+    FF = w1_16.shape[0]
+    y = torch.empty_like(x32) if want_y else None
+    ln = torch.empty(M, D, device=x32.device, dtype=torch.float32 if ln_f32 else _state["dtype"])
+    _call("ffn_fused", Lb.sfm_ffn_fused_ln, (_p(x32), _p(lnw), _p(lnb), _p(w1_16), _p(b1), _p(w2_16), _p(b2), _p(y), M, D, FF,
+                                             float(alpha), float(eps), _p(ln2w), _p(ln2b), _p(ln), 1 if ln_f32 else 0, _dt(),
+                                             _stream()), 4.0 * M * D * FF, M * D * (8.0 if want_y else 4.0) + M * D * (4.0 if ln_f32 else 2.0))
+    return y, ln
+
+
 def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True):
     """SincConv1d FIR on split 16-bit operands -> out [B, L, C] channels-last (+ GroupNorm partials)."""
     Lb = _lib.load()
