@@ -35,6 +35,21 @@ class HipModule(torch.nn.Module):
         if p is not None and not p.is_cuda:
             raise RuntimeError("%s: parameters are on CPU; call .cuda() first" % type(self).__name__)
 
+    def enable_eval_autograd(self, flag=True):
+        """eval() normally runs the fused inference kernels and records no autograd graph (also when parameters require
+        grad, which they do by default: inference code that forgets torch.no_grad() must not pay for a training
+        forward).  With this flag - or whenever an INPUT requires grad - eval() runs the autograd nodes instead
+        (dropout off, BatchNorm on running statistics), as the reference's modules would under autograd."""
+        for m in self.modules():
+            if isinstance(m, HipModule):
+                m.__dict__["_sfm_eval_autograd"] = bool(flag)
+        return self
+
+    def _wants_autograd(self, *inputs):
+        if not torch.is_grad_enabled():
+            return False
+        return self.__dict__.get("_sfm_eval_autograd", False) or any(t.requires_grad for t in inputs)
+
     def _require_inference(self):
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError(

@@ -87,7 +87,7 @@ class ConformerBlock(HipModule):
 
     def forward(self, x):
         self._require_device(x)
-        if self.training:
+        if self.training or self._wants_autograd(x):
             return self._train_forward(x)
         pk = self._packed(lambda sd: Fn.pack_block(sd, self.num_heads))
         B, T, D = x.shape
@@ -104,8 +104,11 @@ class ConformerBlock(HipModule):
         params = [named[k] for k in train.PARAM_NAMES]
         bn = self.conv.batch_norm
         buffers = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        meta = (self.num_heads, float(self.ff1.dropout.p), seed, buffers, float(bn.momentum or 0.1), float(bn.eps))
+        # eval() with autograd (gradient-based analysis, fine-tuning with frozen statistics): no dropout, BatchNorm on its
+        # running statistics, same backward kernels
+        p = float(self.ff1.dropout.p) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+        meta = (self.num_heads, p, seed, buffers, float(bn.momentum or 0.1), float(bn.eps), not self.training)
         return train.ConformerBlockFunction.apply(x, meta, *params)
 
 
@@ -147,7 +150,7 @@ class ComplexConformer(HipModule):
 
     def forward(self, stft_real, stft_imag):
         self._require_device(stft_real, stft_imag)
-        if self.training:
+        if self.training or self._wants_autograd(stft_real, stft_imag):
             return self._train_forward(stft_real, stft_imag)
         pk = self._packed(lambda sd: Fn.pack_complex_conformer(sd, self.num_blocks, self.num_heads))
         return Fn.complex_conformer_forward(stft_real.float(), stft_imag.float(), pk, self.num_heads)

@@ -576,15 +576,17 @@ def col_stats(y32, aux=None, mean=None, rstd=None):
     return S
 
 
-def bn_swish_bwd(g, y32, mean, rstd, gamma, beta):
-    """backward through Swish(BatchNorm_train(y)): returns dy [M,C] fp32, dgamma, dbeta."""
+def bn_swish_bwd(g, y32, mean, rstd, gamma, beta, eval_mode=False):
+    """backward through Swish(BatchNorm(y)): returns dy [M,C] fp32, dgamma, dbeta.  eval_mode: mean / rstd are the
+    running statistics (constants), so dy carries no batch-statistics correction."""
     L = _lib.load()
     M, C = y32.shape
     S = torch.zeros(C, 2, device=y32.device, dtype=torch.float32)
     dy = torch.empty_like(y32)
     gf = 1 if g.dtype == torch.float32 else 0
     for ps in (0, 1):
-        _call("bn_swish_bwd", L.sfm_bn_swish_bwd, (_p(g), _p(y32), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(S), _p(dy), M, C, gf,
+        Sx = torch.zeros_like(S) if (eval_mode and ps == 1) else S
+        _call("bn_swish_bwd", L.sfm_bn_swish_bwd, (_p(g), _p(y32), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(Sx), _p(dy), M, C, gf,
                                                    ps, _dt(), _stream()))
     return dy, S[:, 1].contiguous(), S[:, 0].contiguous()
 

@@ -136,7 +136,7 @@ def _mhsa_bwd(dy, c, G):
 # ---------------------------------------------------------------------------
 # ConvolutionModule (models/conformer.py:101-128), BatchNorm1d in training mode
 # ---------------------------------------------------------------------------
-def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5):
+def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5, bn_eval=False):
     dt = ops.compute_dtype()
     M, D = x.shape
     lw, lb = _f32(P["conv.layer_norm.weight"]), _f32(P["conv.layer_norm.bias"])
@@ -153,11 +153,14 @@ def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5):
     ones = torch.ones(D, device=x.device)
     yc = torch.empty(M, D, device=x.device, dtype=torch.float32)
     ops.dwconv_folded(g16, wdw.t().contiguous(), ones, bdw, B, T, D, out=yc, act=0)   # conv + bias, fp32
-    S = ops.col_stats(yc)
-    mean = S[:, 0] / M
-    var = (S[:, 1] / M - mean * mean).clamp_min(0.0)
+    if bn_eval:                                                              # eval(): the running statistics, no update
+        mean, var = bn_buffers[0].detach().float(), bn_buffers[1].detach().float()
+    else:
+        S = ops.col_stats(yc)
+        mean = S[:, 0] / M
+        var = (S[:, 1] / M - mean * mean).clamp_min(0.0)
     rstd = torch.rsqrt(var + eps)
-    if bn_buffers is not None:                                               # running statistics (unbiased var), momentum 0.1
+    if bn_buffers is not None and not bn_eval:                               # running statistics (unbiased var), momentum 0.1
         rm, rv, nbt = bn_buffers
         with torch.no_grad():
             rm.mul_(1 - momentum).add_(momentum * mean.to(rm.dtype))
@@ -170,7 +173,7 @@ def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5):
     sd = seeds.next()
     y = _resid_gemm(s16, f2, x, 1.0, p, sd)
     return y, dict(x=x, lw=lw, h16=h16, pre=pre, g16=g16, yc=yc, mean=mean, rstd=rstd, gam=gam, bet=bet, s16=s16, b1=b1, b2=b2,
-                   wdw=wdw, KS=KS, sd=sd, p=p, B=B, T=T)
+                   wdw=wdw, KS=KS, sd=sd, p=p, B=B, T=T, bn_eval=bn_eval)
 
 
 def _conv_bwd(dy, c, G):
@@ -181,7 +184,7 @@ def _conv_bwd(dy, c, G):
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=1.0, p=c["p"], seed=c["sd"])
     ops.gemm16_tn(do, c["s16"], G["conv.pointwise2.weight"].view(D, D), G["conv.pointwise2.bias"])
     ds = ops.linear16(do, c["b2"], out_dtype=torch.float32)
-    dyc, dgam, dbet = ops.bn_swish_bwd(ds, c["yc"], c["mean"], c["rstd"], c["gam"], c["bet"])
+    dyc, dgam, dbet = ops.bn_swish_bwd(ds, c["yc"], c["mean"], c["rstd"], c["gam"], c["bet"], eval_mode=c["bn_eval"])
     G["conv.batch_norm.weight"] += dgam
     G["conv.batch_norm.bias"] += dbet
     dw, db = ops.dwconv_wgrad(c["g16"], dyc, B, T, D, KS)
@@ -203,11 +206,11 @@ def _conv_bwd(dy, c, G):
 # ---------------------------------------------------------------------------
 # whole block
 # ---------------------------------------------------------------------------
-def block_train_forward(x32, P, B, T, H, p, seed, bn_buffers=None, momentum=0.1, eps=1e-5):
+def block_train_forward(x32, P, B, T, H, p, seed, bn_buffers=None, momentum=0.1, eps=1e-5, bn_eval=False):
     seeds = _Seeds(seed)
     x1, c1 = _ffn_fwd(x32, P, "ff1.", p, seeds)
     x2, c2 = _mhsa_fwd(x1, P, B, T, H, p, seeds)
-    x3, c3 = _conv_fwd(x2, P, B, T, p, seeds, bn_buffers, momentum, eps)
+    x3, c3 = _conv_fwd(x2, P, B, T, p, seeds, bn_buffers, momentum, eps, bn_eval)
     x4, c4 = _ffn_fwd(x3, P, "ff2.", p, seeds)
     fw, fb = _f32(P["final_norm.weight"]), _f32(P["final_norm.bias"])
     y = torch.empty_like(x4)
@@ -231,10 +234,10 @@ class ConformerBlockFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *params):
         B, T, D = x.shape
-        H, p, seed, bn_buffers, momentum, eps = meta
+        H, p, seed, bn_buffers, momentum, eps, bn_eval = meta
         P = dict(zip(PARAM_NAMES, params))
         x32 = x.detach().float().reshape(B * T, D).contiguous()
-        y, saved = block_train_forward(x32, P, B, T, H, p, seed, bn_buffers, momentum, eps)
+        y, saved = block_train_forward(x32, P, B, T, H, p, seed, bn_buffers, momentum, eps, bn_eval)
         ctx.saved, ctx.P, ctx.in_dtype, ctx.shape = saved, P, x.dtype, (B, T, D)
         ctx.param_dtypes = [t.dtype for t in params]
         return y.reshape(B, T, D).to(x.dtype)

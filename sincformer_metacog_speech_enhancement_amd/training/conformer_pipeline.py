@@ -83,7 +83,7 @@ class SpeechEnhancer(HipModule):
 
     def forward(self, noisy_real, noisy_imag):
         self._require_device(noisy_real, noisy_imag)
-        if self.training:
+        if self.training or self._wants_autograd(noisy_real, noisy_imag):
             return self._train_forward(noisy_real, noisy_imag)
         pk = self._packed(self._pack)
         nr, ni = noisy_real.float().contiguous(), noisy_imag.float().contiguous()

@@ -472,3 +472,37 @@ def test_speech_enhancer_fp16_with_torch_gradscaler():
         hist.append(float(loss.detach()))
     print("fp16 + GradScaler loss history", ["%.3f" % h for h in hist], "scale", scaler.get_scale())
     assert hist[-1] < hist[0] - 0.2
+
+
+def test_eval_mode_autograd_uses_running_statistics():
+    """eval() + an input that requires grad (or enable_eval_autograd()): dropout off, BatchNorm on its running statistics,
+    gradients equal torch autograd of the oracle's eval-mode block; plain eval() calls stay on the inference kernels."""
+    from sincformer_metacog_speech_enhancement_amd import ops, train
+    ops.set_compute_dtype(torch.float16)
+    m, sd = _block(0.2, seed=37)
+    m.eval()
+    x = arr("ex", (2, 90, 256), 38, 1.0)
+    dy = arr("edy", (2, 90, 256), 39, 1.0)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = orc.conformer_block(xr, ref_sd, 4)                      # eval-mode oracle: running statistics
+    yr.backward(dy)
+    rm0 = m.conv.batch_norm.running_mean.clone()
+    y_plain = m(x.cuda())                                        # parameters require grad, the input does not: inference path
+    assert y_plain.grad_fn is None
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    assert y.grad_fn is not None
+    y.backward(dy.cuda())
+    assert torch.equal(rm0, m.conv.batch_norm.running_mean)     # eval: no running-stat update
+    assert rmse(y.detach().cpu(), yr.detach()) < 2e-3 and rmse(y_plain.cpu(), yr.detach()) < 2e-3
+    assert _rel(xg.grad.cpu(), xr.grad) < 0.01
+    named = dict(m.named_parameters())
+    for k in train.PARAM_NAMES:
+        r = _rel(named[k].grad.cpu(), ref_sd[k].grad)
+        assert r < 0.01, (k, r)
+    m.zero_grad()
+    m.enable_eval_autograd()
+    y2 = m(x.cuda())
+    assert y2.grad_fn is not None
