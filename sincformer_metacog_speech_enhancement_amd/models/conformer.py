@@ -13,6 +13,21 @@ from .. import config, functional as Fn
 from .._hostmod import HipModule
 
 
+def _submodule_autograd(mod, kind, x, heads, p, bn):
+    """train() mode (or eval() under autograd) of a stand-alone Conformer sub-module: one HIP autograd node."""
+    from .. import train
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    named = dict(mod.named_parameters())
+    params = [named[k] for k in train.submodule_param_names(kind)]
+    p = float(p) if mod.training else 0.0
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+    buffers = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if (bn is not None and bn.track_running_stats) else None
+    meta = (kind, heads, p, seed, buffers, float(bn.momentum or 0.1) if bn is not None else 0.1,
+            float(bn.eps) if bn is not None else 1e-5, not mod.training)
+    return train.SubmoduleFunction.apply(x, meta, *params)
+
+
 class FeedForwardModule(HipModule):
     """models/conformer.py:28-49 — LN -> Linear -> Swish -> Linear, half-step residual."""
 
@@ -25,7 +40,8 @@ class FeedForwardModule(HipModule):
 
     def forward(self, x):
         self._require_device(x)
-        self._require_inference()
+        if self.training or self._wants_autograd(x):
+            return _submodule_autograd(self, "ffn", x, 1, self.dropout.p, None)
         pk = self._packed(Fn.pack_ffn)
         shp = x.shape
         y = Fn.ffn_forward(x.float().reshape(-1, shp[-1]).contiguous(), pk)
@@ -44,7 +60,8 @@ class MultiHeadSelfAttention(HipModule):
 
     def forward(self, x):
         self._require_device(x)
-        self._require_inference()
+        if self.training or self._wants_autograd(x):
+            return _submodule_autograd(self, "mhsa", x, self.num_heads, self.dropout.p, None)
         pk = self._packed(lambda sd: Fn.pack_mhsa(sd, self.num_heads))
         B, T, D = x.shape
         y = Fn.mhsa_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T, self.num_heads)
@@ -65,7 +82,8 @@ class ConvolutionModule(HipModule):
 
     def forward(self, x):
         self._require_device(x)
-        self._require_inference()
+        if self.training or self._wants_autograd(x):
+            return _submodule_autograd(self, "conv", x, 1, self.dropout.p, self.batch_norm)
         pk = self._packed(Fn.pack_convmod)
         B, T, D = x.shape
         y = Fn.convmod_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T)

@@ -481,3 +481,57 @@ class ComplexMulFunction(torch.autograd.Function):
         ctx.saved = None
         return (dsr.reshape(sr.shape).to(t[0]), dsi.reshape(sr.shape).to(t[1]), dmr.reshape(sr.shape).to(t[2]),
                 dmi.reshape(sr.shape).to(t[3]))
+
+
+# ---------------------------------------------------------------------------
+# stand-alone sub-modules (models/conformer.py:28-128) in training mode: the same forward / backward pieces as the block
+# ---------------------------------------------------------------------------
+_SUB = {
+    "ffn": ("ff1.", ["layer_norm.weight", "layer_norm.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias"]),
+    "mhsa": ("mhsa.", ["layer_norm.weight", "layer_norm.bias", "attention.in_proj_weight", "attention.in_proj_bias",
+                       "attention.out_proj.weight", "attention.out_proj.bias"]),
+    "conv": ("conv.", ["layer_norm.weight", "layer_norm.bias", "pointwise1.weight", "pointwise1.bias", "depthwise.weight",
+                       "depthwise.bias", "batch_norm.weight", "batch_norm.bias", "pointwise2.weight", "pointwise2.bias"]),
+}
+
+
+def submodule_param_names(kind):
+    return list(_SUB[kind][1])
+
+
+class SubmoduleFunction(torch.autograd.Function):
+    """FeedForwardModule / MultiHeadSelfAttention / ConvolutionModule in train() mode (or eval() under autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        kind, H, p, seed, bn_buffers, momentum, eps, bn_eval = meta
+        prefix, names = _SUB[kind]
+        B, T, D = x.shape
+        P = {prefix + n: t for n, t in zip(names, params)}
+        x32 = x.detach().float().reshape(B * T, D).contiguous()
+        seeds = _Seeds(seed)
+        if kind == "ffn":
+            y, c = _ffn_fwd(x32, P, prefix, p, seeds)
+        elif kind == "mhsa":
+            y, c = _mhsa_fwd(x32, P, B, T, H, p, seeds)
+        else:
+            y, c = _conv_fwd(x32, P, B, T, p, seeds, bn_buffers, momentum, eps, bn_eval)
+        ctx.saved, ctx.P, ctx.kind = c, P, kind
+        ctx.shape, ctx.in_dtype, ctx.param_dtypes = (B, T, D), x.dtype, [t.dtype for t in params]
+        return y.reshape(B, T, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, D = ctx.shape
+        prefix, names = _SUB[ctx.kind]
+        G = {prefix + n: torch.zeros(ctx.P[prefix + n].shape, device=dy.device, dtype=torch.float32) for n in names}
+        d = dy.detach().float().reshape(B * T, D).contiguous()
+        if ctx.kind == "ffn":
+            dx = _ffn_bwd(d, ctx.saved, G, prefix)
+        elif ctx.kind == "mhsa":
+            dx = _mhsa_bwd(d, ctx.saved, G)
+        else:
+            dx = _conv_bwd(d, ctx.saved, G)
+        grads = [G[prefix + n].to(t) for n, t in zip(names, ctx.param_dtypes)]
+        ctx.saved = None
+        return (dx.reshape(B, T, D).to(ctx.in_dtype), None) + tuple(grads)
