@@ -132,6 +132,10 @@ int sfm_transpose(const void* src, void* dst, int B, int R, int C, long long src
                   long long dst_batch, long long dst_row, int src_f32, int dst_f32, int dtype, void* stream);
 int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, int Tout, int C,
                   long long ld_src, long long ld_dst, int dtype, void* stream);
+/* as sfm_pool_time with out = scale[b, c] * avg + shift[b, c]: pooled GroupNorm'd latents straight from the raw layer
+ * output (glue G1 applied to agents/perception.py:244-246 without materialising the full-rate normalised tensor) */
+int sfm_pool_time_affine(const float* src, const float* scale, const float* shift, void* dst16, float* dst32, int B,
+                         int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype, void* stream);
 /* agents/msa.py:134-137 */
 int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst, long long M, int F, int zpad,
                           long long ld_dst, int dtype, void* stream);

@@ -478,7 +478,8 @@ extern "C" int sfm_transpose(const void* src, void* dst, int B, int R, int C, lo
 // -> dst 16-bit [B, Tout, ld_dst] cols [0, C).  window i = [floor(i*Tin/Tout), ceil((i+1)*Tin/Tout))
 template <class T>
 __global__ __launch_bounds__(256) void pool_time_kernel(const float* __restrict__ src, u16* dst16, float* dst32,
-                                                        int Tin, int Tout, int C, long long ld_src, long long ld_dst) {
+                                                        int Tin, int Tout, int C, long long ld_src, long long ld_dst,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift) {
   const int b = blockIdx.z, i = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
@@ -487,24 +488,34 @@ __global__ __launch_bounds__(256) void pool_time_kernel(const float* __restrict_
   float acc = 0.f;
   for (long long t = s; t < e; ++t) acc += src[((long long)b * Tin + t) * ld_src + c];
   acc /= (float)(e - s);
+  if (scale) acc = acc * scale[(long long)b * C + c] + shift[(long long)b * C + c];   // affine commutes with the average
   long long o = ((long long)b * Tout + i) * ld_dst + c;
   if (dst16) dst16[o] = T::from_f32(acc);
   if (dst32) dst32[o] = acc;
 }
 
-extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, int Tout, int C,
-                             long long ld_src, long long ld_dst, int dtype, void* stream) {
-  if (!src || (!dst16 && !dst32)) return SFM_ERR_ARG;
+// sfm_pool_time_affine: out = scale[b, c] * avg(src) + shift[b, c].  Pooling the RAW output of a GroupNorm'd layer with
+// the layer's per-(utterance, channel) scale / shift gives the pooled normalised latents without ever writing the
+// full-rate normalised tensor (the real / imag latent heads of the PerceptionAgent have no activation after the norm).
+extern "C" int sfm_pool_time_affine(const float* src, const float* scale, const float* shift, void* dst16, float* dst32,
+                                    int B, int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype,
+                                    void* stream) {
+  if (!src || (!dst16 && !dst32) || ((scale == nullptr) != (shift == nullptr))) return SFM_ERR_ARG;
   if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return SFM_ERR_SHAPE;
   dim3 grid((C + 255) / 256, Tout, B), block(256);
   if (dtype == SFM_DT_F16)
     SFM_LAUNCH((pool_time_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin, Tout,
-                       C, ld_src, ld_dst);
+                       C, ld_src, ld_dst, scale, shift);
   else
     SFM_LAUNCH((pool_time_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin,
-                       Tout, C, ld_src, ld_dst);
+                       Tout, C, ld_src, ld_dst, scale, shift);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
+}
+
+extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, int Tout, int C,
+                             long long ld_src, long long ld_dst, int dtype, void* stream) {
+  return sfm_pool_time_affine(src, nullptr, nullptr, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, dtype, stream);
 }
 
 // log1p-magnitude normalisation of the noisy STFT (agents/msa.py:134-137) written as

@@ -330,7 +330,7 @@ def _conv_gn(x16, pw, B, Lin, stride, pad, groups, raw_dtype):
     return raw, part, P, Lout
 
 
-def perception_forward(wave, pk, keep_sinc=False):
+def perception_forward(wave, pk, keep_sinc=False, latents=True):
     """wave [B, L] fp32 -> zcat [B, T_pa, 2D] fp32 (z_real | z_imag, channels-last), sigma [B, T_pa] fp32."""
     dt = ops.compute_dtype()
     wave = wave.contiguous()
@@ -374,8 +374,13 @@ def perception_forward(wave, pk, keep_sinc=False):
     # complex latent heads: one GEMM for (real | imag), GroupNorm(16) per half = 32 groups over 2D channels
     rz, pz, Pz, _ = _conv_gn(xd, pk["zproj"], B, Tpa, 1, 0, 32, torch.float32)
     sz, hz = ops.gn_finalize(pz, pk["z_w"], pk["z_b"], B, Pz, 32, 2 * D, Tpa)
-    zcat = torch.empty(B, Tpa, 2 * D, device=dev, dtype=torch.float32)
-    ops.gn_apply(rz, sz, hz, zcat, B, Tpa, 2 * D, act=0)
+    if latents:
+        zcat = torch.empty(B, Tpa, 2 * D, device=dev, dtype=torch.float32)
+        ops.gn_apply(rz, sz, hz, zcat, B, Tpa, 2 * D, act=0)
+    else:
+        # latents=False: the caller only pools the latents (glue G1); GroupNorm without activation is affine per
+        # (utterance, channel), so it commutes with the average: hand back raw output + scale/shift instead
+        zcat = (rz, sz, hz)
     # uncertainty head
     u = torch.empty(B, Tpa, pk["u0"].N, device=dev, dtype=dt)
     ops.gemm16(xd, pk["u0"], u, B=B, Lout=Tpa, Lin=Tpa, a_batch_stride=Tpa * D, ldo=pk["u0"].N,
@@ -515,11 +520,13 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     M = B * T
     pa = packs["pa"]
     D = pa["D"]
-    zcat, sigma = perception_forward(wave, pa)                         # [B, Tpa, 2D] fp32
-    Tpa = zcat.shape[1]
+    want_lat = "latents" in want
+    zcat, sigma = perception_forward(wave, pa, latents=want_lat)       # [B, Tpa, 2D] fp32 (or raw + GroupNorm affine)
+    zsrc, zsc, zsh = (zcat, None, None) if want_lat else zcat
+    Tpa = zsrc.shape[1]
     fused = torch.empty(M, FUSE_LD, device=dev, dtype=dt)
     zpool = torch.empty(B, T, 2 * D, device=dev, dtype=torch.float32) if use_memory else None
-    ops.pool_time(zcat, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD)  # G1 -> fused[:, :2D]
+    ops.pool_time(zsrc, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD, scale=zsc, shift=zsh)   # G1 -> fused[:, :2D]
     oc4 = 4 * packs["cpea"]["oc"]
     cpea_forward(fused, packs["cpea"], B, T, out=fused[:, 2 * D:2 * D + oc4])   # CPEA(z_real pooled) -> fused cols
     nr, ni = stft(wave)
@@ -528,7 +535,7 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     bias = None
     out = {}
     if use_memory:
-        ops.pool_time(zcat, None, zpool, B, Tpa, T, 2 * D, 2 * D, 2 * D)
+        ops.pool_time(zsrc, None, zpool, B, Tpa, T, 2 * D, 2 * D, 2 * D, scale=zsc, shift=zsh)
         emb = torch.empty(B, 1, 2 * D, device=dev, dtype=torch.float32)
         ops.pool_time(zpool, None, emb, B, T, 1, 2 * D, 2 * D, 2 * D)   # G2: key = mean over frames
         params, kd, vd, slots, temp = packs["memory"]
@@ -542,7 +549,9 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     spec = torch.zeros(M, ld, device=dev, dtype=torch.float32)
     ops.polar_mask(lm, lp, B, T, N_FREQ, PHASE_SCALE_MSA, lm.stride(0), mag_bias=bias, nr=nr, ni=ni, mr=mr, mi=mi,
                    er=spec, ei=spec[:, N_FREQ:], ld_enh=ld)            # G3 bias; enhanced spectrum packed for iSTFT
-    out.update(mask_real=mr, mask_imag=mi, sigma=sigma, zcat=zcat, noisy_real=nr, noisy_imag=ni, spec=spec)
+    out.update(mask_real=mr, mask_imag=mi, sigma=sigma, noisy_real=nr, noisy_imag=ni, spec=spec)
+    if want_lat:
+        out["zcat"] = zcat
     if "wave" in want:
         out["enhanced"] = istft_from_packed(spec, B, T, L)
     return out

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sfm_convert_rows": [c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_transpose": [c_vp, c_vp, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_vp],
     "sfm_pool_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
+    "sfm_pool_time_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_stft_lognorm_pack": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_i, c_vp],
     "sfm_polar_mask": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_f, c_ll, c_ll,
                        c_vp],

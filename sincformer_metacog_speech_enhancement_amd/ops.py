@@ -386,9 +386,11 @@ def transpose(src, dst, B, R, C, src_batch, src_row, dst_batch, dst_row):
           *_cost_of("transpose", locals()))
 
 
-def pool_time(src32, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst):
+def pool_time(src32, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, scale=None, shift=None):
+    """adaptive average pooling over time; scale / shift [B, C]: out = scale * avg + shift (pooled GroupNorm output)"""
     L = _lib.load()
-    _call("pool_time", L.sfm_pool_time, (_p(src32), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src, ld_dst, _dt(), _stream()),
+    _call("pool_time", L.sfm_pool_time_affine, (_p(src32), _p(scale), _p(shift), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src,
+                                                ld_dst, _dt(), _stream()),
           *_cost_of("pool_time", locals()))
 
 
