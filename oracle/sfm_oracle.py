@@ -327,7 +327,7 @@ def _num_blocks(sd, prefix="blocks."):
     return (max(ids) + 1) if ids else 0
 
 
-def complex_conformer_forward(sd, stft_real, stft_imag, num_heads):
+def complex_conformer_forward(sd, stft_real, stft_imag, num_heads, bn_train=False):
     """ComplexConformer.forward — models/conformer.py:193-228."""
     sd = {k: _t(v) for k, v in sd.items()}
     x = torch.cat([_t(stft_real), _t(stft_imag)], dim=-1)
@@ -335,7 +335,7 @@ def complex_conformer_forward(sd, stft_real, stft_imag, num_heads):
     x = linear(x, sd["input_proj.weight"], sd["input_proj.bias"])
     skip = x
     for i in range(_num_blocks(sd)):
-        x = conformer_block(x, sub(sd, "blocks.%d" % i), num_heads)
+        x = conformer_block(x, sub(sd, "blocks.%d" % i), num_heads, bn_train)
     x = x + skip
     x = linear(x, sd["output_proj.weight"], sd["output_proj.bias"])
     return x[..., :n_freq], x[..., n_freq:]
@@ -351,7 +351,7 @@ def apply_mask(sr, si, mr, mi):
 # MaskSynthesisAgent (agents/msa.py:106-174)
 # ----------------------------------------------------------------------------
 def msa_forward(sd, z_real, z_imag, cpea, noisy_real, noisy_imag, num_heads=4,
-                mag_logit_bias=None, return_logits=False):
+                mag_logit_bias=None, return_logits=False, bn_train=False):
     """MaskSynthesisAgent.forward.  z_* [B, D, T]; cpea dict of [B, T, 64];
     noisy_* [B, T, 129].  mag_logit_bias (optional [B,129]) is the build-defined
     injection point of the episodic-memory bias (DESIGN.md glue G3): added to
@@ -370,7 +370,7 @@ def msa_forward(sd, z_real, z_imag, cpea, noisy_real, noisy_imag, num_heads=4,
     h = linear(h, sd["fusion.3.weight"], sd["fusion.3.bias"])
     h = layer_norm(h, sd["fusion.4.weight"], sd["fusion.4.bias"])
     d_half = h.shape[-1] // 2
-    mr, mi = complex_conformer_forward(sub(sd, "conformer"), h[..., :d_half], h[..., d_half:], num_heads)
+    mr, mi = complex_conformer_forward(sub(sd, "conformer"), h[..., :d_half], h[..., d_half:], num_heads, bn_train)
     lm = linear(gelu(linear(mr, sd["mask_proj_real.0.weight"], sd["mask_proj_real.0.bias"])),
                 sd["mask_proj_real.2.weight"], sd["mask_proj_real.2.bias"])
     lp = linear(gelu(linear(mi, sd["mask_proj_imag.0.weight"], sd["mask_proj_imag.0.bias"])),

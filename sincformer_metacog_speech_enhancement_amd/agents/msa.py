@@ -39,10 +39,13 @@ class MaskSynthesisAgent(HipModule):
         """Returns (mask_real, mask_imag), each [B, T, n_freq] fp32.  `mag_logit_bias` ([B, n_freq],
         optional, build-defined glue G3) is added to the magnitude logit before the sigmoid."""
         self._require_device(z_real, z_imag, noisy_stft_real, noisy_stft_imag)
-        self._require_inference()
         if z_real.shape[-1] != noisy_stft_real.shape[1]:
             raise RuntimeError("Sizes of tensors must match except in dimension 2. Expected size %d but got size %d "
                                "(latents must be at the STFT frame rate)" % (z_real.shape[-1], noisy_stft_real.shape[1]))
+        if self.training or self._wants_autograd(z_real, z_imag, *cpea_outputs.values()):
+            from .. import train                   # train() (or eval() under autograd): HIP autograd nodes
+            return train.msa_train_forward(self, z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag,
+                                           mag_logit_bias)
         pk = self._packed(lambda sd: Fn.pack_msa(sd, self.conformer.num_blocks, self.conformer.num_heads))
         return Fn.msa_forward(z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag, pk,
                               self.conformer.num_heads, mag_bias=mag_logit_bias)

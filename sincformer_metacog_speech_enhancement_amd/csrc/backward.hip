@@ -136,6 +136,8 @@ extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float
 //   mode 2  GLU_FWD   : out16 = a * sigmoid(b)                       z = [a | b] 16-bit [M, 2N]
 //   mode 3  GLU_BWD   : out16[M, 2N] = [ g*sigmoid(b) | g*a*sigmoid(b)*(1-sigmoid(b)) ]
 //   mode 4  SCALE_DROP: out(fp32|16) = [z fp32 +] alpha * g * drop   (residual-branch dropout, fwd and bwd)
+//   mode 5  GELU_FWD  : out(fp32|16) = gelu(z)                         z fp32 [M, N], exact erf
+//   mode 6  GELU_BWD  : out(fp32|16) = g * gelu'(z)                    z fp32, g fp32 or 16-bit
 // `drop` = counter-based keep/(1-p) with element index m*N+n (p == 0 -> 1).
 // ---------------------------------------------------------------------------
 template <class T>
@@ -165,6 +167,13 @@ __global__ __launch_bounds__(256) void ew_train_kernel(const void* __restrict__ 
         orow[n] = T::from_f32(gv * sg);
         orow[N + n] = T::from_f32(gv * a * sg * (1.0f - sg));
       }
+    } else if (mode == 5 || mode == 6) {
+      // exact-erf GELU on an fp32 operand (fusion MLP / mask heads of agents/msa.py:42-71): forward, or g * gelu'(z)
+      const float zv = reinterpret_cast<const float*>(z)[e];
+      const float cdf = 0.5f * (1.0f + erff(zv * 0.70710678118654752440f));
+      const float r = (mode == 5) ? zv * cdf : gv * (cdf + zv * 0.39894228040143267794f * __expf(-0.5f * zv * zv));
+      if (out_f32) reinterpret_cast<float*>(out)[e] = r;
+      else reinterpret_cast<u16*>(out)[e] = T::from_f32(r);
     } else {
       float r = alpha * gv * dr;
       if (z) r += reinterpret_cast<const float*>(z)[e];          // mode 4: optional fp32 residual
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256) void ew_train_vec_kernel(const void* __restric
 template <class T>
 static int ew_train_launch(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                            float alpha, float p, unsigned int seed, hipStream_t st) {
-  const bool aligned = (N % 8 == 0) && (((uintptr_t)z | (uintptr_t)g | (uintptr_t)out) % 16 == 0);
+  const bool aligned = (mode <= 4) && (N % 8 == 0) && (((uintptr_t)z | (uintptr_t)g | (uintptr_t)out) % 16 == 0);
   if (!aligned) {
     long long nb = (M * N + 255) / 256;
     if (nb > 16384) nb = 16384;
@@ -291,8 +300,8 @@ static int ew_train_launch(const void* z, const void* g, void* out, long long M,
 
 extern "C" int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                             float alpha, float p, unsigned int seed, int dtype, void* stream) {
-  if (!out || (mode <= 3 && !z) || ((mode == 1 || mode == 3 || mode == 4) && !g)) return SFM_ERR_ARG;
-  if (M <= 0 || N <= 0 || mode < 0 || mode > 4 || p < 0.f || p >= 1.f) return SFM_ERR_SHAPE;
+  if (!out || ((mode <= 3 || mode >= 5) && !z) || ((mode == 1 || mode == 3 || mode == 4 || mode == 6) && !g)) return SFM_ERR_ARG;
+  if (M <= 0 || N <= 0 || mode < 0 || mode > 6 || p < 0.f || p >= 1.f) return SFM_ERR_SHAPE;
   if (dtype == SFM_DT_F16) return ew_train_launch<F16>(z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed, (hipStream_t)stream);
   return ew_train_launch<BF16>(z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed, (hipStream_t)stream);
 }

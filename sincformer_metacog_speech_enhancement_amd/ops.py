@@ -557,7 +557,7 @@ def layernorm_bwd(x32, gamma, dy32, dres32, dgamma, dbeta, eps=1e-5):
     return dx
 
 
-EW_SWISH_FWD, EW_SWISH_BWD, EW_GLU_FWD, EW_GLU_BWD, EW_SCALE_DROP = range(5)
+EW_SWISH_FWD, EW_SWISH_BWD, EW_GLU_FWD, EW_GLU_BWD, EW_SCALE_DROP, EW_GELU_FWD, EW_GELU_BWD = range(7)
 
 
 def ew_train(mode, out, z=None, g=None, N=None, alpha=1.0, p=0.0, seed=0):

@@ -535,3 +535,87 @@ class SubmoduleFunction(torch.autograd.Function):
         grads = [G[prefix + n].to(t) for n, t in zip(names, ctx.param_dtypes)]
         ctx.saved = None
         return (dx.reshape(B, T, D).to(ctx.in_dtype), None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------
+# small nodes for the fusion MLP / mask heads of MaskSynthesisAgent (agents/msa.py:42-71, 134-172)
+# ---------------------------------------------------------------------------
+class GeluFunction(torch.autograd.Function):
+    """exact-erf GELU on fp32 rows [M, N]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x32 = x.detach().float().contiguous()
+        y = torch.empty_like(x32)
+        ops.ew_train(ops.EW_GELU_FWD, y, z=x32)
+        ctx.saved = x32
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32 = ctx.saved
+        dx = torch.empty_like(x32)
+        ops.ew_train(ops.EW_GELU_BWD, dx, z=x32, g=dy.detach().float().contiguous())
+        ctx.saved = None
+        return dx.to(ctx.in_dtype)
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """nn.LayerNorm on fp32 rows [M, D <= 512], fp32 out"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x32 = x.detach().float().contiguous()
+        lw, lb = _f32(w), _f32(b)
+        y = torch.empty_like(x32)
+        ops.layernorm(x32, lw, lb, out32=y)
+        ctx.saved = (x32, lw)
+        ctx.dtypes = (x.dtype, w.dtype, b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, lw = ctx.saved
+        D = lw.numel()
+        dg = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        dx = ops.layernorm_bwd(x32, lw, dy.detach().float().contiguous(), None, dg, db)
+        t = ctx.dtypes
+        ctx.saved = None
+        return dx.to(t[0]), dg.to(t[1]), db.to(t[2])
+
+
+def msa_train_forward(msa, z_real, z_imag, cpea_outputs, noisy_real, noisy_imag, mag_logit_bias=None):
+    """MaskSynthesisAgent.forward (agents/msa.py:106-174) built from HIP autograd nodes: fusion MLP -> ComplexConformer
+    (its own training / eval-autograd path) -> two GELU heads -> bounded polar mask.  The log1p normalisation of the noisy
+    STFT and the concatenation carry no parameters and run as torch ops on the device (their inputs may carry gradients
+    from a trainable front-end)."""
+    B, D, T = z_real.shape
+    M = B * T
+    nr, ni = noisy_real.float(), noisy_imag.float()
+    mag = torch.sqrt(nr ** 2 + ni ** 2 + 1e-8)
+    nf = torch.log1p(mag) / mag
+    fused = torch.cat([z_real.float().transpose(1, 2), z_imag.float().transpose(1, 2), cpea_outputs["rho_s"].float(),
+                       cpea_outputs["rho_n"].float(), cpea_outputs["phi1"].float(), cpea_outputs["phi2"].float(),
+                       nr * nf, ni * nf], dim=-1).reshape(M, -1)
+    f = msa.fusion
+    x = LNLinearFunction.apply(fused, None, None, f[0].weight, f[0].bias)
+    x = GeluFunction.apply(LayerNormFunction.apply(x, f[1].weight, f[1].bias))
+    x = LNLinearFunction.apply(x, None, None, f[3].weight, f[3].bias)
+    x = LayerNormFunction.apply(x, f[4].weight, f[4].bias)
+    half = x.shape[-1] // 2
+    mask_r, mask_i = msa.conformer(x[:, :half].reshape(B, T, half), x[:, half:].reshape(B, T, half))
+    heads = []
+    for seq, src in ((msa.mask_proj_real, mask_r), (msa.mask_proj_imag, mask_i)):
+        h = LNLinearFunction.apply(src.reshape(M, -1), None, None, seq[0].weight, seq[0].bias)
+        heads.append(LNLinearFunction.apply(GeluFunction.apply(h), None, None, seq[2].weight, seq[2].bias))
+    lm, lp = heads
+    if mag_logit_bias is not None:                                            # glue G3
+        lm = (lm.reshape(B, T, -1) + mag_logit_bias.float().unsqueeze(1)).reshape(M, -1)
+    logits = torch.cat([lm, lp], dim=-1)
+    F = lm.shape[-1]
+    ones = torch.ones(B, T, F, device=logits.device, dtype=torch.float32)
+    # mask = polar(logits) applied to the constant spectrum 1 + 0j: the "enhanced" outputs ARE mask_real, mask_imag
+    mr, mi, _ = PolarMaskFunction.apply(logits, ones, torch.zeros_like(ones), 3.14159 / 8.0)
+    return mr, mi

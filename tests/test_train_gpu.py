@@ -539,3 +539,53 @@ def test_standalone_submodules_train_mode(kind):
         if k == "depthwise.bias":
             continue
         assert _rel(p_.grad.cpu(), ref[k].grad) < 0.01, k
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_mask_synthesis_agent_train_mode(dt):
+    """MaskSynthesisAgent (agents/msa.py:106-174) in train() mode, dropout 0, for a fixed cotangent on the masks: masks,
+    gradients of every parameter and of the latent / CPEA inputs vs torch autograd of the oracle (BatchNorm batch stats)."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.agents import MaskSynthesisAgent
+    ops.set_compute_dtype(dt)
+    sd = synth_sd("MaskSynthesisAgent", 53)
+    m = MaskSynthesisAgent()
+    m.load_state_dict(sd, strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    m.cuda().train()
+    B, T = 2, 45
+    zr, zi = arr("mzr", (B, 256, T), 54), arr("mzi", (B, 256, T), 55)
+    cp = {k: arr("mc" + k, (B, T, 64), 56 + i, 0.5) for i, k in enumerate(("rho_s", "rho_n", "phi1", "phi2"))}
+    nr, ni = arr("mnr", (B, T, 129), 60, 0.5), arr("mni", (B, T, 129), 61, 0.5)
+    cr, ci = arr("mcr2", (B, T, 129), 62), arr("mci2", (B, T, 129), 63)
+    # oracle with autograd (training-mode BatchNorm inside the conformer blocks)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    zr_r, zi_r = zr.clone().requires_grad_(True), zi.clone().requires_grad_(True)
+    cp_r = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
+    mr_o, mi_o = orc.msa_forward(ref_sd, zr_r, zi_r, cp_r, nr, ni, 4, bn_train=True)
+    (mr_o * cr + mi_o * ci).sum().backward()
+    zr_g, zi_g = zr.cuda().requires_grad_(True), zi.cuda().requires_grad_(True)
+    cp_g = {k: v.cuda().requires_grad_(True) for k, v in cp.items()}
+    mr, mi = m(zr_g, zi_g, cp_g, nr.cuda(), ni.cuda())
+    (mr * cr.cuda() + mi * ci.cuda()).sum().backward()
+    e = rmse(torch.cat([mr, mi], -1).detach().cpu(), torch.cat([mr_o, mi_o], -1).detach())
+    print("MSA train-mode masks %s: rmse %.3e" % (dt, e))
+    assert e < (1e-3 if dt is torch.float16 else 4e-3)
+    tol = 0.01 if dt is torch.float16 else 0.06
+    assert _rel(zr_g.grad.cpu(), zr_r.grad) < tol and _rel(zi_g.grad.cpu(), zi_r.grad) < tol
+    for k in cp:
+        assert _rel(cp_g[k].grad.cpu(), cp_r[k].grad) < tol, k
+    worst = ("", 0.0)
+    for k, p_ in m.named_parameters():
+        if k.endswith("depthwise.bias"):
+            continue
+        r = _rel(p_.grad.cpu(), ref_sd[k].grad)
+        if r > worst[1]:
+            worst = (k, r)
+    print("  worst parameter-gradient rel rmse: %s %.3e" % worst)
+    assert worst[1] < tol, worst
