@@ -253,6 +253,13 @@ int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const floa
                       unsigned int seed, int dtype, void* stream);
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
+/* training: as sfm_bilstm_layer, also saving the activated gates and cell states [B, T, 2, 5, H] fp32; and the BPTT of
+ * the layer: dout [B, T, 2H] -> dxg [B, T, 2, 4H] = gradient w.r.t. the input projection (dW_ih, dW_hh, biases and dx
+ * are GEMMs / column sums of dxg afterwards). */
+int sfm_bilstm_layer_train(const float* xg, const float* whh, float* out, float* save, int B, int T, int H, int dtype,
+                           void* stream);
+int sfm_bilstm_layer_bwd(const float* save, const float* whh, const float* dout, float* dxg, int B, int T, int H,
+                         void* stream);
 /* EpisodicMemory.forward eval (agents/memory.py:112-133) in one launch, see memory.hip */
 int sfm_memory_fwd(const float* emb, const float* params, float* bias_out, float* gate_out, int* top_idx,
                    float* sim_out, int B, int key_dim, int value_dim, int slots, float temperature, void* stream);

@@ -26,7 +26,9 @@ class CorrelationPhaseEstimationAgent(HipModule):
 
     def forward(self, z_t):
         self._require_device(z_t)
-        self._require_inference()
+        if self.training or self._wants_autograd(z_t):
+            from .. import train                   # train() (or eval() under autograd): BPTT on the HIP kernels
+            return train.cpea_train_forward(self, z_t)
         pk = self._packed(lambda sd: Fn.pack_cpea(sd, self.num_layers))
         z = z_t.float()
         dt = ops.compute_dtype()

@@ -36,10 +36,11 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
 }
 
+// save (training): [B, T, 2, 5, H] fp32 = the activated gates i, f, g, o and the cell state c of every step
 template <int H>
 __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __restrict__ xg,
                                                              const float* __restrict__ whh,
-                                                             float* __restrict__ out, int T) {
+                                                             float* __restrict__ out, int T, float* __restrict__ save) {
   constexpr int KS = H / 8;                                  // k-slice length per lane
   constexpr int SL = KS + 4;                                 // slice stride in LDS: slices ks and ks+4 on different banks
   __shared__ __attribute__((aligned(16))) float hs[2][8 * SL];
@@ -97,26 +98,127 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
       hs[(s + 1) & 1][hslot] = h;
       ob[(long long)t * (2 * H)] = h;
     }
+    if (save) {
+      float* sv = save + ((((long long)b * T + t) * 2 + dir) * 5) * H + j;
+      if (ks < 4) sv[mygate * H] = act;
+      if (ks == 4) sv[4 * H] = c;
+    }
     // LDS-only barrier (__syncthreads() would also drain vmcnt: the global store of h and the x prefetch)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
 // xg [B, T, 2, 4H] fp32 (dir-major gates), whh [2, 4H, H] fp32, out [B, T, 2H] fp32
-extern "C" int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype,
-                                void* stream) {
+// ---------------------------------------------------------------------------
+// BPTT of one BiLSTM layer (training of agents/cpea.py:43-50): same workgroup = chain mapping as the forward.
+// Per step (reverse of the chain's own time order):  dh = dout[t] + W_hh^T da[t+];  from the saved gates / cell states
+// the pre-activation gradients da = (di i(1-i), df f(1-f), dg (1-g^2), do o(1-o)) are formed by lane 0 of each unit,
+// published through LDS, written to dxg (= gradient w.r.t. the input projection, from which dW_ih, db, dx and dW_hh are
+// GEMMs afterwards) and every thread multiplies its 4 x H/8 slice of W_hh^T into the next step's recurrent dh.
+// ---------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(8 * H) void bilstm_layer_bwd_kernel(const float* __restrict__ save,
+                                                                 const float* __restrict__ whh,
+                                                                 const float* __restrict__ dout,
+                                                                 float* __restrict__ dxg, int T) {
+  constexpr int G4 = 4 * H;                                   // contraction length of W_hh^T
+  constexpr int KS = G4 / 8;                                  // slice per lane
+  constexpr int SL = KS + 4;
+  __shared__ __attribute__((aligned(16))) float das[2][8 * SL];
+  const int tid = threadIdx.x;
+  const int j = tid >> 3, ks = tid & 7;
+  const int dir = blockIdx.x, b = blockIdx.y;
+  float w[KS];                                                // W_hh[r, j] for r in this lane's slice of the 4H gate rows
+#pragma unroll
+  for (int i = 0; i < KS; ++i) w[i] = whh[((long long)dir * G4 + ks * KS + i) * H + j];
+  if (tid < 8 * SL) { das[0][tid] = 0.f; das[1][tid] = 0.f; }
+  __syncthreads();
+  const long long cb = (long long)b * T;
+  float dh_rec = 0.f, dc_next = 0.f;
+  // the chain ran t = t_first, t_first + dt, ...; BPTT walks it backwards
+  const int dt = dir ? -1 : 1;
+  int t = dir ? 0 : (T - 1);
+  // lane 0 of each unit streams the step's 7 saved values one step ahead of their use
+  float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int tt) {
+    const float* sv = save + (((cb + tt) * 2 + dir) * 5) * H + j;
+    nx[0] = sv[0]; nx[1] = sv[H]; nx[2] = sv[2 * H]; nx[3] = sv[3 * H]; nx[4] = sv[4 * H];
+    const int tp = tt - dt;                                    // previous step of the chain
+    nx[5] = (tp >= 0 && tp < T) ? save[(((cb + tp) * 2 + dir) * 5 + 4) * H + j] : 0.f;
+    nx[6] = dout[(cb + tt) * (2 * H) + dir * H + j];
+  };
+  if (ks == 0) fetch(t);
+  for (int s = 0; s < T; ++s, t -= dt) {
+    if (ks == 0) {
+      const float ig = nx[0], fg = nx[1], gg = nx[2], og = nx[3], c = nx[4], cp = nx[5];
+      const float dh = nx[6] + dh_rec;
+      if (s + 1 < T) fetch(t - dt);
+      const float tc = 2.0f * fast_sigmoid(2.0f * c) - 1.0f;
+      const float dc = dh * og * (1.0f - tc * tc) + dc_next;
+      const float dai = dc * gg * ig * (1.0f - ig);
+      const float daf = dc * cp * fg * (1.0f - fg);
+      const float dag = dc * ig * (1.0f - gg * gg);
+      const float dao = dh * tc * og * (1.0f - og);
+      dc_next = dc * fg;
+      float* dx = dxg + (cb + t) * (8 * H) + (long long)dir * G4 + j;
+      dx[0] = dai; dx[H] = daf; dx[2 * H] = dag; dx[3 * H] = dao;
+      float* da = das[s & 1];                                  // row r = g*H + j lives at (r / KS) * SL + r % KS
+      da[((0 * H + j) / KS) * SL + (0 * H + j) % KS] = dai;
+      da[((1 * H + j) / KS) * SL + (1 * H + j) % KS] = daf;
+      da[((2 * H + j) / KS) * SL + (2 * H + j) % KS] = dag;
+      da[((3 * H + j) / KS) * SL + (3 * H + j) % KS] = dao;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float* dc_ = das[s & 1] + ks * SL;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < KS; i += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dc_ + i);
+      a += w[i] * v[0];
+      a += w[i + 1] * v[1];
+      a += w[i + 2] * v[2];
+      a += w[i + 3] * v[3];
+    }
+    a = dpp_add<DPP_XOR1>(a);
+    a = dpp_add<DPP_XOR2>(a);
+    a = dpp_add<DPP_HALF_MIRROR>(a);
+    dh_rec = a;                                                // every lane of the unit holds it; lane 0 uses it
+  }
+}
+
+template <int H>
+static int bilstm_fwd_go(const float* xg, const float* whh, float* out, float* save, int B, int T, hipStream_t st) {
+  SFM_LAUNCH((bilstm_layer_kernel<H>), dim3(2, B), dim3(8 * H), 0, st, xg, whh, out, T, save);
+  return SFM_OK;
+}
+
+// xg [B, T, 2, 4H] fp32 (dir-major gates), whh [2, 4H, H] fp32, out [B, T, 2H] fp32
+extern "C" int sfm_bilstm_layer_train(const float* xg, const float* whh, float* out, float* save, int B, int T, int H,
+                                      int dtype, void* stream) {
   (void)dtype;
   if (!xg || !whh || !out) return SFM_ERR_ARG;
   if (B <= 0 || T <= 0) return SFM_ERR_SHAPE;
-  if (H == 128) {
-    SFM_LAUNCH((bilstm_layer_kernel<128>), dim3(2, B), dim3(1024), 0, (hipStream_t)stream, xg, whh, out, T);
-  } else if (H == 64) {
-    SFM_LAUNCH((bilstm_layer_kernel<64>), dim3(2, B), dim3(512), 0, (hipStream_t)stream, xg, whh, out, T);
-  } else if (H == 32) {
-    SFM_LAUNCH((bilstm_layer_kernel<32>), dim3(2, B), dim3(256), 0, (hipStream_t)stream, xg, whh, out, T);
-  } else {
-    return SFM_ERR_SHAPE;
-  }
-  SFM_CHECK_LAUNCH();
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 128) return bilstm_fwd_go<128>(xg, whh, out, save, B, T, st);
+  if (H == 64) return bilstm_fwd_go<64>(xg, whh, out, save, B, T, st);
+  if (H == 32) return bilstm_fwd_go<32>(xg, whh, out, save, B, T, st);
+  return SFM_ERR_SHAPE;
+}
+
+extern "C" int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype,
+                                void* stream) {
+  return sfm_bilstm_layer_train(xg, whh, out, nullptr, B, T, H, dtype, stream);
+}
+
+// save [B, T, 2, 5, H] from sfm_bilstm_layer_train, dout [B, T, 2H] fp32 -> dxg [B, T, 2, 4H] fp32
+extern "C" int sfm_bilstm_layer_bwd(const float* save, const float* whh, const float* dout, float* dxg, int B, int T, int H,
+                                    void* stream) {
+  if (!save || !whh || !dout || !dxg) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0) return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 128) SFM_LAUNCH((bilstm_layer_bwd_kernel<128>), dim3(2, B), dim3(1024), 0, st, save, whh, dout, dxg, T);
+  else if (H == 64) SFM_LAUNCH((bilstm_layer_bwd_kernel<64>), dim3(2, B), dim3(512), 0, st, save, whh, dout, dxg, T);
+  else if (H == 32) SFM_LAUNCH((bilstm_layer_bwd_kernel<32>), dim3(2, B), dim3(256), 0, st, save, whh, dout, dxg, T);
+  else return SFM_ERR_SHAPE;
   return SFM_OK;
 }

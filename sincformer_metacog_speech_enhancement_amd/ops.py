@@ -641,6 +641,23 @@ def bilstm_layer(xg, whh, B, T, H):
     return out
 
 
+def bilstm_layer_train(xg, whh, B, T, H):
+    """forward of one BiLSTM layer that also saves the activated gates / cell states [B, T, 2, 5, H] for the BPTT"""
+    L = _lib.load()
+    out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)
+    save = torch.empty(B, T, 2, 5, H, device=xg.device, dtype=torch.float32)
+    _call("bilstm_layer", L.sfm_bilstm_layer_train, (_p(xg), _p(whh), _p(out), _p(save), B, T, H, _dt(), _stream()))
+    return out, save
+
+
+def bilstm_layer_bwd(save, whh, dout, B, T, H):
+    """dout [B, T, 2H] fp32 -> gradient w.r.t. the input projection xg [B, T, 2, 4H] fp32"""
+    L = _lib.load()
+    dxg = torch.empty(B, T, 2, 4 * H, device=dout.device, dtype=torch.float32)
+    _call("bilstm_bwd", L.sfm_bilstm_layer_bwd, (_p(save), _p(whh), _p(dout), _p(dxg), B, T, H, _stream()))
+    return dxg
+
+
 def memory_fwd(emb, params, key_dim, value_dim, slots, temperature):
     L = _lib.load()
     Bn = emb.shape[0]

@@ -619,3 +619,106 @@ def msa_train_forward(msa, z_real, z_imag, cpea_outputs, noisy_real, noisy_imag,
     # mask = polar(logits) applied to the constant spectrum 1 + 0j: the "enhanced" outputs ARE mask_real, mask_imag
     mr, mi, _ = PolarMaskFunction.apply(logits, ones, torch.zeros_like(ones), 3.14159 / 8.0)
     return mr, mi
+
+
+# ---------------------------------------------------------------------------
+# CorrelationPhaseEstimationAgent (agents/cpea.py:43-112): BiLSTM layers with BPTT, inter-layer dropout, 4 heads
+# ---------------------------------------------------------------------------
+class BiLSTMLayerFunction(torch.autograd.Function):
+    """one bidirectional nn.LSTM layer: x [B, T, Din] -> h [B, T, 2H].  Input projection, input gradient and all weight
+    gradients are GEMMs on the matrix cores; the recurrence and its BPTT are the persistent kernels of lstm.hip."""
+
+    @staticmethod
+    def forward(ctx, x, wif, whf, bif, bhf, wir, whr, bir, bhr):
+        B, T, Din = x.shape
+        H = whf.shape[1]
+        M = B * T
+        dt = ops.compute_dtype()
+        x32 = x.detach().float().reshape(M, Din).contiguous()
+        wih = torch.cat([_f32(wif), _f32(wir)], dim=0)                               # [8H, Din]
+        bias = torch.cat([_f32(bif) + _f32(bhf), _f32(bir) + _f32(bhr)], dim=0)
+        whh = torch.stack([_f32(whf), _f32(whr)], dim=0).contiguous()                # [2, 4H, H]
+        x16 = torch.empty(M, Din, device=x.device, dtype=dt)
+        ops.convert_rows(x32, x16, M, Din, Din, Din, Din)
+        xg = ops.linear16(x16, ops.pack_linear(wih, bias), out_dtype=torch.float32)   # [M, 8H] = [B, T, 2, 4H]
+        h, save = ops.bilstm_layer_train(xg, whh, B, T, H)
+        ctx.saved = (x16, wih, whh, save, h)
+        ctx.dims = (B, T, Din, H)
+        ctx.dtypes = [t.dtype for t in (x, wif, whf, bif, bhf, wir, whr, bir, bhr)]
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x16, wih, whh, save, h = ctx.saved
+        B, T, Din, H = ctx.dims
+        M = B * T
+        dev, dt = dh.device, ops.compute_dtype()
+        dxg = ops.bilstm_layer_bwd(save, whh, dh.detach().float().contiguous(), B, T, H).reshape(M, 8 * H)
+        dxg16 = torch.empty(M, 8 * H, device=dev, dtype=dt)
+        ops.convert_rows(dxg, dxg16, M, 8 * H, 8 * H, 8 * H, 8 * H)
+        dwih = torch.zeros(8 * H, Din, device=dev, dtype=torch.float32)
+        db = torch.zeros(8 * H, device=dev, dtype=torch.float32)
+        ops.gemm16_tn(dxg16, x16, dwih, db)
+        dx = ops.linear16(dxg16, ops.pack_linear(wih.t().contiguous()), out_dtype=torch.float32).reshape(B, T, Din)
+        # dW_hh[dir] = sum_t da[t] (x) h_prev[t]: the chain's previous output (zero at its first step)
+        hprev = torch.zeros_like(h)
+        hprev[:, 1:, :H] = h[:, :-1, :H]
+        hprev[:, :-1, H:] = h[:, 1:, H:]
+        hp16 = torch.empty(M, 2 * H, device=dev, dtype=dt)
+        ops.convert_rows(hprev.reshape(M, 2 * H), hp16, M, 2 * H, 2 * H, 2 * H, 2 * H)
+        dwhh = torch.zeros(2, 4 * H, H, device=dev, dtype=torch.float32)
+        for d in range(2):
+            ops.gemm16_tn(dxg16[:, d * 4 * H:(d + 1) * 4 * H], hp16[:, d * H:(d + 1) * H], dwhh[d])
+        t = ctx.dtypes
+        ctx.saved = None
+        g = 4 * H
+        return (dx.to(t[0]), dwih[:g].to(t[1]), dwhh[0].to(t[2]), db[:g].to(t[3]), db[:g].to(t[4]),
+                dwih[g:].to(t[5]), dwhh[1].to(t[6]), db[g:].to(t[7]), db[g:].to(t[8]))
+
+
+class DropoutFunction(torch.autograd.Function):
+    """inverted dropout with the counter-based keep function (inter-layer dropout of nn.LSTM, agents/cpea.py:49)"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x32 = x.detach().float().contiguous()
+        y = torch.empty_like(x32)
+        n = x32.shape[-1]
+        ops.ew_train(ops.EW_SCALE_DROP, y.reshape(-1, n), g=x32.reshape(-1, n), alpha=1.0, p=p, seed=seed)
+        ctx.meta = (p, seed, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, dtp = ctx.meta
+        d = dy.detach().float().contiguous()
+        dx = torch.empty_like(d)
+        n = d.shape[-1]
+        ops.ew_train(ops.EW_SCALE_DROP, dx.reshape(-1, n), g=d.reshape(-1, n), alpha=1.0, p=p, seed=seed)
+        return dx.to(dtp), None, None
+
+
+def cpea_train_forward(cpea, z_t):
+    """CorrelationPhaseEstimationAgent.forward (agents/cpea.py:79-112) from HIP autograd nodes; the sigmoid / tanh * pi
+    of the four 64-wide heads run as torch element-wise ops on the device."""
+    import math
+    if z_t.dim() == 3 and z_t.shape[-1] != cpea.input_dim:
+        z_t = z_t.transpose(1, 2)
+    x = z_t.float().contiguous()
+    B, T, _ = x.shape
+    L = cpea.lstm
+    for l in range(cpea.num_layers):
+        ps = [getattr(L, n % l) for n in ("weight_ih_l%d", "weight_hh_l%d", "bias_ih_l%d", "bias_hh_l%d",
+                                          "weight_ih_l%d_reverse", "weight_hh_l%d_reverse", "bias_ih_l%d_reverse",
+                                          "bias_hh_l%d_reverse")]
+        x = BiLSTMLayerFunction.apply(x, *ps)
+        if cpea.training and L.dropout > 0 and l + 1 < cpea.num_layers:
+            x = DropoutFunction.apply(x, float(L.dropout), int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+    M = B * T
+    heads = [cpea.rho_s_head[0], cpea.rho_n_head[0], cpea.phi1_head[0], cpea.phi2_head[0]]
+    W = torch.cat([h.weight for h in heads], dim=0)
+    b = torch.cat([h.bias for h in heads], dim=0)
+    lg = LNLinearFunction.apply(x.reshape(M, -1), None, None, W, b).reshape(B, T, -1)
+    oc = heads[0].weight.shape[0]
+    return {"rho_s": torch.sigmoid(lg[..., :oc]), "rho_n": torch.sigmoid(lg[..., oc:2 * oc]),
+            "phi1": torch.tanh(lg[..., 2 * oc:3 * oc]) * math.pi, "phi2": torch.tanh(lg[..., 3 * oc:]) * math.pi}

@@ -589,3 +589,56 @@ def test_mask_synthesis_agent_train_mode(dt):
             worst = (k, r)
     print("  worst parameter-gradient rel rmse: %s %.3e" % worst)
     assert worst[1] < tol, worst
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T", [(3, 40), (1, 7)])
+def test_cpea_train_mode_bptt(dt, B, T):
+    """CorrelationPhaseEstimationAgent (agents/cpea.py:79-112) in train() mode (inter-layer dropout forced to 0): outputs,
+    input gradient and every LSTM / head parameter gradient vs torch autograd of the oracle's restated LSTM."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.agents import CorrelationPhaseEstimationAgent
+    ops.set_compute_dtype(dt)
+    sd = synth_sd("CorrelationPhaseEstimationAgent", 65)
+    m = CorrelationPhaseEstimationAgent()
+    m.load_state_dict(sd, strict=True)
+    m.lstm.dropout = 0.0
+    m.cuda().train()
+    z = arr("cz", (B, T, 256), 66 + T)
+    cots = {k: arr("cc" + k, (B, T, 64), 67 + i) for i, k in enumerate(("rho_s", "rho_n", "phi1", "phi2"))}
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    zr = z.clone().requires_grad_(True)
+    out_o = orc.cpea_forward(ref_sd, zr)
+    sum((out_o[k] * cots[k]).sum() for k in cots).backward()
+    zg = z.cuda().requires_grad_(True)
+    out = m(zg)
+    sum((out[k] * cots[k].cuda()).sum() for k in cots).backward()
+    for k in cots:
+        e = rmse(out[k].detach().cpu(), out_o[k].detach())
+        assert e < (2e-3 if dt is torch.float16 else 1.5e-2), (k, e)
+    tol = 0.02 if dt is torch.float16 else 0.1
+    r = _rel(zg.grad.cpu(), zr.grad)
+    worst = ("input", r)
+    for k, p_ in m.named_parameters():
+        r = _rel(p_.grad.cpu(), ref_sd[k].grad)
+        if r > worst[1]:
+            worst = (k, r)
+    print("CPEA BPTT %s B%d T%d: worst gradient rel rmse %s %.3e" % (dt, B, T, worst[0], worst[1]))
+    assert worst[1] < tol, worst
+
+
+def test_cpea_train_mode_interlayer_dropout_runs():
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.agents import CorrelationPhaseEstimationAgent
+    ops.set_compute_dtype(torch.bfloat16)
+    m = CorrelationPhaseEstimationAgent().cuda().train()
+    z = arr("cz2", (2, 30, 256), 70).cuda().requires_grad_(True)
+    torch.manual_seed(4)
+    a = m(z)["rho_s"].detach().clone()
+    torch.manual_seed(4)
+    b_ = m(z)["rho_s"].detach().clone()
+    torch.manual_seed(5)
+    c = m(z)["rho_s"].detach().clone()
+    assert torch.equal(a, b_) and not torch.equal(a, c)
+    sum(v.sum() for v in m(z).values()).backward()
+    assert torch.isfinite(z.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters())
