@@ -30,6 +30,15 @@ class EpisodicMemory(HipModule):
 
     def forward(self, environment_embedding):
         self._require_device(environment_embedding)
+        if (self.training and torch.is_grad_enabled()) or self._wants_autograd(environment_embedding):
+            from .. import train
+            out = train.memory_train_forward(self, environment_embedding)
+            if self.training:
+                with torch.no_grad():
+                    top = out["top_indices"]
+                    self.usage_count.index_add_(0, top, torch.ones_like(top, dtype=self.usage_count.dtype))
+                    self.num_queries += environment_embedding.shape[0]
+            return out
         params = self._packed(Fn.pack_memory_params)
         e = environment_embedding.float().contiguous()
         bias, gate, top, sim = ops.memory_fwd(e, params, self.key_dim, self.value_dim, self.num_slots, self.temperature)

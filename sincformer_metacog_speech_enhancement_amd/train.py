@@ -722,3 +722,46 @@ def cpea_train_forward(cpea, z_t):
     oc = heads[0].weight.shape[0]
     return {"rho_s": torch.sigmoid(lg[..., :oc]), "rho_n": torch.sigmoid(lg[..., oc:2 * oc]),
             "phi1": torch.tanh(lg[..., 2 * oc:3 * oc]) * math.pi, "phi2": torch.tanh(lg[..., 3 * oc:]) * math.pi}
+
+
+def memory_train_forward(mem, emb):
+    """EpisodicMemory.forward (agents/memory.py:95-148) with autograd: the Linear / LayerNorm / GELU layers are the HIP
+    nodes above; the [B, 64]-slot cosine read-out (normalise, softmax, two small matmuls), tanh and the 1-unit gate are a
+    few thousand FLOPs per utterance and run as torch ops on the device."""
+    import torch.nn.functional as F
+    e = emb.float()
+    kp = mem.key_proj
+    q = LNLinearFunction.apply(e, None, None, kp[0].weight, kp[0].bias)
+    q = GeluFunction.apply(LayerNormFunction.apply(q, kp[1].weight, kp[1].bias))
+    q = LNLinearFunction.apply(q, None, None, kp[3].weight, kp[3].bias)
+    sim = (F.normalize(q, dim=-1) @ F.normalize(mem.keys.float(), dim=-1).t()) / mem.temperature
+    att = torch.softmax(sim, dim=-1)
+    retrieved = att @ mem.values.float()
+    bias = torch.tanh(LNLinearFunction.apply(retrieved, None, None, mem.value_proj[0].weight, mem.value_proj[0].bias))
+    gate = torch.sigmoid(F.linear(torch.cat([q, retrieved], dim=-1), mem.gate[0].weight.float(), mem.gate[0].bias.float()))
+    top = sim.argmax(dim=-1)
+    return {"bias": bias * gate, "gate": gate, "top_indices": top, "similarity": sim.max(dim=-1)[0]}
+
+
+class IstftFunction(torch.autograd.Function):
+    """batch_istft (training/conformer_pipeline.py:205-211) with its adjoint: irfft-by-matrix + overlap-add forward;
+    backward = frames-x-matrix product of g / envelope with the transposed operand (the objective's own path in
+    EnhancerLossFunction does the same inline)."""
+
+    @staticmethod
+    def forward(ctx, real, imag, length, n_fft, hop, win):
+        from . import functional as Fn
+        r, i = real.detach().float().contiguous(), imag.detach().float().contiguous()
+        ctx.meta = (tuple(r.shape), length, n_fft, hop, win, real.dtype, imag.dtype)
+        return Fn.istft(r, i, length, n_fft, hop, win)
+
+    @staticmethod
+    def backward(ctx, g):
+        (B, T, F), L, n_fft, hop, win, d0, d1 = ctx.meta
+        genv = (g.detach().float() * _inv_envelope(L, T, n_fft, hop, win, g.device)).contiguous()
+        dr = torch.empty(B, T, F, device=g.device, dtype=torch.float32)
+        di = torch.empty(B, T, F, device=g.device, dtype=torch.float32)
+        ops.framed_gemm(genv, _adjoint_consts(n_fft, win, g.device)["invT"], dr, B=B, M=T, Ls=L, sig_batch_stride=L, hop=hop,
+                        padl=n_fft // 2 - (n_fft - win) // 2, K=win, N=2 * F, o_batch_stride=T * F, ldm=F, ldn=1, mode=0,
+                        out2=di, nsplit=F)
+        return dr.to(d0), di.to(d1), None, None, None, None

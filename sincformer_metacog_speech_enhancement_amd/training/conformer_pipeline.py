@@ -154,9 +154,50 @@ class EnhancementPath(HipModule):
         return tuple([ops.compute_dtype()] + [(p.data_ptr(), p._version) for p in self.parameters()] +
                      [(b.data_ptr(), b._version) for n, b in self.named_buffers() if "usage" not in n and "num_queries" not in n])
 
+    def freeze_perception(self, flag=True):
+        """The PerceptionAgent's backward kernels are not built yet: train() of the composition needs the front-end
+        frozen explicitly (its GroupNorm-only stack has no train/eval difference, so the forward is exact either way)."""
+        self.__dict__["_sfm_pa_frozen"] = bool(flag)
+        for p in self.perception.parameters():
+            p.requires_grad_(not flag)
+        return self
+
+    def _train_forward(self, waveform):
+        """train() mode with a frozen front-end: PA on the inference kernels (no graph), then CPEA (BPTT), EpisodicMemory,
+        MaskSynthesisAgent, apply_mask and iSTFT as HIP autograd nodes; glue G1-G3 as in eval()."""
+        from .. import train
+        if not self.__dict__.get("_sfm_pa_frozen", False):
+            raise NotImplementedError("EnhancementPath.train(): the PerceptionAgent backward is not part of this build; call "
+                                      "path.freeze_perception() to train CPEA / memory / MaskSynthesisAgent on a frozen "
+                                      "front-end, or use eval() / torch.no_grad().")
+        wave = waveform.float().contiguous()
+        B, L = wave.shape
+        T = 1 + L // Fn.HOP
+        D = self.perception.encoder_channels if hasattr(self.perception, "encoder_channels") else 256
+        with torch.no_grad():
+            pa = self.perception._packed(lambda sd: Fn.pack_perception(sd, self.sample_rate))     # frozen: packed once
+            (rz, sz, hz), _sigma = Fn.perception_forward(wave, pa, latents=False)
+            zp = torch.empty(B, T, 2 * D, device=wave.device, dtype=torch.float32)
+            ops.pool_time(rz, None, zp, B, rz.shape[1], T, 2 * D, 2 * D, 2 * D, scale=sz, shift=hz)      # glue G1
+            nr, ni = Fn.stft(wave)
+        z_real, z_imag = zp[..., :D].transpose(1, 2), zp[..., D:].transpose(1, 2)
+        cpea = self.cpea(zp[..., :D])
+        bias = None
+        out = {}
+        if self.memory is not None:
+            mem = self.memory(zp[..., :self.memory.key_dim].mean(dim=1))                                 # glue G2
+            bias = mem["bias"]                                                                            # glue G3
+            out.update(mem_bias=mem["bias"], mem_gate=mem["gate"], mem_top=mem["top_indices"], mem_sim=mem["similarity"])
+        mr, mi = self.msa(z_real, z_imag, cpea, nr, ni, mag_logit_bias=bias)
+        er, ei = train.ComplexMulFunction.apply(nr, ni, mr, mi)
+        out.update(mask_real=mr, mask_imag=mi, noisy_real=nr, noisy_imag=ni,
+                   enhanced=train.IstftFunction.apply(er, ei, L, Fn.N_FFT, Fn.HOP, Fn.WIN))
+        return out
+
     def forward(self, waveform, want=("mask", "wave")):
         self._require_device(waveform)
-        self._require_inference()
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(waveform)
         packs = self._packed(self._pack)
         return Fn.enhance_path(waveform.float(), packs, H=self.msa.conformer.num_heads,
                                use_memory=self.memory is not None, want=want)

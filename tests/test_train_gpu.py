@@ -642,3 +642,64 @@ def test_cpea_train_mode_interlayer_dropout_runs():
     assert torch.equal(a, b_) and not torch.equal(a, c)
     sum(v.sum() for v in m(z).values()).backward()
     assert torch.isfinite(z.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters())
+
+
+def test_enhancement_path_trains_with_frozen_front_end():
+    """EnhancementPath.train(): PerceptionAgent frozen (inference kernels), CPEA + EpisodicMemory + MaskSynthesisAgent +
+    apply_mask + iSTFT under HIP autograd.  Gradients of a waveform-domain loss vs torch autograd of the oracle's
+    composition with the same frozen front-end; without freeze_perception() train mode refuses loudly."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    ops.set_compute_dtype(torch.float16)
+    sds = {"pa": synth_sd("PerceptionAgent", 391, sinc_scale=2000.0), "cpea": synth_sd("CorrelationPhaseEstimationAgent", 392),
+           "msa": synth_sd("MaskSynthesisAgent", 393), "memory": synth_sd("EpisodicMemory", 394)}
+    path = EnhancementPath(sample_rate=16000, use_memory=True)
+    path.perception.load_state_dict(sds["pa"])
+    path.cpea.load_state_dict(sds["cpea"])
+    path.msa.load_state_dict(sds["msa"])
+    path.memory.load_state_dict(sds["memory"])
+    for mod in path.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    path.cpea.lstm.dropout = 0.0
+    path = path.cuda().train()
+    B, L = 2, 2400
+    noisy, clean = _waves(B, L, 395)
+    with pytest.raises(NotImplementedError):
+        path(noisy.cuda())
+    path.freeze_perception()
+    out = path(noisy.cuda())
+    loss = (out["enhanced"] - clean.cuda()).pow(2).mean() * 1e3
+    loss.backward()
+    # oracle: same composition, front-end outputs detached
+    T = 1 + L // 80
+    with torch.no_grad():
+        zr, zi, _ = orc.perception_forward(sds["pa"], noisy, 16000)
+        zr_t, zi_t = orc.pool_latents(zr, T), orc.pool_latents(zi, T)
+        nr, ni = orc.stft(noisy)
+    ref = {n: {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and "usage" not in k
+                   else v.clone()) for k, v in sds[n].items()} for n in ("cpea", "msa", "memory")}
+    cp = orc.cpea_forward(ref["cpea"], zr_t.transpose(1, 2))
+    mem = orc.memory_forward(ref["memory"], zr_t.mean(dim=-1))
+    mr, mi = orc.msa_forward(ref["msa"], zr_t, zi_t, cp, nr, ni, 4, mag_logit_bias=mem["bias"], bn_train=True)
+    er, ei = orc.apply_mask(nr, ni, mr, mi)
+    wav = orc.istft(er, ei, L)
+    ref_loss = (wav - clean).pow(2).mean() * 1e3
+    ref_loss.backward()
+    print("path train: loss %.5f (oracle %.5f)" % (float(loss.detach()), float(ref_loss.detach())))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-3 * abs(float(ref_loss.detach()))
+    worst = ("", 0.0)
+    for name, mod in (("cpea", path.cpea), ("msa", path.msa), ("memory", path.memory)):
+        for k, p_ in mod.named_parameters():
+            if k.endswith("depthwise.bias"):
+                continue
+            rg = ref[name][k].grad
+            assert p_.grad is not None and rg is not None, (name, k)
+            r = _rel(p_.grad.cpu(), rg)
+            if r > worst[1]:
+                worst = (name + "." + k, r)
+    print("  worst parameter-gradient rel rmse: %s %.3e" % worst)
+    assert worst[1] < 0.03, worst
+    assert all(p_.grad is None for p_ in path.perception.parameters())
