@@ -216,6 +216,15 @@ int sfm_ssnr_frames(const float* clean, const float* enh, double* acc, int B, in
                     float lower, void* stream);
 int sfm_stoi_frames(const float* cr, const float* ci, const float* er, const float* ei, const double* sc, const double* se,
                     double* acc, int B, int nframes, int F, void* stream);
+/* Backward of the PerceptionAgent's GroupNorm nodes out = act(GN(x1) [+ GN(x2)]) (agents/perception.py:121-129, 157,
+ * 192-206), channels-last [B, L, C].  tab = [4][B][C] fp32 (scale, shift, group mean, group rstd, broadcast to channels);
+ * reduce: S [B][C][3] += { sum dp, sum dp xhat1, sum dp xhat2 } with dp = dout * act'(p);  apply: dx_i = a dp - b - xhat_i c
+ * with coef = [3][B][C] fp32 built by the host from S (see train.py). */
+int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* tab1, const void* x2,
+                      int x2_f32, const float* tab2, float* S, int B, int L, int C, int act, int dtype, void* stream);
+int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* tab1, const float* coef1,
+                     void* dx1, int dx1_f32, const void* x2, int x2_f32, const float* tab2, const float* coef2, void* dx2,
+                     int dx2_f32, int B, int L, int C, int act, int dtype, void* stream);
 /* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
  * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
  * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */

@@ -69,6 +69,9 @@ SIGNATURES = {
                                   c_vp],
     "sfm_ssnr_frames": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp],
     "sfm_stoi_frames": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "sfm_gn_bwd_reduce": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_gn_bwd_apply": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
+                         c_vp],
     "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp],
     "sfm_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp],
     "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],

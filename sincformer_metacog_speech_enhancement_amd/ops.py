@@ -530,6 +530,56 @@ def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits)
                                              ld_logits, dlog.stride(0), _stream()), 0.0, 32.0 * M * F)
 
 
+def gn_stats(partial, rows, C, G):
+    """group mean / rstd [B, G] from the per-64-row partial sums a producing GEMM wrote ([B, P, G, 2] = sum, sum of squares)"""
+    s = partial.double().sum(dim=1)
+    n = float(rows * (C // G))
+    mean = s[..., 0] / n
+    var = (s[..., 1] / n - mean * mean).clamp_min(0.0)
+    return mean.float(), torch.rsqrt(var + 1e-5).float()
+
+
+def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, sc2=None, sh2=None, mean2=None, rstd2=None,
+                    gamma2=None, dx_dtype=None):
+    """backward of out = act(GN(x1) [+ GN(x2)]) on channels-last [B, L, C] tensors (PerceptionAgent nodes).
+    sc / sh [B, C]: the forward's scale and shift; mean / rstd [B, G]; gamma [C].
+    Returns dx1, dgamma1, dbeta1 (and dx2, dgamma2, dbeta2 when two inputs)."""
+    L_ = _lib.load()
+    B, L, C = x1.shape
+    cg = C // G
+    dx_dtype = dx_dtype or _state["dtype"]
+    two = x2 is not None
+
+    def table(sc, sh, mean, rstd):
+        return torch.stack([sc.float(), sh.float(), mean.repeat_interleave(cg, dim=1), rstd.repeat_interleave(cg, dim=1)]).contiguous()
+    t1 = table(sc1, sh1, mean1, rstd1)
+    t2 = table(sc2, sh2, mean2, rstd2) if two else None
+    S = torch.zeros(B, C, 3, device=x1.device, dtype=torch.float32)
+    f32 = lambda t: 1 if t.dtype == torch.float32 else 0
+    dout = dout.contiguous()
+    _call("gn_bwd", L_.sfm_gn_bwd_reduce, (_p(dout), f32(dout), _p(x1), f32(x1), _p(t1), _p(x2), f32(x2) if two else 0, _p(t2), _p(S),
+                                           B, L, C, int(act), _dt(), _stream()), 0.0, 8.0 * B * L * C)
+    n = float(L * cg)
+
+    def coefs(gamma, rstd, col):
+        g = gamma.float()
+        A = (S[:, :, 0] * g).reshape(B, G, cg).sum(-1)                       # sum over the group of dp * gamma
+        Bq = (S[:, :, col] * g).reshape(B, G, cg).sum(-1)                    # ... of dp * gamma * xhat
+        r = rstd.repeat_interleave(cg, dim=1)
+        return torch.stack([r * g, r * A.repeat_interleave(cg, dim=1) / n, r * Bq.repeat_interleave(cg, dim=1) / n]).contiguous()
+    c1 = coefs(gamma1, rstd1, 1)
+    c2 = coefs(gamma2, rstd2, 2) if two else None
+    dx1 = torch.empty(B, L, C, device=x1.device, dtype=dx_dtype)
+    dx2 = torch.empty(B, L, C, device=x1.device, dtype=dx_dtype) if two else None
+    _call("gn_bwd", L_.sfm_gn_bwd_apply, (_p(dout), f32(dout), _p(x1), f32(x1), _p(t1), _p(c1), _p(dx1), f32(dx1), _p(x2),
+                                          f32(x2) if two else 0, _p(t2), _p(c2), _p(dx2), f32(dx2) if two else 0, B, L, C, int(act),
+                                          _dt(), _stream()), 0.0, 10.0 * B * L * C)
+    dbeta = S[:, :, 0].sum(0)
+    if two:
+        return dx1, S[:, :, 1].sum(0), dbeta, dx2, S[:, :, 2].sum(0), dbeta.clone()
+    return dx1, S[:, :, 1].sum(0), dbeta
+
+
 # ---------------------------------------------------------------------------
 # training path (ConformerBlock backward)
 # ---------------------------------------------------------------------------

@@ -195,3 +195,37 @@ def test_attention_train_fwd_bwd(ops, dt, B, T, H, p, hd):
     report("attn bwd dk", dqkv.float().cpu()[:, D:2 * D], gref[:, D:2 * D], 0.03 * scale + 8 * EPS[dt] * scale)
     report("attn bwd dv", dqkv.float().cpu()[:, 2 * D:], gref[:, 2 * D:], 0.03 * scale + 8 * EPS[dt] * scale)
     assert rmse(dqkv.float().cpu(), gref) < (0.02 if dt is torch.bfloat16 else 0.004) * float(gref.pow(2).mean().sqrt()) + 1e-6
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,L,C,G,act,two", [(2, 300, 64, 8, 1, False), (3, 257, 128, 16, 1, True), (1, 130, 256, 16, 0, False),
+                                             (2, 200, 512, 32, 0, False)])
+def test_groupnorm_act_backward(ops, dt, B, L, C, G, act, two):
+    """out = act(GN(x1) [+ GN(x2)]) (PerceptionAgent nodes, channels-last): dx, dgamma, dbeta vs F.group_norm autograd"""
+    ops.set_compute_dtype(dt)
+    xs = [(arr("gx%d" % i, (B, L, C), 500 + i + C, 1.5) + 0.3) for i in range(2 if two else 1)]
+    gam = [(arr("gg%d" % i, (C,), 510 + i) * 0.2 + 1.0) for i in range(len(xs))]
+    bet = [arr("gb%d" % i, (C,), 520 + i) * 0.2 for i in range(len(xs))]
+    dout = arr("gdo", (B, L, C), 530 + C)
+    xq = [q16(x, dt).requires_grad_(True) for x in xs]                       # the raw conv outputs are stored 16-bit
+    gr = [g.clone().requires_grad_(True) for g in gam]
+    br = [b_.clone().requires_grad_(True) for b_ in bet]
+    p = sum(F.group_norm(x.transpose(1, 2), G, g, b_, 1e-5).transpose(1, 2) for x, g, b_ in zip(xq, gr, br))
+    out = F.gelu(p) if act else p
+    out.backward(dout)
+    # forward statistics the way the producing GEMM + gn_finalize provide them
+    args = []
+    for x, g, b_ in zip(xq, gam, bet):
+        xg = x.detach().reshape(B, L, G, C // G)
+        mean = xg.mean(dim=(1, 3))
+        rstd = torch.rsqrt(xg.var(dim=(1, 3), unbiased=False) + 1e-5)
+        sc = rstd.repeat_interleave(C // G, dim=1) * g
+        sh = b_ - mean.repeat_interleave(C // G, dim=1) * sc
+        args += [x.detach().cuda().to(dt).contiguous(), sc.cuda(), sh.cuda(), mean.cuda(), rstd.cuda(), g.cuda()]
+    res = ops.gn_act_backward(dout.cuda(), act, G, *args, dx_dtype=torch.float32)
+    for i in range(len(xs)):
+        dx, dg, db = res[3 * i:3 * i + 3]
+        scale = float(xq[i].grad.abs().max())
+        report("gn bwd dx%d C%d act%d" % (i, C, act), dx.cpu(), xq[i].grad, 2e-3 * scale + 1e-5)
+        report("gn bwd dgamma%d" % i, dg.cpu(), gr[i].grad, 2e-3 * float(gr[i].grad.abs().max()) + 1e-4)
+        report("gn bwd dbeta%d" % i, db.cpu(), br[i].grad, 2e-3 * float(br[i].grad.abs().max()) + 1e-4)
