@@ -236,6 +236,11 @@ int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* 
  * db[n] += sum_m G[m,n] in the same launch; sfm_colsum = the stand-alone bias gradient */
 int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw,
                   int dtype, void* stream);
+/* Conv1d weight gradient (training of agents/perception.py:121-129, 160-188 convs): G = dY [B*Lout, N] 16-bit, x
+ * [B, Lin, Cin] channels-last 16-bit, dW [N, ksize*Cin] tap-major fp32 += G^T im2col(x) with the im2col rows addressed
+ * in place (zero padding by range check); db (optional) += column sums of G. */
+int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* db, int B, int Lout, int Lin, int Cin, int N, int ksize,
+                     int stride, int pad, long long x_batch_stride, int ldg, int ldw, int dtype, void* stream);
 int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream);
 int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                       float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream);

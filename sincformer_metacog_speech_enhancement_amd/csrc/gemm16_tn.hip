@@ -10,10 +10,18 @@
 
 #define TN_ROW 160      // u16 elements per LDS row (128 + 32 pad) = 320 B
 
+// conv addressing of X (weight gradient of a Conv1d on channels-last activations): row m = (b, l) of the im2col matrix is
+// x[b, l*stride - pad + tap, ch] with k = tap*Cin + ch; positions outside [0, Lin) are the conv's zero padding.
+// Lout == 0: plain row-major X with row stride ldx.
+struct TnConv {
+  int Lout, Lin, Cin, stride, pad;
+  long long x_batch_stride;
+};
+
 template <class T>
 __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
                                                         float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                        int K, int ldg, int ldx, int ldw, int rows_per_split) {
+                                                        int K, int ldg, int ldx, int ldw, int rows_per_split, TnConv cv) {
   __shared__ __attribute__((aligned(16))) u16 Gs[64 * TN_ROW];
   __shared__ __attribute__((aligned(16))) u16 Xs[64 * TN_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,7 +60,16 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
           for (int e = 0; e < 8; ++e) t[e] = (n0 + scol[i] + e < N) ? G[(long long)m * ldg + n0 + scol[i] + e] : (u16)0;
           a = *reinterpret_cast<const u32x4*>(t);
         }
-        if (k0 + scol[i] + 8 <= K) b = *reinterpret_cast<const u32x4*>(X + (long long)m * ldx + k0 + scol[i]);
+        if (cv.Lout > 0) {                                     // implicit im2col row (Cin % 8 == 0: a chunk stays in one tap)
+          const int kk = k0 + scol[i];
+          if (kk < K) {
+            const int bb = m / cv.Lout, l = m - bb * cv.Lout;
+            const int tap = kk / cv.Cin, ch = kk - tap * cv.Cin;
+            const int pos = l * cv.stride - cv.pad + tap;
+            if (pos >= 0 && pos < cv.Lin)
+              b = *reinterpret_cast<const u32x4*>(X + (long long)bb * cv.x_batch_stride + (long long)pos * cv.Cin + ch);
+          }
+        } else if (k0 + scol[i] + 8 <= K) b = *reinterpret_cast<const u32x4*>(X + (long long)m * ldx + k0 + scol[i]);
         else {
           u16 t[8];
 #pragma unroll
@@ -193,11 +210,10 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const void* __restrict_
   }
 }
 
-// db (optional): bias gradient out[n] += sum_m G[m, n], computed from the G tiles the k-tile-0 workgroups stage anyway
-extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx,
-                             int ldw, int dtype, void* stream) {
+static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw,
+                            int dtype, void* stream, TnConv cv) {
   if (!G || !X || !dW) return SFM_ERR_ARG;
-  if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (ldx % 8) != 0) return SFM_ERR_SHAPE;
+  if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (cv.Lout == 0 && (ldx % 8) != 0)) return SFM_ERR_SHAPE;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int splits = (1024 + tiles - 1) / tiles;                    // aim at ~1024 workgroups
   const int max_splits = (M + 255) / 256;
@@ -209,11 +225,28 @@ extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db,
   dim3 grid((N + 127) / 128, (K + 127) / 128, splits), block(256);
   if (dtype == SFM_DT_F16)
     SFM_LAUNCH((gemm16_tn_kernel<F16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
-               ldg, ldx, ldw, rows);
+               ldg, ldx, ldw, rows, cv);
   else
     SFM_LAUNCH((gemm16_tn_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
-               ldg, ldx, ldw, rows);
+               ldg, ldx, ldw, rows, cv);
   return SFM_OK;
+}
+
+// db (optional): bias gradient out[n] += sum_m G[m, n], computed from the G tiles the k-tile-0 workgroups stage anyway
+extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx,
+                             int ldw, int dtype, void* stream) {
+  TnConv cv = {0, 0, 0, 0, 0, 0};
+  return gemm16_tn_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv);
+}
+
+// Conv1d weight gradient: G = dY [B*Lout, N] (16-bit), x [B, Lin, Cin] channels-last 16-bit;
+// dW [N, ksize*Cin] (tap-major, the layout of the packed conv weight) += sum_m G[m, n] * im2col(x)[m, k]
+extern "C" int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* db, int B, int Lout, int Lin, int Cin, int N,
+                                int ksize, int stride, int pad, long long x_batch_stride, int ldg, int ldw, int dtype,
+                                void* stream) {
+  if (B <= 0 || Lout <= 0 || Lin <= 0 || Cin <= 0 || (Cin % 8) != 0 || ksize <= 0 || stride <= 0) return SFM_ERR_SHAPE;
+  TnConv cv = {Lout, Lin, Cin, stride, pad, x_batch_stride};
+  return gemm16_tn_launch(G, x, dW, db, B * Lout, N, ksize * Cin, ldg, 0, ldw, dtype, stream, cv);
 }
 
 extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream) {

@@ -592,6 +592,43 @@ def gemm16_tn(G16, X16, dW, db=None):
                                          _dt(), _stream()), 2.0 * M * N * K, M * (N + K) * 2.0)
 
 
+def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
+    """Conv1d weight / bias gradient from dY [B*Lout, N] and the channels-last input x [B, Lin, Cin] (both 16-bit):
+    returns dW in torch's Conv1d layout [N, Cin, ksize] and db [N] (fp32)."""
+    L = _lib.load()
+    dW = torch.zeros(N, ksize * Cin, device=x16.device, dtype=torch.float32)
+    db = torch.zeros(N, device=x16.device, dtype=torch.float32)
+    _call("gemm16_tn", L.sfm_conv_wgrad16, (_p(dy16), _p(x16), _p(dW), _p(db), B, Lout, Lin, Cin, N, ksize, stride, pad,
+                                            Lin * Cin, dy16.stride(0), dW.stride(0), _dt(), _stream()),
+          2.0 * B * Lout * N * ksize * Cin, (B * Lout * N + B * Lin * Cin) * 2.0)
+    return dW.reshape(N, ksize, Cin).permute(0, 2, 1).contiguous(), db
+
+
+def conv_dgrad16(dy16, weight, B, Lout, Lin, stride, pad, accumulate_into=None):
+    """input gradient of Conv1d(weight [N, Cin, k], stride 1 or 2, zero padding) on channels-last tensors:
+    dy16 [B, Lout, N] 16-bit -> dx [B, Lin, Cin] fp32 (added to `accumulate_into` when given).  Stride 1 is the
+    correlation with the flipped, transposed kernel; stride 2 is that per output parity (two implicit GEMMs writing the
+    even / odd rows)."""
+    N, Cin, k = weight.shape
+    w = weight.detach().float()
+    dx = accumulate_into if accumulate_into is not None else torch.zeros(B, Lin, Cin, device=dy16.device, dtype=torch.float32)
+    for r in range(stride):
+        t0 = (r + pad) % stride
+        taps = list(range(t0, k, stride))
+        nq = (Lin - r + stride - 1) // stride
+        if not taps or nq <= 0:
+            continue
+        J = len(taps)
+        c0 = (r + pad - t0) // stride
+        # out[q] = sum_j' in[q - pad2 + j'] Wf[j'],  Wf[j'] = W[:, :, taps[J-1-j']]^T,  pad2 = J - 1 - c0
+        wf = torch.stack([w[:, :, taps[J - 1 - j]] for j in range(J)], dim=2).permute(1, 0, 2).contiguous()   # [Cin, N, J]
+        pw = pack_linear(wf)
+        view = dx.reshape(B, Lin * Cin)[:, r * Cin:]
+        gemm16(dy16, pw, view, B=B, Lout=nq, Lin=Lout, a_batch_stride=Lout * N, ldo=stride * Cin, o_batch_stride=Lin * Cin,
+               stride=1, pad=J - 1 - c0, epi=EPI_RESID, resid=view, ldr=stride * Cin, r_batch_stride=Lin * Cin, alpha=1.0)
+    return dx
+
+
 def colsum(G, out):
     L = _lib.load()
     M, N = G.shape

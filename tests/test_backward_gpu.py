@@ -229,3 +229,30 @@ def test_groupnorm_act_backward(ops, dt, B, L, C, G, act, two):
         report("gn bwd dx%d C%d act%d" % (i, C, act), dx.cpu(), xq[i].grad, 2e-3 * scale + 1e-5)
         report("gn bwd dgamma%d" % i, dg.cpu(), gr[i].grad, 2e-3 * float(gr[i].grad.abs().max()) + 1e-4)
         report("gn bwd dbeta%d" % i, db.cpu(), br[i].grad, 2e-3 * float(br[i].grad.abs().max()) + 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,Lin,Cin,N,k,s,p", [(2, 400, 64, 128, 7, 2, 3), (2, 301, 128, 128, 3, 1, 1), (3, 200, 64, 128, 1, 2, 0),
+                                               (1, 333, 256, 256, 5, 2, 2), (2, 150, 256, 512, 1, 1, 0)])
+def test_conv1d_wgrad_and_dgrad(ops, dt, B, Lin, Cin, N, k, s, p):
+    """weight / bias / input gradients of the PerceptionAgent's Conv1d shapes (channels-last, implicit GEMMs) vs F.conv1d"""
+    ops.set_compute_dtype(dt)
+    Lout = (Lin + 2 * p - k) // s + 1
+    x = q16(arr("cvx", (B, Lin, Cin), 600 + Lin), dt)
+    w = q16(arr("cvw", (N, Cin, k), 601 + k, 0.1), dt)
+    dy = q16(arr("cvdy", (B, Lout, N), 602 + N, 0.5), dt)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = torch.zeros(N, requires_grad=True)
+    y = F.conv1d(xr.transpose(1, 2), wr, br, stride=s, padding=p).transpose(1, 2)
+    y.backward(dy)
+    dy16 = dy.cuda().to(dt).contiguous()
+    dW, db = ops.conv_wgrad16(dy16.reshape(B * Lout, N), x.cuda().to(dt).contiguous(), B, Lout, Lin, Cin, N, k, s, p)
+    tolw = 3e-3 * float(wr.grad.abs().max()) + 1e-3
+    report("conv wgrad k%d s%d" % (k, s), dW.cpu(), wr.grad, tolw)
+    report("conv bias grad", db.cpu(), br.grad, 2e-3 * float(br.grad.abs().max()) + 1e-3)
+    dx = ops.conv_dgrad16(dy16, w.cuda(), B, Lout, Lin, s, p)
+    report("conv dgrad k%d s%d" % (k, s), dx.cpu(), xr.grad, 3e-3 * float(xr.grad.abs().max()) + 1e-3)
+    # accumulation into an existing gradient (two consumers of one activation)
+    base = arr("cvb", (B, Lin, Cin), 603).cuda()
+    dx2 = ops.conv_dgrad16(dy16, w.cuda(), B, Lout, Lin, s, p, accumulate_into=base.clone())
+    report("conv dgrad accumulate", (dx2 - base).cpu(), xr.grad, 3e-3 * float(xr.grad.abs().max()) + 1e-3)
