@@ -136,6 +136,9 @@ int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, i
  * output (glue G1 applied to agents/perception.py:244-246 without materialising the full-rate normalised tensor) */
 int sfm_pool_time_affine(const float* src, const float* scale, const float* shift, void* dst16, float* dst32, int B,
                          int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype, void* stream);
+/* adjoint of sfm_pool_time (training: gradient of the pooled latents back to the full-rate latents), fp32 */
+int sfm_pool_time_bwd(const float* dout, float* dsrc, int B, int Tin, int Tout, int C, long long ld_dout,
+                      long long ld_dsrc, void* stream);
 /* agents/msa.py:134-137 */
 int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst, long long M, int F, int zpad,
                           long long ld_dst, int dtype, void* stream);
@@ -216,6 +219,12 @@ int sfm_ssnr_frames(const float* clean, const float* enh, double* acc, int B, in
                     float lower, void* stream);
 int sfm_stoi_frames(const float* cr, const float* ci, const float* er, const float* ei, const double* sc, const double* se,
                     double* acc, int B, int nframes, int F, void* stream);
+/* Gradient of the SincConv1d FIR bank w.r.t. its taps (training of agents/perception.py:79-118):
+ * dfilt [C, K] += sum_{b,l} dy[b, l, c] x[b, l + k - K/2]; x [B, L] fp32, dy [B, L, C] 16-bit or fp32; scratch:
+ * sfm_sinc_wgrad_scratch_floats floats (need not be zeroed).  K <= 256. */
+long long sfm_sinc_wgrad_scratch_floats(int B, int L, int C, int K);
+int sfm_sinc_wgrad(const float* x, const void* dy, int dy_f32, float* dfilt, float* scratch, int B, int L, int C, int K,
+                   int dtype, void* stream);
 /* Backward of the PerceptionAgent's GroupNorm nodes out = act(GN(x1) [+ GN(x2)]) (agents/perception.py:121-129, 157,
  * 192-206), channels-last [B, L, C].  tab = [4][B][C] fp32 (scale, shift, group mean, group rstd, broadcast to channels);
  * reduce: S [B][C][3] += { sum dp, sum dp xhat1, sum dp xhat2 } with dp = dout * act'(p);  apply: dx_i = a dp - b - xhat_i c

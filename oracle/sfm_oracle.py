@@ -526,7 +526,7 @@ def pool_latents(z, T):
     return out
 
 
-def enhance_path(sds, wave, sample_rate, use_memory=False, num_heads=4):
+def enhance_path(sds, wave, sample_rate, use_memory=False, num_heads=4, bn_train=False):
     """North-star composition with the glue G1-G3:
       PA -> pool to T frames -> CPEA(z_real) -> STFT -> [memory] -> MSA ->
       apply_mask -> iSTFT.  sds: dict of state_dicts pa/cpea/msa[/memory]."""
@@ -542,7 +542,7 @@ def enhance_path(sds, wave, sample_rate, use_memory=False, num_heads=4):
     if use_memory:
         mem = memory_forward(sds["memory"], zr_t.mean(dim=-1))     # G2: key = mean over frames
         bias = mem["bias"]
-    mr, mi = msa_forward(sds["msa"], zr_t, zi_t, cpea, nr, ni, num_heads, mag_logit_bias=bias)
+    mr, mi = msa_forward(sds["msa"], zr_t, zi_t, cpea, nr, ni, num_heads, mag_logit_bias=bias, bn_train=bn_train)
     er, ei = apply_mask(nr, ni, mr, mi)
     wav = istft(er, ei, L)
     return {"mask_real": mr, "mask_imag": mi, "enh_real": er, "enh_imag": ei, "enhanced": wav,

@@ -106,11 +106,14 @@ class PerceptionAgent(HipModule):
         if waveform.dim() == 3:
             waveform = waveform.squeeze(1)
         self._require_device(waveform)
-        self._require_inference()
         pk = self._packed(lambda sd: Fn.pack_perception(sd, self.sample_rate))
         return Fn.perception_forward(waveform.float(), pk)
 
     def forward(self, waveform):
+        if (self.training and torch.is_grad_enabled()) or self._wants_autograd(waveform):
+            from .. import train                   # train() (or eval() under autograd): HIP backward kernels
+            self._require_device(waveform)
+            return train.perception_train_forward(self, waveform)
         zcat, sigma = self.forward_channels_last(waveform)
         B, Tpa, D2 = zcat.shape
         D = D2 // 2

@@ -518,6 +518,33 @@ extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B,
   return sfm_pool_time_affine(src, nullptr, nullptr, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, dtype, stream);
 }
 
+// adjoint of pool_time: dsrc[b, t, c] = sum over the windows i that contain t of dout[b, i, c] / |window i|
+__global__ __launch_bounds__(256) void pool_time_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc, int Tin,
+                                                            int Tout, int C, long long ld_dout, long long ld_dsrc) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  long long lo = ((long long)t * Tout) / Tin;
+  long long hi = (((long long)(t + 1)) * Tout + Tin - 1) / Tin - 1;
+  if (hi > Tout - 1) hi = Tout - 1;
+  float acc = 0.f;
+  for (long long i = lo; i <= hi; ++i) {
+    const long long s = (i * Tin) / Tout, e = ((i + 1) * Tin + Tout - 1) / Tout;
+    acc += dout[((long long)b * Tout + i) * ld_dout + c] / (float)(e - s);
+  }
+  dsrc[((long long)b * Tin + t) * ld_dsrc + c] = acc;
+}
+
+extern "C" int sfm_pool_time_bwd(const float* dout, float* dsrc, int B, int Tin, int Tout, int C, long long ld_dout,
+                                 long long ld_dsrc, void* stream) {
+  if (!dout || !dsrc) return SFM_ERR_ARG;
+  if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0 || Tin > 65535 * 16 || B > 65535) return SFM_ERR_SHAPE;
+  dim3 grid((C + 255) / 256, Tin, B), block(256);
+  SFM_LAUNCH(pool_time_bwd_kernel, grid, block, 0, (hipStream_t)stream, dout, dsrc, Tin, Tout, C, ld_dout, ld_dsrc);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
 // log1p-magnitude normalisation of the noisy STFT (agents/msa.py:134-137) written as
 // 16-bit into the fusion operand: cols [0,F) real, [F,2F) imag, [2F, 2F+zpad) zero.
 template <class T>

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sfm_convert_rows": [c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_transpose": [c_vp, c_vp, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_vp],
     "sfm_pool_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
+    "sfm_pool_time_bwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_vp],
     "sfm_pool_time_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_stft_lognorm_pack": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_i, c_vp],
     "sfm_polar_mask": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_f, c_ll, c_ll,
@@ -69,6 +70,8 @@ SIGNATURES = {
                                   c_vp],
     "sfm_ssnr_frames": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp],
     "sfm_stoi_frames": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "sfm_sinc_wgrad_scratch_floats": [c_i, c_i, c_i, c_i],
+    "sfm_sinc_wgrad": [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_gn_bwd_reduce": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_gn_bwd_apply": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
                          c_vp],

@@ -386,6 +386,16 @@ def transpose(src, dst, B, R, C, src_batch, src_row, dst_batch, dst_row):
           *_cost_of("transpose", locals()))
 
 
+def pool_time_bwd(dout32, B, Tin, Tout, C):
+    """adjoint of pool_time: dout fp32 [B, Tout, C] -> dsrc fp32 [B, Tin, C]"""
+    L = _lib.load()
+    dout32 = dout32.contiguous()
+    dsrc = torch.empty(B, Tin, C, device=dout32.device, dtype=torch.float32)
+    _call("pool_time_bwd", L.sfm_pool_time_bwd, (_p(dout32), _p(dsrc), B, Tin, Tout, C, C, C, _stream()), 0.0,
+          4.0 * B * (Tin + Tout) * C)
+    return dsrc
+
+
 def pool_time(src32, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, scale=None, shift=None):
     """adaptive average pooling over time; scale / shift [B, C]: out = scale * avg + shift (pooled GroupNorm output)"""
     L = _lib.load()
@@ -528,6 +538,17 @@ def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits)
     L = _lib.load()
     _call("loss_bwd", L.sfm_polar_mask_bwd, (_p(lm), _p(lp), _p(nr), _p(ni), _p(der), _p(dei), _p(dlog), M, F, float(phase_scale),
                                              ld_logits, dlog.stride(0), _stream()), 0.0, 32.0 * M * F)
+
+
+def sinc_wgrad(wave, dy, C, K):
+    """dfilt [C, K] = sum_{b,l} dy[b, l, c] * wave[b, l + k - K//2]   (dy [B, L, C] 16-bit or fp32)"""
+    L_ = _lib.load()
+    B, L = wave.shape
+    dfilt = torch.zeros(C, K, device=wave.device, dtype=torch.float32)
+    scratch = torch.empty(int(L_.sfm_sinc_wgrad_scratch_floats(B, L, C, K)), device=wave.device, dtype=torch.float32)
+    _call("sinc_wgrad", L_.sfm_sinc_wgrad, (_p(wave), _p(dy), 1 if dy.dtype == torch.float32 else 0, _p(dfilt), _p(scratch), B, L, C,
+                                            K, _dt(), _stream()), 2.0 * B * L * C * K, B * L * (4.0 + C * dy.element_size()))
+    return dfilt
 
 
 def gn_stats(partial, rows, C, G):

@@ -765,3 +765,197 @@ class IstftFunction(torch.autograd.Function):
                         padl=n_fft // 2 - (n_fft - win) // 2, K=win, N=2 * F, o_batch_stride=T * F, ldm=F, ldn=1, mode=0,
                         out2=di, nsplit=F)
         return dr.to(d0), di.to(d1), None, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# PerceptionAgent (agents/perception.py:132-254) in training mode
+# ---------------------------------------------------------------------------
+def sinc_filters_autograd(low_hz_, band_hz_, window, n_, sample_rate, min_low_hz=50.0, min_band_hz=50.0):
+    """The analytic band-pass bank of SincConv1d.forward (agents/perception.py:88-112) as differentiable torch ops on the
+    [C, K] = [64, 251] filter matrix: the chain rule from the tap gradient (sfm_sinc_wgrad) to the 2 x 64 cut-off
+    parameters.  Same quirk as the reference: the cut-offs are divided by the sample rate although n_ already is."""
+    low = min_low_hz + low_hz_.abs()
+    high = torch.clamp(low + min_band_hz + band_hz_.abs(), max=sample_rate / 2.0)
+    f_lo, f_hi = low / sample_rate, high / sample_rate
+    left = (torch.sin(f_hi * n_) - torch.sin(f_lo * n_)) / (n_ / 2.0 + 1e-8)
+    bp = torch.cat([left, 2.0 * (f_hi - f_lo), left.flip(dims=[1])], dim=1) * window
+    return bp / (bp.abs().sum(dim=1, keepdim=True) + 1e-8)
+
+
+def _pa_param_names(pa):
+    return [k for k, _ in pa.named_parameters()]
+
+
+class PerceptionFunction(torch.autograd.Function):
+    """waveform [B, L] -> latents zcat [B, T_pa, 2D] fp32 (z_real | z_imag).  Forward = the inference kernels of
+    functional.perception_forward, keeping every raw conv output and its GroupNorm statistics; backward = GroupNorm /
+    GELU backward kernels, Conv1d input and weight gradients as implicit GEMMs, the FIR tap gradient and, through
+    sinc_filters_autograd, the gradients of the 128 sinc parameters.  The waveform itself gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, wave, pa, *params):
+        from . import functional as Fn
+        names = _pa_param_names(pa)
+        P = dict(zip(names, params))
+        dt = ops.compute_dtype()
+        wave = wave.detach().float().contiguous()
+        B, L = wave.shape
+        dev = wave.device
+        fs = float(pa.sample_rate)
+        sc_ = pa.sinc_conv
+        with torch.no_grad():
+            filt = sinc_filters_autograd(_f32(P["sinc_conv.low_hz_"]), _f32(P["sinc_conv.band_hz_"]), sc_.window.float(),
+                                         sc_.n_.float(), fs).contiguous()
+        C0, K = filt.shape
+        raw0 = torch.empty(B, L, C0, device=dev, dtype=dt)
+        part0, P0 = ops.sinc_fir16(wave, filt, raw0, B, L, C0, K)
+        nodes = []
+
+        def norm(raws, parts, Ps, gws, gbs, G, rows, act, out_dtype):
+            """GroupNorm (+ second branch) + activation; remembers what the backward needs"""
+            C = raws[0].shape[-1]
+            tabs = []
+            for r, p_, pn, gw, gb in zip(raws, parts, Ps, gws, gbs):
+                s, h = ops.gn_finalize(p_, _f32(gw), _f32(gb), B, pn, G, C, rows)
+                mean, rstd = ops.gn_stats(p_, rows, C, G)
+                tabs.append((s, h, mean, rstd))
+            out = torch.empty(B, rows, C, device=dev, dtype=out_dtype)
+            if len(raws) == 2:
+                ops.gn_apply(raws[0], tabs[0][0], tabs[0][1], out, B, rows, C, act=act, x2=raws[1], sc2=tabs[1][0], sh2=tabs[1][1])
+            else:
+                ops.gn_apply(raws[0], tabs[0][0], tabs[0][1], out, B, rows, C, act=act)
+            return out, tabs
+
+        x, t0 = norm([raw0], [part0], [P0], [P["sinc_norm.weight"]], [P["sinc_norm.bias"]], 8, L, 1, dt)
+        saved = {"wave": wave, "raw0": raw0, "t0": t0, "x0": x, "blocks": []}
+        Lc = L
+        for i in range(3):
+            pre = "conv_blocks.%d." % i
+            w1, b1 = P[pre + "main.0.weight"], P[pre + "main.0.bias"]
+            w2, b2 = P[pre + "main.3.weight"], P[pre + "main.3.bias"]
+            ws, bs = P[pre + "skip.0.weight"], P[pre + "skip.0.bias"]
+            C = w1.shape[0]
+            G = min(16, C)
+            r1, p1, P1, L1 = Fn._conv_gn(x, ops.pack_linear(_f32(w1), _f32(b1)), B, Lc, 2, 3, G, dt)
+            a1, t1 = norm([r1], [p1], [P1], [P[pre + "main.1.weight"]], [P[pre + "main.1.bias"]], G, L1, 1, dt)
+            r2, p2, P2, _ = Fn._conv_gn(a1, ops.pack_linear(_f32(w2), _f32(b2)), B, L1, 1, 1, G, dt)
+            rs, ps, Ps, _ = Fn._conv_gn(x, ops.pack_linear(_f32(ws), _f32(bs)), B, Lc, 2, 0, G, dt)
+            xo, t2 = norm([r2, rs], [p2, ps], [P2, Ps], [P[pre + "main.4.weight"], P[pre + "skip.1.weight"]],
+                          [P[pre + "main.4.bias"], P[pre + "skip.1.bias"]], G, L1, 1, dt)
+            saved["blocks"].append(dict(xin=x, Lin=Lc, L1=L1, C=C, G=G, r1=r1, t1=t1, a1=a1, r2=r2, rs=rs, t2=t2))
+            x, Lc = xo, L1
+        D = P["downsample.0.weight"].shape[0]
+        rd, pd, Pd, Tpa = Fn._conv_gn(x, ops.pack_linear(_f32(P["downsample.0.weight"]), _f32(P["downsample.0.bias"])), B, Lc, 2,
+                                      2, 16, dt)
+        xd, td = norm([rd], [pd], [Pd], [P["downsample.1.weight"]], [P["downsample.1.bias"]], 16, Tpa, 1, dt)
+        wz = torch.cat([_f32(P["real_proj.0.weight"]), _f32(P["imag_proj.0.weight"])], dim=0)
+        bz = torch.cat([_f32(P["real_proj.0.bias"]), _f32(P["imag_proj.0.bias"])], dim=0)
+        gz = torch.cat([_f32(P["real_proj.1.weight"]), _f32(P["imag_proj.1.weight"])])
+        hz = torch.cat([_f32(P["real_proj.1.bias"]), _f32(P["imag_proj.1.bias"])])
+        rz, pz, Pz, _ = Fn._conv_gn(xd, ops.pack_linear(wz, bz), B, Tpa, 1, 0, 32, torch.float32)
+        zcat, tz = norm([rz], [pz], [Pz], [gz], [hz], 32, Tpa, 0, torch.float32)
+        saved.update(x3=x, L3=Lc, rd=rd, td=td, xd=xd, Tpa=Tpa, D=D, rz=rz, tz=tz, wz=wz, gz=gz, filt_shape=(C0, K))
+        ctx.saved, ctx.P, ctx.names, ctx.pa = saved, P, names, pa
+        ctx.dtypes = [t.dtype for t in params]
+        return zcat
+
+    @staticmethod
+    def backward(ctx, dz):
+        S, P, pa = ctx.saved, ctx.P, ctx.pa
+        dt = ops.compute_dtype()
+        B, L = S["wave"].shape
+        Tpa, D = S["Tpa"], S["D"]
+        G = {}
+
+        def gnb(dout, act, groups, raws, tabs, gammas):
+            a = []
+            for r, t, g in zip(raws, tabs, gammas):
+                a += [r, t[0], t[1], t[2], t[3], _f32(g)]
+            return ops.gn_act_backward(dout, act, groups, *a, dx_dtype=dt)
+
+        # latent heads: GroupNorm(16) per half, 1x1 conv (real | imag stacked)
+        d_rz, dgz, dbz = gnb(dz.detach().float().contiguous(), 0, 32, [S["rz"]], S["tz"], [S["gz"]])
+        G["real_proj.1.weight"], G["imag_proj.1.weight"] = dgz[:D], dgz[D:]
+        G["real_proj.1.bias"], G["imag_proj.1.bias"] = dbz[:D], dbz[D:]
+        dWz, dbz0 = ops.conv_wgrad16(d_rz.reshape(B * Tpa, 2 * D), S["xd"], B, Tpa, Tpa, D, 2 * D, 1, 1, 0)
+        G["real_proj.0.weight"], G["imag_proj.0.weight"] = dWz[:D], dWz[D:]
+        G["real_proj.0.bias"], G["imag_proj.0.bias"] = dbz0[:D], dbz0[D:]
+        d_xd = ops.conv_dgrad16(d_rz, S["wz"], B, Tpa, Tpa, 1, 0)
+        # downsample: conv k5 s2 p2 -> GN(16) -> GELU
+        d_rd, G["downsample.1.weight"], G["downsample.1.bias"] = gnb(d_xd, 1, 16, [S["rd"]], S["td"], [P["downsample.1.weight"]])
+        L3 = S["L3"]
+        G["downsample.0.weight"], G["downsample.0.bias"] = ops.conv_wgrad16(d_rd.reshape(B * Tpa, D), S["x3"], B, Tpa, L3, D, D, 5, 2, 2)
+        dx = ops.conv_dgrad16(d_rd, P["downsample.0.weight"], B, Tpa, L3, 2, 2)
+        # residual blocks, last to first
+        for i in (2, 1, 0):
+            b_ = S["blocks"][i]
+            pre = "conv_blocks.%d." % i
+            C, Gp, L1, Lin = b_["C"], b_["G"], b_["L1"], b_["Lin"]
+            Cin = b_["xin"].shape[-1]
+            res = gnb(dx, 1, Gp, [b_["r2"], b_["rs"]], b_["t2"], [P[pre + "main.4.weight"], P[pre + "skip.1.weight"]])
+            d_r2, G[pre + "main.4.weight"], G[pre + "main.4.bias"], d_rs, G[pre + "skip.1.weight"], G[pre + "skip.1.bias"] = res
+            G[pre + "main.3.weight"], G[pre + "main.3.bias"] = ops.conv_wgrad16(d_r2.reshape(B * L1, C), b_["a1"], B, L1, L1, C, C, 3, 1, 1)
+            d_a1 = ops.conv_dgrad16(d_r2, P[pre + "main.3.weight"], B, L1, L1, 1, 1)
+            d_r1, G[pre + "main.1.weight"], G[pre + "main.1.bias"] = gnb(d_a1, 1, Gp, [b_["r1"]], b_["t1"], [P[pre + "main.1.weight"]])
+            G[pre + "main.0.weight"], G[pre + "main.0.bias"] = ops.conv_wgrad16(d_r1.reshape(B * L1, C), b_["xin"], B, L1, Lin, Cin, C, 7, 2, 3)
+            G[pre + "skip.0.weight"], G[pre + "skip.0.bias"] = ops.conv_wgrad16(d_rs.reshape(B * L1, C), b_["xin"], B, L1, Lin, Cin, C, 1, 2, 0)
+            dx = ops.conv_dgrad16(d_r1, P[pre + "main.0.weight"], B, L1, Lin, 2, 3)
+            dx = ops.conv_dgrad16(d_rs, P[pre + "skip.0.weight"], B, L1, Lin, 2, 0, accumulate_into=dx)
+        # sinc stage: GN(8) + GELU, then the FIR tap gradient and the chain rule to the cut-off parameters
+        d_raw0, G["sinc_norm.weight"], G["sinc_norm.bias"] = gnb(dx, 1, 8, [S["raw0"]], S["t0"], [P["sinc_norm.weight"]])
+        C0, K = S["filt_shape"]
+        dfilt = ops.sinc_wgrad(S["wave"], d_raw0, C0, K)
+        sc_ = pa.sinc_conv
+        with torch.enable_grad():
+            lo = _f32(P["sinc_conv.low_hz_"]).clone().requires_grad_(True)
+            bw = _f32(P["sinc_conv.band_hz_"]).clone().requires_grad_(True)
+            filt = sinc_filters_autograd(lo, bw, sc_.window.float(), sc_.n_.float(), float(pa.sample_rate))
+            glo, gbw = torch.autograd.grad(filt, [lo, bw], grad_outputs=dfilt)
+        G["sinc_conv.low_hz_"], G["sinc_conv.band_hz_"] = glo, gbw
+        out = []
+        for k, dtp in zip(ctx.names, ctx.dtypes):
+            g = G.get(k)
+            out.append(None if g is None else g.reshape(P[k].shape).to(dtp))     # uncertainty head: no gradient path here
+        ctx.saved = None
+        return (None, None) + tuple(out)
+
+
+class PoolTimeFunction(torch.autograd.Function):
+    """glue G1 under autograd: adaptive average pooling of channels-last latents [B, Tin, C] fp32 to Tout frames"""
+
+    @staticmethod
+    def forward(ctx, x, Tout):
+        x = x.detach().float().contiguous()
+        B, Tin, C = x.shape
+        out = torch.empty(B, Tout, C, device=x.device, dtype=torch.float32)
+        ops.pool_time(x, None, out, B, Tin, Tout, C, C, C)
+        ctx.dims = (B, Tin, Tout, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Tin, Tout, C = ctx.dims
+        return ops.pool_time_bwd(dout.detach().float(), B, Tin, Tout, C), None
+
+
+def perception_latents_train(pa, waveform):
+    """channels-last latents [B, T_pa, 2D] (z_real | z_imag) of the PerceptionAgent as an autograd node"""
+    if waveform.dim() == 3:
+        waveform = waveform.squeeze(1)
+    return PerceptionFunction.apply(waveform, pa, *[p for _, p in pa.named_parameters()])
+
+
+def perception_train_forward(pa, waveform):
+    """PerceptionAgent.forward (agents/perception.py:216-251) under autograd: (z_real, z_imag [B, D, T_pa], sigma).  sigma
+    is evaluated on the inference kernels and carries no gradient (the uncertainty head is not part of any objective on
+    the path)."""
+    from . import functional as Fn
+    if waveform.dim() == 3:
+        waveform = waveform.squeeze(1)
+    zcat = perception_latents_train(pa, waveform)
+    with torch.no_grad():
+        pk = pa._packed(lambda sd: Fn.pack_perception(sd, pa.sample_rate))
+        _, sigma = Fn.perception_forward(waveform.detach().float(), pk, latents=False)
+    D = zcat.shape[-1] // 2
+    z = zcat.transpose(1, 2)
+    return z[:, :D], z[:, D:], sigma.reshape(sigma.shape[0], 1, -1)

@@ -155,31 +155,32 @@ class EnhancementPath(HipModule):
                      [(b.data_ptr(), b._version) for n, b in self.named_buffers() if "usage" not in n and "num_queries" not in n])
 
     def freeze_perception(self, flag=True):
-        """The PerceptionAgent's backward kernels are not built yet: train() of the composition needs the front-end
-        frozen explicitly (its GroupNorm-only stack has no train/eval difference, so the forward is exact either way)."""
+        """Train CPEA / memory / MaskSynthesisAgent on a frozen front-end: the PerceptionAgent then runs on the inference
+        kernels (its GroupNorm-only stack has no train/eval difference, so the forward is the same either way) and keeps
+        none of its activations."""
         self.__dict__["_sfm_pa_frozen"] = bool(flag)
         for p in self.perception.parameters():
             p.requires_grad_(not flag)
         return self
 
     def _train_forward(self, waveform):
-        """train() mode with a frozen front-end: PA on the inference kernels (no graph), then CPEA (BPTT), EpisodicMemory,
-        MaskSynthesisAgent, apply_mask and iSTFT as HIP autograd nodes; glue G1-G3 as in eval()."""
+        """train() mode: PerceptionAgent, pooling (glue G1), CPEA (BPTT), EpisodicMemory, MaskSynthesisAgent, apply_mask and
+        iSTFT as HIP autograd nodes; glue G1-G3 as in eval().  With freeze_perception() the front-end runs without autograd."""
         from .. import train
-        if not self.__dict__.get("_sfm_pa_frozen", False):
-            raise NotImplementedError("EnhancementPath.train(): the PerceptionAgent backward is not part of this build; call "
-                                      "path.freeze_perception() to train CPEA / memory / MaskSynthesisAgent on a frozen "
-                                      "front-end, or use eval() / torch.no_grad().")
         wave = waveform.float().contiguous()
         B, L = wave.shape
         T = 1 + L // Fn.HOP
         D = self.perception.encoder_channels if hasattr(self.perception, "encoder_channels") else 256
         with torch.no_grad():
-            pa = self.perception._packed(lambda sd: Fn.pack_perception(sd, self.sample_rate))     # frozen: packed once
-            (rz, sz, hz), _sigma = Fn.perception_forward(wave, pa, latents=False)
-            zp = torch.empty(B, T, 2 * D, device=wave.device, dtype=torch.float32)
-            ops.pool_time(rz, None, zp, B, rz.shape[1], T, 2 * D, 2 * D, 2 * D, scale=sz, shift=hz)      # glue G1
             nr, ni = Fn.stft(wave)
+        if self.__dict__.get("_sfm_pa_frozen", False):
+            with torch.no_grad():
+                pa = self.perception._packed(lambda sd: Fn.pack_perception(sd, self.sample_rate))     # frozen: packed once
+                (rz, sz, hz), _sigma = Fn.perception_forward(wave, pa, latents=False)
+                zp = torch.empty(B, T, 2 * D, device=wave.device, dtype=torch.float32)
+                ops.pool_time(rz, None, zp, B, rz.shape[1], T, 2 * D, 2 * D, 2 * D, scale=sz, shift=hz)      # glue G1
+        else:
+            zp = train.PoolTimeFunction.apply(train.perception_latents_train(self.perception, wave), T)     # glue G1
         z_real, z_imag = zp[..., :D].transpose(1, 2), zp[..., D:].transpose(1, 2)
         cpea = self.cpea(zp[..., :D])
         bias = None

@@ -644,10 +644,11 @@ def test_cpea_train_mode_interlayer_dropout_runs():
     assert torch.isfinite(z.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters())
 
 
-def test_enhancement_path_trains_with_frozen_front_end():
-    """EnhancementPath.train(): PerceptionAgent frozen (inference kernels), CPEA + EpisodicMemory + MaskSynthesisAgent +
-    apply_mask + iSTFT under HIP autograd.  Gradients of a waveform-domain loss vs torch autograd of the oracle's
-    composition with the same frozen front-end; without freeze_perception() train mode refuses loudly."""
+@pytest.mark.parametrize("frozen", [True, False])
+def test_enhancement_path_trains(frozen):
+    """EnhancementPath.train(): PerceptionAgent + pooling + CPEA + EpisodicMemory + MaskSynthesisAgent + apply_mask + iSTFT
+    under HIP autograd (frozen=True: front-end on the inference kernels via freeze_perception()).  Gradients of a
+    waveform-domain loss vs torch autograd of the oracle's composition."""
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
     ops.set_compute_dtype(torch.float16)
@@ -667,39 +668,90 @@ def test_enhancement_path_trains_with_frozen_front_end():
     path = path.cuda().train()
     B, L = 2, 2400
     noisy, clean = _waves(B, L, 395)
-    with pytest.raises(NotImplementedError):
-        path(noisy.cuda())
-    path.freeze_perception()
+    if frozen:
+        path.freeze_perception()
     out = path(noisy.cuda())
     loss = (out["enhanced"] - clean.cuda()).pow(2).mean() * 1e3
     loss.backward()
-    # oracle: same composition, front-end outputs detached
-    T = 1 + L // 80
-    with torch.no_grad():
-        zr, zi, _ = orc.perception_forward(sds["pa"], noisy, 16000)
-        zr_t, zi_t = orc.pool_latents(zr, T), orc.pool_latents(zi, T)
-        nr, ni = orc.stft(noisy)
-    ref = {n: {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and "usage" not in k
-                   else v.clone()) for k, v in sds[n].items()} for n in ("cpea", "msa", "memory")}
-    cp = orc.cpea_forward(ref["cpea"], zr_t.transpose(1, 2))
-    mem = orc.memory_forward(ref["memory"], zr_t.mean(dim=-1))
-    mr, mi = orc.msa_forward(ref["msa"], zr_t, zi_t, cp, nr, ni, 4, mag_logit_bias=mem["bias"], bn_train=True)
-    er, ei = orc.apply_mask(nr, ni, mr, mi)
-    wav = orc.istft(er, ei, L)
-    ref_loss = (wav - clean).pow(2).mean() * 1e3
+    names = ("cpea", "msa", "memory") + (() if frozen else ("pa",))
+
+    def leaf(k, v):
+        return v.dtype.is_floating_point and "running" not in k and "usage" not in k and k.split(".")[-1] not in ("window", "n_")
+    ref = {n: {k: (v.clone().requires_grad_(True) if leaf(k, v) and n in names else v.clone()) for k, v in sds[n].items()}
+           for n in sds}
+    ro = orc.enhance_path(ref, noisy, 16000, use_memory=True, bn_train=True)
+    ref_loss = (ro["enhanced"] - clean).pow(2).mean() * 1e3
     ref_loss.backward()
-    print("path train: loss %.5f (oracle %.5f)" % (float(loss.detach()), float(ref_loss.detach())))
+    print("path train (frozen=%s): loss %.5f (oracle %.5f)" % (frozen, float(loss.detach()), float(ref_loss.detach())))
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-3 * abs(float(ref_loss.detach()))
     worst = ("", 0.0)
-    for name, mod in (("cpea", path.cpea), ("msa", path.msa), ("memory", path.memory)):
-        for k, p_ in mod.named_parameters():
-            if k.endswith("depthwise.bias"):
-                continue
+    mods = {"cpea": path.cpea, "msa": path.msa, "memory": path.memory, "pa": path.perception}
+    for name in names:
+        for k, p_ in mods[name].named_parameters():
             rg = ref[name][k].grad
+            if name == "pa" and k.startswith("uncertainty_head"):
+                assert p_.grad is None and rg is None
+                continue
             assert p_.grad is not None and rg is not None, (name, k)
+            rms = float(rg.pow(2).mean().sqrt())
+            if rms < 1e-7 * float(ref_loss.detach()):
+                # analytically zero gradients (a conv bias in front of a GroupNorm / BatchNorm, band_hz_ behind the clamp)
+                assert float(p_.grad.abs().max()) < 1e-3
+                continue
             r = _rel(p_.grad.cpu(), rg)
             if r > worst[1]:
                 worst = (name + "." + k, r)
     print("  worst parameter-gradient rel rmse: %s %.3e" % worst)
     assert worst[1] < 0.03, worst
-    assert all(p_.grad is None for p_ in path.perception.parameters())
+    if frozen:
+        assert all(p_.grad is None for p_ in path.perception.parameters())
+
+
+@pytest.mark.parametrize("sinc_scale", [2000.0, None])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_perception_agent_train_mode(dt, sinc_scale):
+    """PerceptionAgent (agents/perception.py:216-251) under autograd, for a fixed cotangent on the latents: latents and the
+    gradient of every parameter (sinc cut-offs through the FIR tap gradient, GroupNorms, strided convs) vs torch autograd
+    of the oracle.  The uncertainty head has no gradient path (sigma is not part of the latents)."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.agents import PerceptionAgent
+    ops.set_compute_dtype(dt)
+    sd = synth_sd("PerceptionAgent", 75, sinc_scale=sinc_scale)   # None: the analytic init (band_hz_ not clamped away)
+    m = PerceptionAgent(sample_rate=16000)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    B, L = 2, 3200
+    noisy, _ = _waves(B, L, 76)
+    cr, ci = arr("pcr", (B, 256, L // 16), 77), arr("pci", (B, 256, L // 16), 78)
+    ref_sd = {k: (v.clone().requires_grad_(True) if k.split(".")[-1] not in ("window", "n_") else v.clone()) for k, v in sd.items()}
+    zr_o, zi_o, sg_o = orc.perception_forward(ref_sd, noisy, 16000)
+    ((zr_o * cr).sum() + (zi_o * ci).sum()).backward()
+    zr, zi, sg = m(noisy.cuda())
+    ((zr * cr.cuda()).sum() + (zi * ci.cuda()).sum()).backward()
+    e = rmse(torch.cat([zr, zi], 1).detach().cpu(), torch.cat([zr_o, zi_o], 1).detach())
+    print("PA train-mode latents %s: rmse %.3e (rms %.3e)" % (dt, e, float(zr_o.detach().pow(2).mean().sqrt())))
+    assert e < (3e-3 if dt is torch.float16 else 2e-2)
+    assert rmse(sg.cpu(), sg_o.detach()) < 2e-2 * float(sg_o.abs().max())
+    tol = 0.02 if dt is torch.float16 else 0.1
+    worst = ("", 0.0)
+    for k, p_ in m.named_parameters():
+        if k.startswith("uncertainty_head"):
+            assert p_.grad is None
+            continue
+        rg = ref_sd[k].grad
+        rms = float(rg.pow(2).mean().sqrt())
+        if k.endswith(".bias") and (".main.0." in k or ".main.3." in k or ".skip.0." in k or k.startswith("downsample.0")
+                                     or k.startswith("real_proj.0") or k.startswith("imag_proj.0")):
+            continue                              # conv bias followed by GroupNorm: analytically zero gradient
+        r = _rel(p_.grad.cpu(), rg)
+        print("  d%-36s rel rmse %.3e  ref_rms %.3e" % (k, r, rms))
+        if k.startswith("sinc_conv.") and sinc_scale is None:
+            # analytic init: the normalised filters barely depend on the cut-offs (SURVEY.md F4), d(filter)/d(cut-off) nearly
+            # annihilates the tap gradient (1e-7 against 1e+1 elsewhere) and 16-bit rounding of the incoming gradient dominates.
+            # The tap gradient (test_sinc_fir_tap_gradient) and the chain rule (test_sinc_filter_chain_rule_matches_the_oracle)
+            # are pinned separately; here: finite and of the reference's magnitude.
+            assert bool(torch.isfinite(p_.grad).all()) and float(p_.grad.abs().max()) < 100 * float(rg.abs().max()) + 1e-12
+            continue
+        if r > worst[1]:
+            worst = (k, r)
+    assert worst[1] < tol, worst
