@@ -27,6 +27,9 @@ WORKLOADS = {
     "c3p": (256, 40880, "B256 x 512-frame utterances (L40880, T512) forward"),
     "c3se": (256, 64000, "B256 x 4 s (L64000, T801) SpeechEnhancer training step: STFT, forward, SI-SNR + L1 + multi-res "
                          "STFT objective, backward, gradient all-reduce, clip, AdamW (BASELINE configs[2]/[3])"),
+    "c2t": (64, 64000, "B64 x 4 s (L64000, T801) SincNet+Conformer path (PerceptionAgent, CPEA, MaskSynthesisAgent) training "
+                       "step: forward, SI-SNR + L1 + multi-res STFT objective, backward through every module, all-reduce, "
+                       "clip, AdamW"),
     "c5": (32, 480000, "B32 x 30 s (L480000, T6001) forward with episodic memory (BASELINE configs[4], fwd)"),
 }
 PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "hbm": 8000.0}      # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
@@ -113,8 +116,41 @@ def cpu_baseline_train(sd, L, iters=8, batch=8):
                       "iterations, %.1f s each; no optimiser step" % (batch, L, iters, dt)}
 
 
+def cpu_baseline_path_train(weights, L, iters=3, batch=4):
+    """oracle forward + backward of the whole-path training step (torch autograd on the host cores), small batch."""
+    import torch
+    from oracle import sfm_oracle as orc
+    from sincformer_metacog_speech_enhancement_amd import synthetic as syn
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    noisy, clean = syn.synth_wave(batch, L, 77)
+    noisy, clean = torch.from_numpy(noisy), torch.from_numpy(clean)
+
+    def subd(prefix):
+        p = prefix + "."
+        out = {}
+        for k, v in weights.items():
+            if k.startswith(p):
+                v = torch.from_numpy(v) if not torch.is_tensor(v) else v
+                leaf = v.dtype.is_floating_point and "running" not in k and k.split(".")[-1] not in ("window", "n_")
+                out[k[len(p):]] = v.clone().requires_grad_(True) if leaf else v.clone()
+        return out
+    sds = {"pa": subd("perception"), "cpea": subd("cpea"), "msa": subd("msa")}
+    t0 = time.perf_counter()
+    for i in range(iters):
+        print("[bench] cpu baseline (path training) iter %d/%d" % (i + 1, iters), file=sys.stderr, flush=True)
+        total, _, _ = orc.path_loss(sds, noisy, clean, 16000, bn_train=True)
+        total.backward()
+    dt = (time.perf_counter() - t0) / iters
+    T = 1 + L // 80
+    return {"value": batch * T / dt, "unit": "STFT frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (torch fp32 autograd restatement) forward+backward of the same step, batch %d x %d samples, %d "
+                      "iterations, %.1f s each; no optimiser step" % (batch, L, iters, dt)}
+
+
 def main_train(args):
-    """--workload c3se: one training step of training/conformer_pipeline.py (SpeechEnhancer) per bench step."""
+    """--workload c3se / c2t: one training step of training/conformer_pipeline.py per bench step (c3se: the reference's
+    SpeechEnhancer; c2t: the north-star SincNet + Conformer composition)."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -132,10 +168,15 @@ def main_train(args):
     if args.batch:
         B = args.batch
     T = 1 + L // 80
-    model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, 4321).items()}
-    model.load_state_dict(sd)                                       # same weights on every rank
+    whole_path = args.workload == "c2t"
+    if whole_path:
+        from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import compute_path_loss
+        model, sd = build_path(args.dtype, seed=4321)
+    else:
+        model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, 4321).items()}
+        model.load_state_dict(sd)                                   # same weights on every rank
     model.cuda().train()
     opt = FlatAdamW(model.parameters(), lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0)
     noisy, clean = syn.synth_wave(B, L, 1234 + rank)                # each rank trains on its own utterance shard
@@ -144,6 +185,11 @@ def main_train(args):
 
     def step():
         opt.zero_grad()
+        if whole_path:
+            total, _ = compute_path_loss(model, noisy, clean)
+            total.backward()
+            opt.step(loss=total)
+            return total
         nr, ni = batch_stft(noisy, 256, 80, 160)
         cr, ci = batch_stft(clean, 256, 80, 160)
         total, _ = compute_loss(model, nr, ni, clean, cr, ci)
@@ -195,7 +241,7 @@ def main_train(args):
             "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
                        "sharding": "utterances over ranks; one bucketed all-reduce (RCCL) of the flat fp32 gradient per step, "
                                    "overlapped with backward", "optimizer": "AdamW lr 5e-4 betas (0.9, 0.98) wd 0.01, clip 5.0",
-                       "dropout": 0.15},
+                       "dropout": "module defaults (0.1 / 0.15)" if whole_path else 0.15},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                          "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
                          "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]},
@@ -207,7 +253,7 @@ def main_train(args):
         print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
               (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_train(sd, L)
+            line["cpu_baseline"] = cpu_baseline_path_train(sd, L) if whole_path else cpu_baseline_train(sd, L)
         if args.breakdown:
             with open(args.breakdown, "w") as fh:
                 json.dump(breakdown, fh, indent=1)
@@ -228,7 +274,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound small batches)")
     args = ap.parse_args()
-    if args.workload == "c3se":
+    if args.workload in ("c3se", "c2t"):
         return main_train(args)
 
     import torch

@@ -503,11 +503,23 @@ def enhancer_loss(sd, noisy_wav, clean_wav, num_heads=4, bn_train=False):
     nr, ni = stft(noisy_wav)
     cr, ci = stft(clean_wav)
     er, ei, _ = speech_enhancer_forward(sd, nr, ni, num_heads, bn_train)
+    return spectrum_objective(er, ei, clean_wav, cr, ci)
+
+
+def spectrum_objective(er, ei, clean_wav, cr, ci):
+    """the three terms of training/conformer_pipeline.py:553-572 on an enhanced spectrum: total, neg_sisnr, enh_wav"""
     enh = istft(er, ei, _t(clean_wav).shape[-1])
     l_si = si_snr_loss(enh, clean_wav)
     l_mag = (torch.sqrt(er ** 2 + ei ** 2 + 1e-8) - torch.sqrt(cr ** 2 + ci ** 2 + 1e-8)).abs().mean()
     l_st = mr_stft_loss(enh, clean_wav)
     return l_si + 0.5 * l_mag + l_st, l_si, enh
+
+
+def path_loss(sds, noisy_wav, clean_wav, sample_rate, use_memory=False, num_heads=4, bn_train=False):
+    """the same objective on the north-star composition (enhance_path): total, neg_sisnr, enh_wav"""
+    out = enhance_path(sds, noisy_wav, sample_rate, use_memory, num_heads, bn_train)
+    cr, ci = stft(clean_wav)
+    return spectrum_objective(out["enh_real"], out["enh_imag"], clean_wav, cr, ci)
 
 
 # ----------------------------------------------------------------------------

@@ -127,6 +127,18 @@ def compute_loss(model, noisy_real, noisy_imag, clean_wav, clean_real, clean_ima
     return total, aux[0]
 
 
+def compute_path_loss(path, noisy_wav, clean_wav):
+    """The objective of ConformerPipeline._compute_loss (training/conformer_pipeline.py:539-572) on the north-star
+    composition (EnhancementPath in train() mode): SI-SNR + 0.5 * L1 magnitude + multi-resolution STFT of the enhanced
+    spectrum against the clean utterance.  Returns (total, neg_sisnr)."""
+    from .. import train
+    out = path(noisy_wav, want=("mask", "spectrum"))
+    with torch.no_grad():
+        cr, ci = Fn.stft(clean_wav.float().contiguous())
+    total, aux, _ = train.EnhancerLossFunction.apply(out["enh_real"], out["enh_imag"], clean_wav, cr, ci, Fn.N_FFT, Fn.HOP, Fn.WIN)
+    return total, aux[0]
+
+
 class EnhancementPath(HipModule):
     """North-star composition: PerceptionAgent -> (pool to STFT frames) -> CPEA -> STFT ->
     [EpisodicMemory] -> MaskSynthesisAgent -> apply_mask -> iSTFT, fused in the internal
@@ -163,7 +175,7 @@ class EnhancementPath(HipModule):
             p.requires_grad_(not flag)
         return self
 
-    def _train_forward(self, waveform):
+    def _train_forward(self, waveform, want=("mask", "wave")):
         """train() mode: PerceptionAgent, pooling (glue G1), CPEA (BPTT), EpisodicMemory, MaskSynthesisAgent, apply_mask and
         iSTFT as HIP autograd nodes; glue G1-G3 as in eval().  With freeze_perception() the front-end runs without autograd."""
         from .. import train
@@ -191,14 +203,15 @@ class EnhancementPath(HipModule):
             out.update(mem_bias=mem["bias"], mem_gate=mem["gate"], mem_top=mem["top_indices"], mem_sim=mem["similarity"])
         mr, mi = self.msa(z_real, z_imag, cpea, nr, ni, mag_logit_bias=bias)
         er, ei = train.ComplexMulFunction.apply(nr, ni, mr, mi)
-        out.update(mask_real=mr, mask_imag=mi, noisy_real=nr, noisy_imag=ni,
-                   enhanced=train.IstftFunction.apply(er, ei, L, Fn.N_FFT, Fn.HOP, Fn.WIN))
+        out.update(mask_real=mr, mask_imag=mi, noisy_real=nr, noisy_imag=ni, enh_real=er, enh_imag=ei)
+        if "wave" in want:
+            out["enhanced"] = train.IstftFunction.apply(er, ei, L, Fn.N_FFT, Fn.HOP, Fn.WIN)
         return out
 
     def forward(self, waveform, want=("mask", "wave")):
         self._require_device(waveform)
         if self.training and torch.is_grad_enabled():
-            return self._train_forward(waveform)
+            return self._train_forward(waveform, want)
         packs = self._packed(self._pack)
         return Fn.enhance_path(waveform.float(), packs, H=self.msa.conformer.num_heads,
                                use_memory=self.memory is not None, want=want)

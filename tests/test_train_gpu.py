@@ -755,3 +755,47 @@ def test_perception_agent_train_mode(dt, sinc_scale):
         if r > worst[1]:
             worst = (k, r)
     assert worst[1] < tol, worst
+
+
+def test_path_objective_and_optimizer_step():
+    """compute_path_loss (objective of training/conformer_pipeline.py:539-572 on the whole SincNet + Conformer composition):
+    loss value vs the oracle, every trainable parameter receives a finite gradient, and a FlatAdamW step moves them."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath, compute_path_loss
+    ops.set_compute_dtype(torch.float16)
+    sds = {"pa": synth_sd("PerceptionAgent", 491, sinc_scale=2000.0), "cpea": synth_sd("CorrelationPhaseEstimationAgent", 492),
+           "msa": synth_sd("MaskSynthesisAgent", 493)}
+    path = EnhancementPath(sample_rate=16000)
+    path.perception.load_state_dict(sds["pa"])
+    path.cpea.load_state_dict(sds["cpea"])
+    path.msa.load_state_dict(sds["msa"])
+    for mod in path.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    path.cpea.lstm.dropout = 0.0
+    path = path.cuda().train()
+    B, L = 2, 4000
+    noisy, clean = _waves(B, L, 495)
+    opt = FlatAdamW([p_ for n, p_ in path.named_parameters() if "uncertainty_head" not in n], lr=5e-4, betas=(0.9, 0.98),
+                    weight_decay=0.01, max_norm=5.0)
+    opt.zero_grad()
+    total, neg = compute_path_loss(path, noisy.cuda(), clean.cuda())
+    total.backward()
+    ref_total, ref_neg, _ = orc.path_loss(sds, noisy, clean, 16000, bn_train=True)
+    print("path objective: %.5f (oracle %.5f), -SI-SNR %.4f (oracle %.4f)" % (float(total.detach()), float(ref_total),
+                                                                             float(neg.detach()), float(ref_neg)))
+    assert abs(float(total.detach()) - float(ref_total)) < 5e-3
+    assert abs(float(neg.detach()) - float(ref_neg)) < 5e-3
+    for n, p_ in path.named_parameters():
+        if "uncertainty_head" in n:
+            continue
+        assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n
+    first = next(iter(path.perception.parameters())).detach().clone()
+    opt.step(loss=total)
+    torch.cuda.synchronize()
+    st = opt.stats()
+    assert not st["skipped"] and st["step"] == 1 and math.isfinite(st["grad_norm"]), st
+    assert not torch.equal(first, next(iter(path.perception.parameters())).detach())
