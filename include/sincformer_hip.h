@@ -225,15 +225,29 @@ int sfm_stoi_frames(const float* cr, const float* ci, const float* er, const flo
 long long sfm_sinc_wgrad_scratch_floats(int B, int L, int C, int K);
 int sfm_sinc_wgrad(const float* x, const void* dy, int dy_f32, float* dfilt, float* scratch, int B, int L, int C, int K,
                    int dtype, void* stream);
+/* The same tap gradient on the matrix cores for a 16-bit dy (K = 251 taps, centre 125): sfm_sinc_shift_pack writes 8 copies
+ * of every utterance, zero-padded and shifted by 0..7 samples, xs 16-bit [B][8][sfm_sinc_shift_len(L)], so that the 8-tap
+ * chunk at any sample is one aligned 16-byte load; sfm_sinc_wgrad16: dW fp32 [C][256] += dy^T * Toeplitz(x) (columns
+ * 251..255 are scratch), dW zeroed by the caller. */
+long long sfm_sinc_shift_len(int L);
+int sfm_sinc_shift_pack(const float* x, void* xs, int B, int L, int dtype, void* stream);
+int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, void* stream);
 /* Backward of the PerceptionAgent's GroupNorm nodes out = act(GN(x1) [+ GN(x2)]) (agents/perception.py:121-129, 157,
- * 192-206), channels-last [B, L, C].  tab = [4][B][C] fp32 (scale, shift, group mean, group rstd, broadcast to channels);
- * reduce: S [B][C][3] += { sum dp, sum dp xhat1, sum dp xhat2 } with dp = dout * act'(p);  apply: dx_i = a dp - b - xhat_i c
- * with coef = [3][B][C] fp32 built by the host from S (see train.py). */
-int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* tab1, const void* x2,
-                      int x2_f32, const float* tab2, float* S, int B, int L, int C, int act, int dtype, void* stream);
-int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* tab1, const float* coef1,
-                     void* dx1, int dx1_f32, const void* x2, int x2_f32, const float* tab2, const float* coef2, void* dx2,
-                     int dx2_f32, int B, int L, int C, int act, int dtype, void* stream);
+ * 192-206), channels-last [B, L, C], C a power of two in [64, 2048].  sc / sh [B, C] fp32: the forward's scale and shift;
+ * mean / rstd [B, G].  reduce: S [B][3][C] += { sum dp, sum dp xhat1, sum dp xhat2 } with dp = dout * act'(p) (S zeroed by
+ * the caller);  coefs: coef = [3][B][C] (a, b, c) and dparam [3][C] += (dbeta, dgamma1, dgamma2) (zeroed by the caller);
+ * apply: dx_i = a dp - b - xhat_i c. */
+int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
+                      const float* mean1, const float* rstd1, const void* x2, int x2_f32, const float* sc2,
+                      const float* sh2, const float* mean2, const float* rstd2, float* S, int B, int L, int C, int G,
+                      int act, int dtype, void* stream);
+int sfm_gn_bwd_coefs(const float* S, const float* gamma1, const float* rstd1, const float* gamma2, const float* rstd2,
+                     float* coef1, float* coef2, float* dparam, int B, int L, int C, int G, void* stream);
+int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
+                     const float* mean1, const float* rstd1, const float* coef1, void* dx1, int dx1_f32, const void* x2,
+                     int x2_f32, const float* sc2, const float* sh2, const float* mean2, const float* rstd2,
+                     const float* coef2, void* dx2, int dx2_f32, int B, int L, int C, int G, int act, int dtype,
+                     void* stream);
 /* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
  * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
  * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */

@@ -13,9 +13,13 @@
 // conv addressing of X (weight gradient of a Conv1d on channels-last activations): row m = (b, l) of the im2col matrix is
 // x[b, l*stride - pad + tap, ch] with k = tap*Cin + ch; positions outside [0, Lin) are the conv's zero padding.
 // Lout == 0: plain row-major X with row stride ldx.
+// toeplitz != 0 (tap gradient of the single-channel sinc FIR, Cin == 1): row m = (b, t) is x[b, t + k - K/2], k = 0..K-1, read
+// from 8 zero-padded copies of the utterance shifted by 0..7 samples (sfm_sinc_shift_pack) so that the 8-tap chunk starting
+// at any sample is one aligned 16-byte load: chunk(o) = copy[o & 7][o & ~7 ...], o = t + k + pad.
 struct TnConv {
   int Lout, Lin, Cin, stride, pad;
   long long x_batch_stride;
+  int toeplitz;
 };
 
 template <class T>
@@ -60,7 +64,14 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
           for (int e = 0; e < 8; ++e) t[e] = (n0 + scol[i] + e < N) ? G[(long long)m * ldg + n0 + scol[i] + e] : (u16)0;
           a = *reinterpret_cast<const u32x4*>(t);
         }
-        if (cv.Lout > 0) {                                     // implicit im2col row (Cin % 8 == 0: a chunk stays in one tap)
+        if (cv.toeplitz) {
+          const int kk = k0 + scol[i];
+          if (kk < K) {
+            const int bb = m / cv.Lout, t = m - bb * cv.Lout;
+            const int o = t + kk + cv.pad;
+            b = *reinterpret_cast<const u32x4*>(X + ((long long)bb * 8 + (o & 7)) * cv.x_batch_stride + (o & ~7));
+          }
+        } else if (cv.Lout > 0) {                              // implicit im2col row (Cin % 8 == 0: a chunk stays in one tap)
           const int kk = k0 + scol[i];
           if (kk < K) {
             const int bb = m / cv.Lout, l = m - bb * cv.Lout;
@@ -235,7 +246,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
 // db (optional): bias gradient out[n] += sum_m G[m, n], computed from the G tiles the k-tile-0 workgroups stage anyway
 extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx,
                              int ldw, int dtype, void* stream) {
-  TnConv cv = {0, 0, 0, 0, 0, 0};
+  TnConv cv = {0, 0, 0, 0, 0, 0, 0};
   return gemm16_tn_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv);
 }
 
@@ -245,8 +256,40 @@ extern "C" int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* 
                                 int ksize, int stride, int pad, long long x_batch_stride, int ldg, int ldw, int dtype,
                                 void* stream) {
   if (B <= 0 || Lout <= 0 || Lin <= 0 || Cin <= 0 || (Cin % 8) != 0 || ksize <= 0 || stride <= 0) return SFM_ERR_SHAPE;
-  TnConv cv = {Lout, Lin, Cin, stride, pad, x_batch_stride};
+  TnConv cv = {Lout, Lin, Cin, stride, pad, x_batch_stride, 0};
   return gemm16_tn_launch(G, x, dW, db, B * Lout, N, ksize * Cin, ldg, 0, ldw, dtype, stream, cv);
+}
+
+// Tap gradient of the sinc FIR bank (agents/perception.py:115-118 backward) on the matrix cores.
+// sfm_sinc_shift_pack: x fp32 [B, L] -> xs 16-bit [B][8][Lc], xs[b][j][i] = x[b, i + j - 128] (0 outside [0, L)),
+//   Lc = sfm_sinc_shift_len(L) (covers every chunk the GEMM reads).
+// sfm_sinc_wgrad16: dW [C][256] fp32 += sum_{b,t} dy[b, t, c] * x[b, t + k - 125]   (columns 251..255: don't care)
+template <class T>
+__global__ __launch_bounds__(256) void sinc_shift_pack_kernel(const float* __restrict__ x, u16* __restrict__ xs, int L, int Lc) {
+  const int b = blockIdx.z, j = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Lc) return;
+  const int s = i + j - 128;
+  const float v = (s >= 0 && s < L) ? x[(long long)b * L + s] : 0.f;
+  xs[((long long)b * 8 + j) * Lc + i] = T::from_f32(v);
+}
+
+extern "C" long long sfm_sinc_shift_len(int L) { return ((long long)L + 272 + 7) / 8 * 8; }
+
+extern "C" int sfm_sinc_shift_pack(const float* x, void* xs, int B, int L, int dtype, void* stream) {
+  if (!x || !xs) return SFM_ERR_ARG;
+  if (B <= 0 || L <= 0 || B > 65535) return SFM_ERR_SHAPE;
+  const int Lc = (int)sfm_sinc_shift_len(L);
+  dim3 grid((Lc + 255) / 256, 8, B), block(256);
+  if (dtype == SFM_DT_F16) SFM_LAUNCH((sinc_shift_pack_kernel<F16>), grid, block, 0, (hipStream_t)stream, x, (u16*)xs, L, Lc);
+  else SFM_LAUNCH((sinc_shift_pack_kernel<BF16>), grid, block, 0, (hipStream_t)stream, x, (u16*)xs, L, Lc);
+  return SFM_OK;
+}
+
+extern "C" int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, void* stream) {
+  if (B <= 0 || L <= 0 || C <= 0 || (C % 8) != 0 || (long long)B * L > 2000000000LL) return SFM_ERR_SHAPE;
+  TnConv cv = {L, L, 1, 1, 128 - 125, sfm_sinc_shift_len(L), 1};
+  return gemm16_tn_launch(dy, xs, dW, nullptr, B * L, C, 256, C, 0, 256, dtype, stream, cv);
 }
 
 extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream) {

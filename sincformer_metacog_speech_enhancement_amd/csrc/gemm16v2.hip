@@ -330,6 +330,299 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form (variant 6): 128 x BN tiles, 2-stage ring, 2 workgroups per CU that each walk a list of tiles.
+// The skinny GEMMs of the path (K = 64 .. 1280, i.e. 1 .. 20 k-tiles per output tile) spend as long in workgroup launch,
+// the first loads' latency and the epilogue as in the MFMA loop; here the first k-tile of the NEXT tile is already in
+// flight while a tile's epilogue runs (the epilogue image is a separate, per-wave 8-row LDS strip, so the ring stays
+// free), and there is one workgroup launch per CU slot instead of one per tile.
+// Tile order: XCD x owns the contiguous range [x Q, (x+1) Q) of the (batch, M-tile, N-tile) list and its resident
+// workgroups take neighbouring tiles, so the N-tiles of one M-tile share that XCD's L2.
+template <class T, int BN>
+__global__ __launch_bounds__(256) void gemm16p_kernel(Gemm2Params p, int total_tiles) {
+  constexpr int BM = 128, BKB = 128;
+  constexpr int WN = BN / 2, NJ = WN / 32;
+  constexpr int A_STAGE = BM * BKB, B_STAGE = BN * BKB, STAGE = A_STAGE + B_STAGE;
+  constexpr int NA = BM / 32, NB = BN / 32;
+  constexpr int IMG_LD = WN + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hl = lane >> 5;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int Q = (total_tiles + 7) >> 3;
+  const int t_begin = xcd * Q;
+  const int t_end = min(total_tiles, t_begin + Q);
+  if (t_begin + slot >= t_end) return;                 // whole workgroup leaves together: no barrier is ever missed
+
+  auto w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_records, 0x00020000);
+  const bool contiguous = (p.lda == p.Cin) || (p.cin_shift >= 30);
+  const int nt = p.Kpad >> 6;
+
+  // ---- issue side: (tile, k-tile) of the next LDS-DMA batch and its per-lane source coordinates ----
+  int tile_i = t_begin + slot, ki = 0;
+  int a_rowoff[NA], a_swz[NA], b_rowoff[NB], b_swz[NB];
+  const u16* a_base = p.A;
+  auto setup_issue = [&](int id) {
+    const int ntile = id % p.nNt, rest = id / p.nNt;
+    const int mtile = rest % p.nMt, bb = rest / p.nMt;
+    a_base = p.A + (long long)bb * p.a_batch_stride;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = (wave * NA + i) * 8 + (lane >> 3);
+      const int pos0 = (mtile * BM + row) * p.stride - p.pad;
+      a_rowoff[i] = pos0 * p.lda * 2;
+      a_swz[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = (wave * NB + i) * 8 + (lane >> 3);
+      b_rowoff[i] = (ntile * BN + row) * p.Kpad * 2;
+      b_swz[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  auto issue_next = [&](int stage) {
+    auto a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, p.a_records, 0x00020000);
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = ki * 64 + a_swz[i];
+      const int eoff = contiguous ? j : ((j >> p.cin_shift) * p.lda + (j & (p.Cin - 1)));
+      int voff = a_rowoff[i] + eoff * 2;
+      if (j >= p.K) voff = -1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(sa + (wave * NA + i) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int voff = b_rowoff[i] + (ki * 64 + b_swz[i]) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(sb + (wave * NB + i) * 1024), 16, voff, 0, 0, 0);
+    }
+    if (++ki == nt) {
+      ki = 0;
+      tile_i += nslots;
+      if (tile_i < t_end) setup_issue(tile_i);
+    }
+  };
+
+  // fragment read offsets (bytes) inside a stage
+  int fa_off[2][4], fb_off[NJ][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fa_off[i][s] = row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wn * WN + j * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb_off[j][s] = A_STAGE + row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+  float* img = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * (8 * IMG_LD);
+
+  setup_issue(tile_i);
+  issue_next(0);
+  int stage = 0;
+  for (int tile = t_begin + slot; tile < t_end; tile += nslots) {
+    const int ntile = tile % p.nNt, rest = tile / p.nNt;
+    const int mtile = rest % p.nMt, b = rest / p.nMt;
+    const int n0 = ntile * BN, l0 = mtile * BM;
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int t = 0; t < nt; ++t) {
+      wait_vmcnt<0>();                                 // this wave's share of the current k-tile has landed
+      __builtin_amdgcn_s_barrier();                    // ... everyone's has, and the other stage is no longer being read
+      if (tile_i < t_end) issue_next(stage ^ 1);
+      const unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x4 fa[2], fb[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sbase + fa_off[i][s]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sbase + fb_off[j][s]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+      }
+      stage ^= 1;
+    }
+
+    // ------------------------------ epilogue: 8 passes of 8 rows through the wave's LDS strip ------------------------------
+    const int row_base = l0 + wm * 64;
+    const bool glu = (p.epi == EPI_GLU);
+    const int ecols = glu ? 32 : WN;
+    const int cpr = ecols >> 3;
+    const int c8 = (lane % cpr) * 8, rsub = lane / cpr;
+    const bool lane_on = rsub < 8;
+    const int colb = n0 + wn * WN;
+    const int ncol0 = glu ? ((colb >> 1) + c8) : (colb + c8);
+    float bia[8], big[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;
+      big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
+    }
+    const long long obase = (long long)b * p.o_batch_stride;
+    float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        const int row = i * 32 + q * 8 + rsub;           // row inside the wave tile
+        const int m = row_base + row;
+        const bool mok = lane_on && m < p.Lout;
+        float v[8];
+        {
+          const int rs = lane_on ? rsub : 0;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8]);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8 + 4]);
+          v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+          v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bia[e];
+          if (glu) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8]);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8 + 4]);
+            const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= sigmoid_f(g[e] + big[e]);
+          }
+        }
+        if (p.gn_partial && mok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
+        }
+        switch (p.epi) {
+          case EPI_SWISH:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = swish_f(v[e]);
+            break;
+          case EPI_GELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            break;
+          case EPI_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
+            break;
+          case EPI_TANH_SCALE:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p.alpha * tanhf(v[e]);
+            break;
+          case EPI_SIGMA:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = expf(0.5f * fminf(fmaxf(v[e], -10.f), 10.f));
+            break;
+          case EPI_CPEA:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (ncol0 + e < p.nsplit) ? sigmoid_f(v[e]) : p.alpha * tanhf(v[e]);
+            break;
+          default: break;
+        }
+        if (mok) {
+          const long long orow = obase + (long long)m * p.ldo + ncol0;
+          if (p.vec_ok && ncol0 + 8 <= p.N) {
+            if (p.epi == EPI_RESID) {
+              if (p.p_drop > 0.f) {
+                const float ik = 1.0f / (1.0f - p.p_drop);
+                const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik);
+              }
+              const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
+              const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
+              const f32x4 r1v = *reinterpret_cast<const f32x4*>(rp + 4);
+              v[0] = r0v[0] + p.alpha * v[0]; v[1] = r0v[1] + p.alpha * v[1];
+              v[2] = r0v[2] + p.alpha * v[2]; v[3] = r0v[3] + p.alpha * v[3];
+              v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
+              v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
+            }
+            if (p.out_f32) {
+              float* op = reinterpret_cast<float*>(p.out) + orow;
+              f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
+              *reinterpret_cast<f32x4*>(op) = a;
+              *reinterpret_cast<f32x4*>(op + 4) = c;
+            } else {
+              u32x4 pk;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+              *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              if (ncol0 + e < p.N) {
+                float y = v[e];
+                if (p.epi == EPI_RESID) {
+                  if (p.p_drop > 0.f)
+                    y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
+                  y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
+                }
+                if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
+                else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
+              }
+            }
+          }
+        }
+      }
+    if (p.gn_partial) {
+      for (int o = cpr; o < 64; o <<= 1) {               // lanes with the same column chunk hold different rows
+        gsum += __shfl_xor(gsum, o, 64);
+        gsq += __shfl_xor(gsq, o, 64);
+      }
+      const int cpg = p.gn_group >> 3;
+      for (int o = 1; o < cpg; o <<= 1) {
+        gsum += __shfl_xor(gsum, o, 64);
+        gsq += __shfl_xor(gsq, o, 64);
+      }
+      if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N && (row_base >> 6) < p.gn_slots) {
+        const int ngroups = p.N / p.gn_group;
+        const long long sl = ((long long)b * p.gn_slots + (row_base >> 6)) * ngroups + ncol0 / p.gn_group;
+        p.gn_partial[sl * 2 + 0] = gsum;
+        p.gn_partial[sl * 2 + 1] = gsq;
+      }
+    }
+  }
+  wait_vmcnt<0>();                                     // nothing of the ring is in flight when the workgroup retires
+}
+
+template <class T, int BN>
+static int launch_p(const Gemm2Params& p, hipStream_t stream) {
+  constexpr int lds = 2 * (128 + BN) * 128 + 4 * 8 * (BN / 2 + 4) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm16p_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int total = p.nMt * p.nNt * p.B;
+  int nblk = 512;                                      // 2 workgroups on each of the 256 CUs
+  if (total < nblk) nblk = (total + 7) / 8 * 8;
+  SFM_LAUNCH((gemm16p_kernel<T, BN>), dim3(nblk), dim3(256), lds, stream, p, total);
+  return SFM_OK;
+}
+
 template <class T, int BN, int STAGES, int BM>
 static int launch_v2(const Gemm2Params& p, hipStream_t stream) {
   constexpr int ring = STAGES * (BM + BN) * 128, image = 4 * 64 * (BN / 2 + 4) * 4;
@@ -352,7 +645,8 @@ extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, vo
                              int nsplit, int dtype, void* stream);
 
 // same contract as sfm_gemm16_v1 (include/sincformer_hip.h); `variant`: 0 = auto, 1 = v1 register-staged kernel,
-// 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU), 4 / 5 = 256-row tiles with 2 / 3 stages
+// 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU), 4 / 5 = 256-row tiles with 2 / 3 stages,
+// 6 = persistent 2-stage kernel (tile loop inside the workgroup, next tile prefetched under the epilogue)
 // sfm_gemm16_train = sfm_gemm16_ex + residual-branch dropout in the EPI_RESID epilogue (training forward):
 // out = resid + alpha * keep(seed, m*N + n) / (1 - p_drop) * (A W^T + bias)
 extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out, const float* resid,
@@ -406,7 +700,11 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   p.gn_slots = 2 * ((Lout + 127) / 128);               // partial slots per batch entry: one per 64 output rows (padded to 128)
   hipStream_t st = (hipStream_t)stream;
   const bool s3 = (variant == 3 || variant == 5);
+  // the persistent kernel is 5-20 % faster than variant 2 on isolated launches of the path's skinny GEMMs
+  // (tools/gemm_bench.py) but 2 % slower inside the forward pass (bench.py, same box, A/B/A/B): not the default
+  const bool persistent = (variant == 6);
 #define GO(TT)                                                                                            \
+  if (persistent) return bn128 ? launch_p<TT, 128>(p, st) : launch_p<TT, 64>(p, st);                    \
   if (big) return s3 ? launch_v2<TT, 128, 3, 256>(p, st) : launch_v2<TT, 128, 2, 256>(p, st);           \
   if (bn128) return s3 ? launch_v2<TT, 128, 3, 128>(p, st) : launch_v2<TT, 128, 2, 128>(p, st);          \
   else return s3 ? launch_v2<TT, 64, 3, 128>(p, st) : launch_v2<TT, 64, 2, 128>(p, st);

@@ -1,140 +1,273 @@
 // Backward of the PerceptionAgent's normalisation nodes (agents/perception.py:121-129, 157, 192-206, 233-246):
 //   out = act( GN(x1) [+ GN(x2)] ),   GN(x)[b,l,c] = (x - mean[b,g]) rstd[b,g] gamma[c] + beta[c],  act = identity | GELU(erf)
-// channels-last [B, L, C]; x1 / x2 are the raw conv outputs the forward kept (16-bit or fp32).  Two streaming passes:
-//   gn_bwd_reduce : dp = dout * act'(p);  S[b][c] = { sum_l dp, sum_l dp xhat1, sum_l dp xhat2 }   (fp32 atomics)
-//                   from S the host forms dgamma / dbeta (sums over b) and, per (b, group), the two correction sums
-//   gn_bwd_apply  : dx_i = a_i dp - b_i - xhat_i c_i   with the per-(b, c) coefficients a = rstd gamma,
-//                   b = rstd/N sum_g(dp gamma), c = rstd/N sum_g(dp gamma xhat)   (dp is recomputed, not stored)
-// Per-(b, c) tables (fp32 [B, C]): sc / sh = the forward's scale and shift (to recompute p), mu / rs = group mean and
-// rstd broadcast to channels (xhat = (x - mu) rs).
+// channels-last [B, L, C]; x1 / x2 are the raw conv outputs the forward kept (16-bit or fp32).  Two streaming passes and
+// a tiny one in between, all HBM-bound (16-byte loads: a thread owns 8 neighbouring channels and walks down the rows):
+//   gn_bwd_reduce : dp = dout * act'(p);  S[b][k][c] = { sum_l dp, sum_l dp xhat1, sum_l dp xhat2 }
+//   gn_bwd_coefs  : per (b, c): a = rstd gamma, b = rstd/N sum_g(dp gamma), c = rstd/N sum_g(dp gamma xhat);
+//                   dbeta / dgamma = sums of S over b
+//   gn_bwd_apply  : dx_i = a_i dp - b_i - xhat_i c_i          (dp is recomputed, not stored)
+// sc / sh [B, C]: the forward's per-(utterance, channel) scale and shift (to recompute p); mean / rstd [B, G].
 #include "sfm_common.h"
 
 struct GnIn {
   const void* x;          // raw input [B, L, C]
   const float* sc;        // [B, C]
   const float* sh;
-  const float* mu;
-  const float* rs;
-  const float* ca;        // apply pass: a, b, c coefficients [B, C]
-  const float* cb;
-  const float* cc;
+  const float* mean;      // [B, G]
+  const float* rstd;
+  const float* coef;      // apply pass: [3][B][C] = a, b, c
   void* dx;               // apply pass output [B, L, C]
   int x_f32, dx_f32;
 };
 
 template <class T>
-__device__ __forceinline__ float gn_ld(const void* p, long long e, int f32) {
-  return f32 ? reinterpret_cast<const float*>(p)[e] : T::to_f32(reinterpret_cast<const u16*>(p)[e]);
+__device__ __forceinline__ void gn_ld8(const void* p, long long e, int f32, float (&v)[8]) {
+  if (f32) {
+    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + e);
+    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + e + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p) + e);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = T::to_f32((u16)(w[j] & 0xffffu));
+      v[2 * j + 1] = T::to_f32((u16)(w[j] >> 16));
+    }
+  }
 }
 
+template <class T>
+__device__ __forceinline__ void gn_st8(void* p, long long e, int f32, const float (&v)[8]) {
+  if (f32) {
+    float* o = reinterpret_cast<float*>(p) + e;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 q;
+    q.x = T::pack(v[0], v[1]); q.y = T::pack(v[2], v[3]); q.z = T::pack(v[4], v[5]); q.w = T::pack(v[6], v[7]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p) + e) = q;
+  }
+}
+
+// d/dz of z Phi(z) = Phi(z) + z phi(z); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), sharing exp(-z^2/2) with phi
 __device__ __forceinline__ float gelu_grad(float z) {
-  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-  return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+  const float ax = fabsf(z) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float ex = __expf(-0.5f * z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * ex;                                      // erf(|z| / sqrt 2)
+  const float cdf = 0.5f * (1.0f + copysignf(erfa, z));
+  return cdf + z * 0.39894228040143267794f * ex;
 }
 
-template <class T>
+struct GnRegs {
+  float sc[8], sh[8], mu[8], rs[8];
+};
+
+__device__ __forceinline__ void gn_load_regs(const GnIn& in, long long b, int c0, int C, int G, GnRegs& r) {
+  const int cg = C / G;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    r.sc[j] = in.sc[b * C + c0 + j];
+    r.sh[j] = in.sh[b * C + c0 + j];
+    r.mu[j] = in.mean[b * G + (c0 + j) / cg];
+    r.rs[j] = in.rstd[b * G + (c0 + j) / cg];
+  }
+}
+
+// grid (row tiles, B); block 256 = (C/8 channel vectors) x (2048/C row lanes); C in {64, 128, 256, 512, 1024, 2048}
+template <class T, int TWO>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void* __restrict__ dout, int dout_f32, GnIn i1, GnIn i2,
-                                                            int two, float* __restrict__ S, int L, int C, int act,
+                                                            float* __restrict__ S, int L, int C, int G, int act,
                                                             int rows_per_block) {
-  __shared__ float red[256][3];
-  const int b = blockIdx.y;
-  const int nc = C < 256 ? C : 256;                    // channels covered per pass of the block
-  const int rl = 256 / nc;                             // row lanes
-  const int tc = threadIdx.x % nc, tr = threadIdx.x / nc;
+  extern __shared__ float red[];                       // [rl][3][C]
+  const long long b = blockIdx.y;
+  const int nv = C >> 3, rl = 256 / nv;
+  const int tv = threadIdx.x % nv, tr = threadIdx.x / nv, c0 = tv * 8;
   const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
-  for (int c = tc; c < C; c += nc) {
-    const long long bc = (long long)b * C + c;
-    const float sc1 = i1.sc[bc], sh1 = i1.sh[bc], mu1 = i1.mu[bc], rs1 = i1.rs[bc];
-    float sc2 = 0.f, sh2 = 0.f, mu2 = 0.f, rs2 = 0.f;
-    if (two) { sc2 = i2.sc[bc]; sh2 = i2.sh[bc]; mu2 = i2.mu[bc]; rs2 = i2.rs[bc]; }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int l = l0 + tr; l < l1; l += rl) {
-      const long long e = ((long long)b * L + l) * C + c;
-      const float x1 = gn_ld<T>(i1.x, e, i1.x_f32);
-      float p = x1 * sc1 + sh1, x2 = 0.f;
-      if (two) { x2 = gn_ld<T>(i2.x, e, i2.x_f32); p += x2 * sc2 + sh2; }
-      float dp = gn_ld<T>(dout, e, dout_f32);
-      if (act) dp *= gelu_grad(p);
-      s0 += dp;
-      s1 += dp * (x1 - mu1) * rs1;
-      if (two) s2 += dp * (x2 - mu2) * rs2;
+  GnRegs r1, r2;
+  gn_load_regs(i1, b, c0, C, G, r1);
+  if (TWO) gn_load_regs(i2, b, c0, C, G, r2);
+  float s0[8] = {}, s1[8] = {}, s2[8] = {};
+  for (int l = l0 + tr; l < l1; l += rl) {
+    const long long e = (b * L + l) * C + c0;
+    float x1[8], x2[8], dp[8];
+    gn_ld8<T>(i1.x, e, i1.x_f32, x1);
+    if (TWO) gn_ld8<T>(i2.x, e, i2.x_f32, x2);
+    gn_ld8<T>(dout, e, dout_f32, dp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float p = x1[j] * r1.sc[j] + r1.sh[j];
+      if (TWO) p += x2[j] * r2.sc[j] + r2.sh[j];
+      const float d = act ? dp[j] * gelu_grad(p) : dp[j];
+      s0[j] += d;
+      s1[j] += d * (x1[j] - r1.mu[j]) * r1.rs[j];
+      if (TWO) s2[j] += d * (x2[j] - r2.mu[j]) * r2.rs[j];
     }
-    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
-    __syncthreads();
-    if (tr == 0) {
-      for (int r = 1; r < rl; ++r) { s0 += red[r * nc + tc][0]; s1 += red[r * nc + tc][1]; s2 += red[r * nc + tc][2]; }
-      atomicAdd(&S[bc * 3 + 0], s0);
-      atomicAdd(&S[bc * 3 + 1], s1);
-      if (two) atomicAdd(&S[bc * 3 + 2], s2);
-    }
-    __syncthreads();
+  }
+  float* mine = red + (long long)tr * 3 * C;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mine[c0 + j] = s0[j];
+    mine[C + c0 + j] = s1[j];
+    mine[2 * C + c0 + j] = s2[j];
+  }
+  __syncthreads();
+  const int nk = TWO ? 3 * C : 2 * C;
+  for (int i = threadIdx.x; i < nk; i += 256) {
+    float a = 0.f;
+    for (int r = 0; r < rl; ++r) a += red[(long long)r * 3 * C + i];
+    atomicAdd(&S[b * 3 * C + i], a);
   }
 }
 
-template <class T>
+// grid B, block 256: coefficient tables + parameter gradients.  dparam [3][C] = dbeta, dgamma1, dgamma2 (zeroed by caller)
+__global__ __launch_bounds__(256) void gn_bwd_coefs_kernel(const float* __restrict__ S, const float* __restrict__ gamma1,
+                                                           const float* __restrict__ rstd1, const float* __restrict__ gamma2,
+                                                           const float* __restrict__ rstd2, float* __restrict__ coef1,
+                                                           float* __restrict__ coef2, float* __restrict__ dparam, int B,
+                                                           int C, int G, float inv_n) {
+  __shared__ float gs[4][256];                         // per group: A1, B1, A2, B2
+  const long long b = blockIdx.x;
+  const int cg = C / G;
+  const float* Sb = S + b * 3 * C;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+      a1 += Sb[c] * gamma1[c];
+      b1 += Sb[C + c] * gamma1[c];
+      if (gamma2) { a2 += Sb[c] * gamma2[c]; b2 += Sb[2 * C + c] * gamma2[c]; }
+    }
+    gs[0][g] = a1; gs[1][g] = b1; gs[2][g] = a2; gs[3][g] = b2;
+  }
+  __syncthreads();
+  const long long BC = (long long)B * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cg;
+    const float r1 = rstd1[b * G + g];
+    coef1[b * C + c] = r1 * gamma1[c];
+    coef1[BC + b * C + c] = r1 * gs[0][g] * inv_n;
+    coef1[2 * BC + b * C + c] = r1 * gs[1][g] * inv_n;
+    atomicAdd(&dparam[c], Sb[c]);
+    atomicAdd(&dparam[C + c], Sb[C + c]);
+    if (gamma2) {
+      const float r2 = rstd2[b * G + g];
+      coef2[b * C + c] = r2 * gamma2[c];
+      coef2[BC + b * C + c] = r2 * gs[2][g] * inv_n;
+      coef2[2 * BC + b * C + c] = r2 * gs[3][g] * inv_n;
+      atomicAdd(&dparam[2 * C + c], Sb[2 * C + c]);
+    }
+  }
+}
+
+template <class T, int TWO>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ dout, int dout_f32, GnIn i1, GnIn i2,
-                                                           int two, int L, int C, int act, long long total) {
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    const long long b = e / ((long long)L * C);
-    const long long bc = b * C + c;
-    const float x1 = gn_ld<T>(i1.x, e, i1.x_f32);
-    float p = x1 * i1.sc[bc] + i1.sh[bc], x2 = 0.f;
-    if (two) { x2 = gn_ld<T>(i2.x, e, i2.x_f32); p += x2 * i2.sc[bc] + i2.sh[bc]; }
-    float dp = gn_ld<T>(dout, e, dout_f32);
-    if (act) dp *= gelu_grad(p);
-    const float d1 = i1.ca[bc] * dp - i1.cb[bc] - (x1 - i1.mu[bc]) * i1.rs[bc] * i1.cc[bc];
-    if (i1.dx_f32) reinterpret_cast<float*>(i1.dx)[e] = d1;
-    else reinterpret_cast<u16*>(i1.dx)[e] = T::from_f32(d1);
-    if (two) {
-      const float d2 = i2.ca[bc] * dp - i2.cb[bc] - (x2 - i2.mu[bc]) * i2.rs[bc] * i2.cc[bc];
-      if (i2.dx_f32) reinterpret_cast<float*>(i2.dx)[e] = d2;
-      else reinterpret_cast<u16*>(i2.dx)[e] = T::from_f32(d2);
+                                                           int B, int L, int C, int G, int act, int rows_per_block) {
+  const long long b = blockIdx.y;
+  const int nv = C >> 3, rl = 256 / nv;
+  const int tv = threadIdx.x % nv, tr = threadIdx.x / nv, c0 = tv * 8;
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  const long long BC = (long long)B * C;
+  GnRegs r1, r2;
+  float a1[8], b1[8], k1[8], a2[8], b2[8], k2[8];
+  gn_load_regs(i1, b, c0, C, G, r1);
+  if (TWO) gn_load_regs(i2, b, c0, C, G, r2);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a1[j] = i1.coef[b * C + c0 + j]; b1[j] = i1.coef[BC + b * C + c0 + j]; k1[j] = i1.coef[2 * BC + b * C + c0 + j];
+    if (TWO) { a2[j] = i2.coef[b * C + c0 + j]; b2[j] = i2.coef[BC + b * C + c0 + j]; k2[j] = i2.coef[2 * BC + b * C + c0 + j]; }
+  }
+  for (int l = l0 + tr; l < l1; l += rl) {
+    const long long e = (b * L + l) * C + c0;
+    float x1[8], x2[8], dp[8], d1[8], d2[8];
+    gn_ld8<T>(i1.x, e, i1.x_f32, x1);
+    if (TWO) gn_ld8<T>(i2.x, e, i2.x_f32, x2);
+    gn_ld8<T>(dout, e, dout_f32, dp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float p = x1[j] * r1.sc[j] + r1.sh[j];
+      if (TWO) p += x2[j] * r2.sc[j] + r2.sh[j];
+      const float d = act ? dp[j] * gelu_grad(p) : dp[j];
+      d1[j] = a1[j] * d - b1[j] - (x1[j] - r1.mu[j]) * r1.rs[j] * k1[j];
+      if (TWO) d2[j] = a2[j] * d - b2[j] - (x2[j] - r2.mu[j]) * r2.rs[j] * k2[j];
     }
+    gn_st8<T>(i1.dx, e, i1.dx_f32, d1);
+    if (TWO) gn_st8<T>(i2.dx, e, i2.dx_f32, d2);
   }
 }
 
-static GnIn gn_in(const void* x, int x_f32, const float* tab, long long BC, void* dx, int dx_f32, const float* coef) {
+static GnIn gn_in(const void* x, int x_f32, const float* sc, const float* sh, const float* mean, const float* rstd,
+                  const float* coef, void* dx, int dx_f32) {
   GnIn g;
-  g.x = x; g.x_f32 = x_f32;
-  g.sc = tab; g.sh = tab ? tab + BC : nullptr; g.mu = tab ? tab + 2 * BC : nullptr; g.rs = tab ? tab + 3 * BC : nullptr;
-  g.ca = coef; g.cb = coef ? coef + BC : nullptr; g.cc = coef ? coef + 2 * BC : nullptr;
-  g.dx = dx; g.dx_f32 = dx_f32;
+  g.x = x; g.x_f32 = x_f32; g.sc = sc; g.sh = sh; g.mean = mean; g.rstd = rstd; g.coef = coef; g.dx = dx; g.dx_f32 = dx_f32;
   return g;
 }
 
-// tab1 / tab2: [4][B][C] fp32 = (scale, shift, mean, rstd);  S: [B][C][3] fp32, zero-filled by the caller
-extern "C" int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* tab1,
-                                 const void* x2, int x2_f32, const float* tab2, float* S, int B, int L, int C, int act,
-                                 int dtype, void* stream) {
-  if (!dout || !x1 || !tab1 || !S || ((x2 == nullptr) != (tab2 == nullptr))) return SFM_ERR_ARG;
-  if (B <= 0 || L <= 0 || C <= 0 || (C > 256 && C % 256 != 0) || (C < 256 && 256 % C != 0)) return SFM_ERR_SHAPE;
-  const long long BC = (long long)B * C;
-  const GnIn a = gn_in(x1, x1_f32, tab1, BC, nullptr, 0, nullptr), c = gn_in(x2, x2_f32, tab2, BC, nullptr, 0, nullptr);
-  const int rpb = 256;
+static bool gn_shape_ok(int B, int L, int C, int G) {
+  if (B <= 0 || L <= 0 || C < 64 || C > 2048 || (C & (C - 1)) || G <= 0 || G > 256 || C % G || B > 65535) return false;
+  return true;
+}
+
+static int gn_rows_per_block(int C) { return 8 * (2048 / C) > 256 ? 8 * (2048 / C) : 256; }
+
+// S: [B][3][C] fp32, zero-filled by the caller
+extern "C" int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
+                                 const float* mean1, const float* rstd1, const void* x2, int x2_f32, const float* sc2,
+                                 const float* sh2, const float* mean2, const float* rstd2, float* S, int B, int L, int C, int G,
+                                 int act, int dtype, void* stream) {
+  if (!dout || !x1 || !sc1 || !sh1 || !mean1 || !rstd1 || !S) return SFM_ERR_ARG;
+  if (x2 && (!sc2 || !sh2 || !mean2 || !rstd2)) return SFM_ERR_ARG;
+  if (!gn_shape_ok(B, L, C, G)) return SFM_ERR_SHAPE;
+  const GnIn a = gn_in(x1, x1_f32, sc1, sh1, mean1, rstd1, nullptr, nullptr, 0);
+  const GnIn c = gn_in(x2, x2_f32, sc2, sh2, mean2, rstd2, nullptr, nullptr, 0);
+  const int rpb = gn_rows_per_block(C);
   dim3 grid((L + rpb - 1) / rpb, B), block(256);
-  if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((gn_bwd_reduce_kernel<F16>), grid, block, 0, (hipStream_t)stream, dout, dout_f32, a, c, x2 ? 1 : 0, S, L, C, act, rpb);
-  else
-    SFM_LAUNCH((gn_bwd_reduce_kernel<BF16>), grid, block, 0, (hipStream_t)stream, dout, dout_f32, a, c, x2 ? 1 : 0, S, L, C, act, rpb);
+  const size_t lds = (size_t)(2048 / C) * 3 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SFM_DT_F16) {
+    if (x2) SFM_LAUNCH((gn_bwd_reduce_kernel<F16, 1>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
+    else SFM_LAUNCH((gn_bwd_reduce_kernel<F16, 0>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
+  } else {
+    if (x2) SFM_LAUNCH((gn_bwd_reduce_kernel<BF16, 1>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
+    else SFM_LAUNCH((gn_bwd_reduce_kernel<BF16, 0>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
+  }
   return SFM_OK;
 }
 
-// coef1 / coef2: [3][B][C] fp32 = (a, b, c);  dx1 / dx2: [B, L, C] 16-bit or fp32
-extern "C" int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* tab1,
-                                const float* coef1, void* dx1, int dx1_f32, const void* x2, int x2_f32, const float* tab2,
-                                const float* coef2, void* dx2, int dx2_f32, int B, int L, int C, int act, int dtype,
+// coef1 / coef2: [3][B][C] fp32 (a, b, c);  dparam: [3][C] fp32 = dbeta, dgamma1, dgamma2, zero-filled by the caller
+extern "C" int sfm_gn_bwd_coefs(const float* S, const float* gamma1, const float* rstd1, const float* gamma2,
+                                const float* rstd2, float* coef1, float* coef2, float* dparam, int B, int L, int C, int G,
                                 void* stream) {
-  if (!dout || !x1 || !tab1 || !coef1 || !dx1) return SFM_ERR_ARG;
-  if (x2 && (!tab2 || !coef2 || !dx2)) return SFM_ERR_ARG;
-  if (B <= 0 || L <= 0 || C <= 0) return SFM_ERR_SHAPE;
-  const long long BC = (long long)B * C, total = (long long)B * L * C;
-  const GnIn a = gn_in(x1, x1_f32, tab1, BC, dx1, dx1_f32, coef1), c = gn_in(x2, x2_f32, tab2, BC, dx2, dx2_f32, coef2);
-  long long nb = (total + 255) / 256;
-  if (nb > 32768) nb = 32768;
-  if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((gn_bwd_apply_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dout, dout_f32, a, c, x2 ? 1 : 0, L, C, act, total);
-  else
-    SFM_LAUNCH((gn_bwd_apply_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dout, dout_f32, a, c, x2 ? 1 : 0, L, C, act, total);
+  if (!S || !gamma1 || !rstd1 || !coef1 || !dparam) return SFM_ERR_ARG;
+  if (gamma2 && (!rstd2 || !coef2)) return SFM_ERR_ARG;
+  if (!gn_shape_ok(B, L, C, G)) return SFM_ERR_SHAPE;
+  const float inv_n = 1.0f / ((float)L * (float)(C / G));
+  SFM_LAUNCH(gn_bwd_coefs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, gamma1, rstd1, gamma2, rstd2, coef1, coef2,
+             dparam, B, C, G, inv_n);
+  return SFM_OK;
+}
+
+// dx1 / dx2: [B, L, C] 16-bit or fp32
+extern "C" int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
+                                const float* mean1, const float* rstd1, const float* coef1, void* dx1, int dx1_f32,
+                                const void* x2, int x2_f32, const float* sc2, const float* sh2, const float* mean2,
+                                const float* rstd2, const float* coef2, void* dx2, int dx2_f32, int B, int L, int C, int G,
+                                int act, int dtype, void* stream) {
+  if (!dout || !x1 || !sc1 || !sh1 || !mean1 || !rstd1 || !coef1 || !dx1) return SFM_ERR_ARG;
+  if (x2 && (!sc2 || !sh2 || !mean2 || !rstd2 || !coef2 || !dx2)) return SFM_ERR_ARG;
+  if (!gn_shape_ok(B, L, C, G)) return SFM_ERR_SHAPE;
+  const GnIn a = gn_in(x1, x1_f32, sc1, sh1, mean1, rstd1, coef1, dx1, dx1_f32);
+  const GnIn c = gn_in(x2, x2_f32, sc2, sh2, mean2, rstd2, coef2, dx2, dx2_f32);
+  const int rpb = gn_rows_per_block(C);
+  dim3 grid((L + rpb - 1) / rpb, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SFM_DT_F16) {
+    if (x2) SFM_LAUNCH((gn_bwd_apply_kernel<F16, 1>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
+    else SFM_LAUNCH((gn_bwd_apply_kernel<F16, 0>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
+  } else {
+    if (x2) SFM_LAUNCH((gn_bwd_apply_kernel<BF16, 1>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
+    else SFM_LAUNCH((gn_bwd_apply_kernel<BF16, 0>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
+  }
   return SFM_OK;
 }

@@ -563,6 +563,20 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
 MR_STFT = ((256, 64, 256), (512, 128, 512), (1024, 256, 1024))
 
 
+
+_COUNTS = {}
+
+
+def counts_tensor(counts, device):
+    """element counts of the multi-resolution spectra as a device tensor, cached per shape: a torch.tensor(list, device=)
+    per step is a blocking pageable copy, i.e. one host-device synchronisation per step"""
+    key = (counts, str(device))
+    t = _COUNTS.get(key)
+    if t is None:
+        t = _COUNTS[key] = torch.tensor(list(counts), device=device, dtype=torch.int64)
+    return t
+
+
 def enhancer_loss(enh_real, enh_imag, clean_wave, clean_real, clean_imag):
     """_compute_loss after the model call: iSTFT -> SI-SNR + 0.5 * L1 magnitude + multi-resolution STFT.
     Returns (losses [4] = total, neg_sisnr, l1_mag, mr_stft — a device tensor, no host sync), enhanced waveform."""
@@ -578,5 +592,5 @@ def enhancer_loss(enh_real, enh_imag, clean_wave, clean_real, clean_imag):
         s = ops.spec_sums(pr, pi, tr, ti)
         Sr[i].copy_(s)
         counts.append(pr.numel())
-    nr = torch.tensor(counts, device=clean_wave.device, dtype=torch.int64)
+    nr = counts_tensor(tuple(counts), clean_wave.device)
     return ops.enhancer_loss_finalize(Sw, Sm, Sr, nr, B, L, enh_real.numel()), enh_wav

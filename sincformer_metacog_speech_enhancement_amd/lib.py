@@ -72,9 +72,14 @@ SIGNATURES = {
     "sfm_stoi_frames": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "sfm_sinc_wgrad_scratch_floats": [c_i, c_i, c_i, c_i],
     "sfm_sinc_wgrad": [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "sfm_gn_bwd_reduce": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "sfm_gn_bwd_apply": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
-                         c_vp],
+    "sfm_sinc_shift_len": [c_i],
+    "sfm_sinc_shift_pack": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "sfm_sinc_wgrad16": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_gn_bwd_reduce": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i,
+                          c_i, c_i, c_i, c_vp],
+    "sfm_gn_bwd_coefs": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_gn_bwd_apply": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp,
+                         c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp],
     "sfm_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp],
     "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
@@ -119,7 +124,7 @@ def load():
         except AttributeError as e:
             raise HipExtensionMissing("symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.argtypes = args
-        fn.restype = c_ll if name.endswith("_scratch_floats") else c_i
+        fn.restype = c_ll if name.endswith("_scratch_floats") or name == "sfm_sinc_shift_len" else c_i
     _lib = lib
     return lib
 

@@ -540,10 +540,20 @@ def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits)
                                              ld_logits, dlog.stride(0), _stream()), 0.0, 32.0 * M * F)
 
 
-def sinc_wgrad(wave, dy, C, K):
-    """dfilt [C, K] = sum_{b,l} dy[b, l, c] * wave[b, l + k - K//2]   (dy [B, L, C] 16-bit or fp32)"""
+def sinc_wgrad(wave, dy, C, K, exact=False):
+    """dfilt [C, K] = sum_{b,l} dy[b, l, c] * wave[b, l + k - K//2]   (dy [B, L, C] 16-bit or fp32).
+    A 16-bit dy with the reference's 251 taps runs on the matrix cores (waveform rounded to the compute dtype, like the
+    activations of every other weight gradient on the path); exact=True or an fp32 dy keeps the fp32 vector kernel."""
     L_ = _lib.load()
     B, L = wave.shape
+    if not exact and K == 251 and dy.dtype == _state["dtype"] and C % 8 == 0:
+        Lc = int(L_.sfm_sinc_shift_len(L))
+        xs = torch.empty(B, 8, Lc, device=wave.device, dtype=dy.dtype)
+        _call("sinc_shift_pack", L_.sfm_sinc_shift_pack, (_p(wave), _p(xs), B, L, _dt(), _stream()), 0.0, B * (4.0 * L + 16.0 * Lc))
+        dW = torch.zeros(C, 256, device=wave.device, dtype=torch.float32)
+        _call("sinc_wgrad16", L_.sfm_sinc_wgrad16, (_p(dy), _p(xs), _p(dW), B, L, C, _dt(), _stream()), 2.0 * B * L * C * 256,
+              B * L * (2.0 * C + 16.0))
+        return dW[:, :K].contiguous()
     dfilt = torch.zeros(C, K, device=wave.device, dtype=torch.float32)
     scratch = torch.empty(int(L_.sfm_sinc_wgrad_scratch_floats(B, L, C, K)), device=wave.device, dtype=torch.float32)
     _call("sinc_wgrad", L_.sfm_sinc_wgrad, (_p(wave), _p(dy), 1 if dy.dtype == torch.float32 else 0, _p(dfilt), _p(scratch), B, L, C,
@@ -567,38 +577,33 @@ def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, s
     Returns dx1, dgamma1, dbeta1 (and dx2, dgamma2, dbeta2 when two inputs)."""
     L_ = _lib.load()
     B, L, C = x1.shape
-    cg = C // G
     dx_dtype = dx_dtype or _state["dtype"]
     two = x2 is not None
-
-    def table(sc, sh, mean, rstd):
-        return torch.stack([sc.float(), sh.float(), mean.repeat_interleave(cg, dim=1), rstd.repeat_interleave(cg, dim=1)]).contiguous()
-    t1 = table(sc1, sh1, mean1, rstd1)
-    t2 = table(sc2, sh2, mean2, rstd2) if two else None
-    S = torch.zeros(B, C, 3, device=x1.device, dtype=torch.float32)
+    dev = x1.device
     f32 = lambda t: 1 if t.dtype == torch.float32 else 0
+    c32 = lambda t: None if t is None else t.float().contiguous()
     dout = dout.contiguous()
-    _call("gn_bwd", L_.sfm_gn_bwd_reduce, (_p(dout), f32(dout), _p(x1), f32(x1), _p(t1), _p(x2), f32(x2) if two else 0, _p(t2), _p(S),
-                                           B, L, C, int(act), _dt(), _stream()), 0.0, 8.0 * B * L * C)
-    n = float(L * cg)
-
-    def coefs(gamma, rstd, col):
-        g = gamma.float()
-        A = (S[:, :, 0] * g).reshape(B, G, cg).sum(-1)                       # sum over the group of dp * gamma
-        Bq = (S[:, :, col] * g).reshape(B, G, cg).sum(-1)                    # ... of dp * gamma * xhat
-        r = rstd.repeat_interleave(cg, dim=1)
-        return torch.stack([r * g, r * A.repeat_interleave(cg, dim=1) / n, r * Bq.repeat_interleave(cg, dim=1) / n]).contiguous()
-    c1 = coefs(gamma1, rstd1, 1)
-    c2 = coefs(gamma2, rstd2, 2) if two else None
-    dx1 = torch.empty(B, L, C, device=x1.device, dtype=dx_dtype)
-    dx2 = torch.empty(B, L, C, device=x1.device, dtype=dx_dtype) if two else None
-    _call("gn_bwd", L_.sfm_gn_bwd_apply, (_p(dout), f32(dout), _p(x1), f32(x1), _p(t1), _p(c1), _p(dx1), f32(dx1), _p(x2),
-                                          f32(x2) if two else 0, _p(t2), _p(c2), _p(dx2), f32(dx2) if two else 0, B, L, C, int(act),
-                                          _dt(), _stream()), 0.0, 10.0 * B * L * C)
-    dbeta = S[:, :, 0].sum(0)
+    sc1, sh1, mean1, rstd1, gamma1 = c32(sc1), c32(sh1), c32(mean1), c32(rstd1), c32(gamma1)
+    sc2, sh2, mean2, rstd2, gamma2 = c32(sc2), c32(sh2), c32(mean2), c32(rstd2), c32(gamma2)
+    work = torch.zeros(3 * B * C + 3 * C, device=dev, dtype=torch.float32)       # S [B][3][C] | dparam [3][C]
+    S, dparam = work[:3 * B * C], work[3 * B * C:].view(3, C)
+    nbytes = float(B * L * C) * ((4 if f32(dout) else 2) + (1 + two) * (4 if f32(x1) else 2))
+    _call("gn_bwd", L_.sfm_gn_bwd_reduce, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(x2),
+                                           f32(x2) if two else 0, _p(sc2), _p(sh2), _p(mean2), _p(rstd2), _p(S), B, L, C, G,
+                                           int(act), _dt(), _stream()), 0.0, nbytes)
+    coef = torch.empty(2, 3, B, C, device=dev, dtype=torch.float32)
+    _call("gn_bwd_coefs", L_.sfm_gn_bwd_coefs, (_p(S), _p(gamma1), _p(rstd1), _p(gamma2), _p(rstd2), _p(coef[0]),
+                                                _p(coef[1]) if two else None, _p(dparam), B, L, C, G, _stream()), 0.0,
+          4.0 * 9 * B * C)
+    dx1 = torch.empty(B, L, C, device=dev, dtype=dx_dtype)
+    dx2 = torch.empty(B, L, C, device=dev, dtype=dx_dtype) if two else None
+    _call("gn_bwd", L_.sfm_gn_bwd_apply, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(coef[0]),
+                                          _p(dx1), f32(dx1), _p(x2), f32(x2) if two else 0, _p(sc2), _p(sh2), _p(mean2), _p(rstd2),
+                                          _p(coef[1]) if two else None, _p(dx2), f32(dx2) if two else 0, B, L, C, G, int(act),
+                                          _dt(), _stream()), 0.0, nbytes + float(B * L * C) * (1 + two) * (4 if f32(dx1) else 2))
     if two:
-        return dx1, S[:, :, 1].sum(0), dbeta, dx2, S[:, :, 2].sum(0), dbeta.clone()
-    return dx1, S[:, :, 1].sum(0), dbeta
+        return dx1, dparam[1], dparam[0], dx2, dparam[2], dparam[0]
+    return dx1, dparam[1], dparam[0]
 
 
 # ---------------------------------------------------------------------------
@@ -610,7 +615,7 @@ def gemm16_tn(G16, X16, dW, db=None):
     M, N = G16.shape
     K = X16.shape[1]
     _call("gemm16_tn", L.sfm_gemm16_tn, (_p(G16), _p(X16), _p(dW), _p(db), M, N, K, G16.stride(0), X16.stride(0), dW.stride(0),
-                                         _dt(), _stream()), 2.0 * M * N * K, M * (N + K) * 2.0)
+                                         _dt(), _stream()), 2.0 * M * N * K, M * (N + K) * 2.0, tag="M%d N%d K%d" % (M, N, K))
 
 
 def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
@@ -621,7 +626,8 @@ def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
     db = torch.zeros(N, device=x16.device, dtype=torch.float32)
     _call("gemm16_tn", L.sfm_conv_wgrad16, (_p(dy16), _p(x16), _p(dW), _p(db), B, Lout, Lin, Cin, N, ksize, stride, pad,
                                             Lin * Cin, dy16.stride(0), dW.stride(0), _dt(), _stream()),
-          2.0 * B * Lout * N * ksize * Cin, (B * Lout * N + B * Lin * Cin) * 2.0)
+          2.0 * B * Lout * N * ksize * Cin, (B * Lout * N + B * Lin * Cin) * 2.0,
+          tag="conv M%d N%d K%d s%d" % (B * Lout, N, ksize * Cin, stride))
     return dW.reshape(N, ksize, Cin).permute(0, 2, 1).contiguous(), db
 
 

@@ -436,7 +436,7 @@ class EnhancerLossFunction(torch.autograd.Function):
                 ops.stft_adjoint_ola(frames, dwave, B, Tr, L, nf, hp, wn, accumulate=True,
                                      post=inv_env if i == R - 1 else None)
                 del g, frames
-        nr = torch.tensor(counts, device=dev, dtype=torch.int64)
+        nr = Fn.counts_tensor(tuple(counts), dev)
         losses = ops.enhancer_loss_finalize(Sw, Sm, Sr, nr, B, L, er.numel())
         if need_grad:
             d_er = torch.empty(B, T, F, device=dev, dtype=torch.float32)

@@ -199,7 +199,7 @@ def test_attention_train_fwd_bwd(ops, dt, B, T, H, p, hd):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,L,C,G,act,two", [(2, 300, 64, 8, 1, False), (3, 257, 128, 16, 1, True), (1, 130, 256, 16, 0, False),
-                                             (2, 200, 512, 32, 0, False)])
+                                             (2, 200, 512, 32, 0, False), (2, 520, 64, 16, 1, True)])
 def test_groupnorm_act_backward(ops, dt, B, L, C, G, act, two):
     """out = act(GN(x1) [+ GN(x2)]) (PerceptionAgent nodes, channels-last): dx, dgamma, dbeta vs F.group_norm autograd"""
     ops.set_compute_dtype(dt)
@@ -229,6 +229,12 @@ def test_groupnorm_act_backward(ops, dt, B, L, C, G, act, two):
         report("gn bwd dx%d C%d act%d" % (i, C, act), dx.cpu(), xq[i].grad, 2e-3 * scale + 1e-5)
         report("gn bwd dgamma%d" % i, dg.cpu(), gr[i].grad, 2e-3 * float(gr[i].grad.abs().max()) + 1e-4)
         report("gn bwd dbeta%d" % i, db.cpu(), br[i].grad, 2e-3 * float(br[i].grad.abs().max()) + 1e-4)
+    # the storage formats of the training path: 16-bit incoming gradient and dx, fp32 raw input (latent heads)
+    args32 = [a.float() if j % 6 == 0 else a for j, a in enumerate(args)]
+    res16 = ops.gn_act_backward(dout.cuda().to(dt), act, G, *args32, dx_dtype=dt)
+    for i in range(len(xs)):
+        scale = float(xq[i].grad.abs().max())
+        report("gn bwd dx%d (16-bit io)" % i, res16[3 * i].float().cpu(), xq[i].grad, (3e-2 if dt is torch.bfloat16 else 4e-3) * scale)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -271,11 +277,14 @@ def test_sinc_fir_tap_gradient(B, L, dt):
     filt = torch.zeros(C, 1, K, dtype=torch.float64, requires_grad=True)
     y = F.conv1d(wave.double().unsqueeze(1), filt, padding=K // 2)               # [B, C, L]
     (y * dy.double().transpose(1, 2)).sum().backward()
-    got = ops.sinc_wgrad(wave.cuda(), dy.cuda(), C, K).cpu().double()
+    got = ops.sinc_wgrad(wave.cuda(), dy.cuda(), C, K, exact=True).cpu().double()
     ref = filt.grad[:, 0]
     rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-    print("sinc tap gradient B%d L%d %s: rel rmse %.2e" % (B, L, dt, rel))
+    got16 = ops.sinc_wgrad(wave.cuda(), dy.cuda(), C, K).cpu().double()         # matrix cores, waveform rounded to 16 bits
+    rel16 = float((got16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print("sinc tap gradient B%d L%d %s: rel rmse %.2e (fp32 vector kernel), %.2e (MFMA, 16-bit waveform)" % (B, L, dt, rel, rel16))
     assert rel < 1e-5
+    assert rel16 < 4 * EPS[dt]
 
 
 @pytest.mark.parametrize("Tin,Tout", [(200, 21), (21, 200), (150, 16), (7, 7), (1000, 101)])
