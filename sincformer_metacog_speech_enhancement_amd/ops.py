@@ -182,6 +182,18 @@ class PackedWeight:
         self.ksize, self.cin, self.glu = ksize, cin, glu
 
 
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n, device):
+    """read-only fp32 zeros [n], cached per device"""
+    key = (int(n), str(device))
+    t = _ZERO_BIAS.get(key)
+    if t is None:
+        t = _ZERO_BIAS[key] = torch.zeros(n, device=device, dtype=torch.float32)
+    return t
+
+
 def pack_linear(weight, bias=None, glu=False, k_pad_to=None, dtype=None):
     """weight [N, K] (nn.Linear) or [N, Cin, k] (nn.Conv1d; repacked to tap-major K).
     glu=True interleaves the two halves in 32-row groups for the GLU epilogue."""
@@ -192,22 +204,28 @@ def pack_linear(weight, bias=None, glu=False, k_pad_to=None, dtype=None):
         ksize = w.shape[2]
         w = w.permute(0, 2, 1).reshape(w.shape[0], -1)       # [N, k*Cin], tap-major
     N, K = w.shape
-    b = bias.detach().float() if bias is not None else torch.zeros(N, device=w.device)
-    if glu:
-        C = N // 2
-        idx = torch.arange(N, device=w.device)
-        blk, t = idx // 64, idx % 64
-        src = torch.where(t < 32, blk * 32 + t, C + blk * 32 + (t - 32))
-        w, b = w[src], b[src]
     Kpad = round_up(k_pad_to or K, 64)
     if glu or (N > 64 and round_up(N, 128) - N < 64):
         Npad = round_up(N, 128)          # 128-column tiles
     else:
         Npad = round_up(N, 64)           # 64-column tiles (kernel picks BN from Npad % 128)
-    W = torch.zeros(Npad, Kpad, device=w.device, dtype=dtype)
-    W[:N, :K] = w.to(dtype)
-    Bp = torch.zeros(Npad, device=w.device, dtype=torch.float32)
-    Bp[:N] = b
+    if not glu and N == Npad and K == Kpad:
+        # already tile-aligned (every Linear / Conv1d of the path but the heads): one convert launch, the bias is used in
+        # place (the training step packs ~150 weights per step; zero-fill + slice-copy per operand was ~800 tiny launches)
+        W = w.to(dtype).contiguous()
+        Bp = bias.detach().float().contiguous() if bias is not None else _zero_bias(Npad, w.device)
+    else:
+        b = bias.detach().float() if bias is not None else _zero_bias(N, w.device)
+        if glu:
+            C = N // 2
+            idx = torch.arange(N, device=w.device)
+            blk, t = idx // 64, idx % 64
+            src = torch.where(t < 32, blk * 32 + t, C + blk * 32 + (t - 32))
+            w, b = w[src], b[src]
+        W = torch.zeros(Npad, Kpad, device=w.device, dtype=dtype)
+        W[:N, :K] = w.to(dtype)
+        Bp = torch.zeros(Npad, device=w.device, dtype=torch.float32)
+        Bp[:N] = b
     if ksize == 1:
         cin = Kpad if k_pad_to else K    # operand rows must be zero padded up to cin
         if cin % 8 != 0:
@@ -622,8 +640,8 @@ def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
     """Conv1d weight / bias gradient from dY [B*Lout, N] and the channels-last input x [B, Lin, Cin] (both 16-bit):
     returns dW in torch's Conv1d layout [N, Cin, ksize] and db [N] (fp32)."""
     L = _lib.load()
-    dW = torch.zeros(N, ksize * Cin, device=x16.device, dtype=torch.float32)
-    db = torch.zeros(N, device=x16.device, dtype=torch.float32)
+    buf = torch.zeros(N * ksize * Cin + N, device=x16.device, dtype=torch.float32)       # dW | db: one fill
+    dW, db = buf[:N * ksize * Cin].view(N, ksize * Cin), buf[N * ksize * Cin:]
     _call("gemm16_tn", L.sfm_conv_wgrad16, (_p(dy16), _p(x16), _p(dW), _p(db), B, Lout, Lin, Cin, N, ksize, stride, pad,
                                             Lin * Cin, dy16.stride(0), dW.stride(0), _dt(), _stream()),
           2.0 * B * Lout * N * ksize * Cin, (B * Lout * N + B * Lin * Cin) * 2.0,

@@ -218,8 +218,19 @@ def block_train_forward(x32, P, B, T, H, p, seed, bn_buffers=None, momentum=0.1,
     return y, dict(c1=c1, c2=c2, c3=c3, c4=c4, x4=x4, fw=fw)
 
 
+def _zero_grads(shapes, device):
+    """{name: zero-filled fp32 tensor of that shape}, all views of ONE buffer (one fill launch instead of one per
+    parameter; every view starts on a 256-byte boundary)"""
+    offs, n = {}, 0
+    for k, shp in shapes.items():
+        offs[k] = n
+        n += (int(torch.Size(shp).numel()) + 63) // 64 * 64
+    flat = torch.zeros(n, device=device, dtype=torch.float32)
+    return {k: flat[o:o + torch.Size(shapes[k]).numel()].view(shapes[k]) for k, o in offs.items()}
+
+
 def block_train_backward(dy32, ctx, P):
-    G = {k: torch.zeros(P[k].shape, device=dy32.device, dtype=torch.float32) for k in PARAM_NAMES}
+    G = _zero_grads({k: P[k].shape for k in PARAM_NAMES}, dy32.device)
     d4 = ops.layernorm_bwd(ctx["x4"], ctx["fw"], dy32, None, G["final_norm.weight"], G["final_norm.bias"])
     d3 = _ffn_bwd(d4, ctx["c4"], G, "ff2.")
     d2 = _conv_bwd(d3, ctx["c3"], G)
@@ -524,7 +535,7 @@ class SubmoduleFunction(torch.autograd.Function):
     def backward(ctx, dy):
         B, T, D = ctx.shape
         prefix, names = _SUB[ctx.kind]
-        G = {prefix + n: torch.zeros(ctx.P[prefix + n].shape, device=dy.device, dtype=torch.float32) for n in names}
+        G = _zero_grads({prefix + n: ctx.P[prefix + n].shape for n in names}, dy.device)
         d = dy.detach().float().reshape(B * T, D).contiguous()
         if ctx.kind == "ffn":
             dx = _ffn_bwd(d, ctx.saved, G, prefix)
