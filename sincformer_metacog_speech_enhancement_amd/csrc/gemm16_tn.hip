@@ -30,8 +30,21 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
   __shared__ __attribute__((aligned(16))) u16 Xs[64 * TN_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-  const int m_begin = blockIdx.z * rows_per_split;
+  // XCD-aware order: consecutive linear workgroup ids go round-robin over the 8 XCDs; give each XCD a contiguous run of
+  // (n-tile, k-tile, m-split) ids so that the tiles of one m-split (same G and X rows) share an L2
+  int bx, by, bz;
+  {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bx = id % gridDim.x;
+    const int rest = id / gridDim.x;
+    by = rest % gridDim.y;
+    bz = rest / gridDim.y;
+  }
+  const int n0 = bx * 128, k0 = by * 128;
+  const int m_begin = bz * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
 
   f32x16 acc[2][2];
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
   const int tcol = (g16 & 1) * 16 + 4 * pp;
 
   // bias gradient (column sums of G): the k-tile-0 workgroups already stage every G tile in LDS
-  const bool do_bias = (db != nullptr) && (blockIdx.y == 0);
+  const bool do_bias = (db != nullptr) && (by == 0);
   float bsum = 0.f;
   load_tile(m_begin);
   for (int mt = m_begin; mt < m_end; mt += 64) {
@@ -226,7 +239,9 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
   if (!G || !X || !dW) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (cv.Lout == 0 && (ldx % 8) != 0)) return SFM_ERR_SHAPE;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int splits = (1024 + tiles - 1) / tiles;                    // aim at ~1024 workgroups
+  // 142 registers -> 3 workgroups per CU: aim at ONE full round of 768 resident workgroups (1024 was 1.3 rounds: the
+  // second round ran on a third of the chip)
+  int splits = 768 / tiles;
   const int max_splits = (M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
