@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
   }
   const uint32_t one16 = T::from_f32(1.0f);
   const uint32_t ones2 = one16 | (one16 << 16);
-  const u32x4 kaug = {hl == 0 ? ones2 : 0u, 0u, 0u, 0u};            // K side of the augmented k-step
+  // augmented k-step: K side (1, 1, pad, 0...) x Q side (-m_hi, -m_lo, -BIG, 0...): the matrix core subtracts the running
+  // max AND pushes the scores of padding keys (>= Tlen, last tile only) to -BIG.  (A VALU mask under a wave-uniform
+  // `if (last tile)` was if-converted by the compiler into ~110 compare / select instructions on EVERY tile.)
+  const uint32_t negbig = (uint32_t)T::from_f32(T::id == SFM_DT_F16 ? -60000.0f : -3.0e38f);
   const u32x4 vones = {ones2, ones2, ones2, ones2};                 // V^T side: a row of ones -> row sums
-  u32x4 qaug = {0u, 0u, 0u, 0u};                                    // Q side: (-m_hi, -m_lo, 0, ...)
+  u32x4 qaug = {0u, hl == 0 ? negbig : 0u, 0u, 0u};                 // Q side: (-m_hi, -m_lo, -BIG, 0, ...)
 
   f32x16 o[2], lacc;
 #pragma unroll
@@ -144,6 +147,8 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         kf[ks] = *reinterpret_cast<const u32x4*>(&Ks[(kj * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
+      const bool pad_ = kt * 64 + kj * 32 + l31 >= Tlen;
+      const u32x4 kaug = {hl == 0 ? ones2 : 0u, (hl == 0 && pad_) ? one16 : 0u, 0u, 0u};
       __builtin_amdgcn_s_setprio(1);
       s[kj] = T::mfma(kaug, qaug, zero);
 #pragma unroll
@@ -155,13 +160,6 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     // DEFER_THR (log2 units) - a rare, wave-uniform branch that rescales O, l and this tile's scores;
     // otherwise P = exp2(s) directly (values up to 2^DEFER_THR).
     const int kbase = kt * 64;
-    if (kbase + 64 > Tlen) {                            // wave-uniform: only the last, partial tile masks keys
-#pragma unroll
-      for (int kj = 0; kj < 2; ++kj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kbase + kj * 32 + mfma_row(r, lane) >= Tlen) s[kj][r] = -3.0e38f;
-    }
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
