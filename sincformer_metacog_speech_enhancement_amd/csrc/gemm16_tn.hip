@@ -7,6 +7,7 @@
 // M is split over gridDim.z; partial tiles are accumulated into the fp32 dW with float atomics
 // (128-byte contiguous per wave-instruction).  sfm_colsum gives the bias gradient.
 #include "sfm_common.h"
+#include <cstdlib>
 
 #define TN_ROW 160      // u16 elements per LDS row (128 + 32 pad) = 320 B
 
@@ -241,7 +242,8 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // 142 registers -> 3 workgroups per CU: aim at ONE full round of 768 resident workgroups (1024 was 1.3 rounds: the
   // second round ran on a third of the chip)
-  int splits = 768 / tiles;
+  static const int target = getenv("SFM_TN_TARGET") ? atoi(getenv("SFM_TN_TARGET")) : 768;   // A/B knob (tools/gemm_tn_bench.py)
+  int splits = target / tiles;
   const int max_splits = (M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
