@@ -338,6 +338,160 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
 // free), and there is one workgroup launch per CU slot instead of one per tile.
 // Tile order: XCD x owns the contiguous range [x Q, (x+1) Q) of the (batch, M-tile, N-tile) list and its resident
 // workgroups take neighbouring tiles, so the N-tiles of one M-tile share that XCD's L2.
+// Epilogue of one wave tile (64 rows x WN columns, accumulators acc[2][NJ]) in 8 passes of 8 rows through the wave's private
+// LDS strip `img` (8 x (WN + 4) floats): bias / activation / GLU / residual / dropout / GroupNorm partials, 16-byte row stores.
+// colb = first packed column of the wave tile, row_base = its first output row (within batch entry b).
+template <class T, int NJ>
+__device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32x16 (&acc)[2][NJ], float* img, int lane, int b,
+                                                       int colb, int row_base) {
+  constexpr int WN = NJ * 32, IMG_LD = WN + 4;
+  const int l31 = lane & 31, hl = lane >> 5;
+  // ------------------------------ epilogue: 8 passes of 8 rows through the wave's LDS strip ------------------------------
+    const bool glu = (p.epi == EPI_GLU);
+  const int ecols = glu ? 32 : WN;
+  const int cpr = ecols >> 3;
+  const int c8 = (lane % cpr) * 8, rsub = lane / cpr;
+  const bool lane_on = rsub < 8;
+  
+  const int ncol0 = glu ? ((colb >> 1) + c8) : (colb + c8);
+  float bia[8], big[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;
+    big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
+  }
+  const long long obase = (long long)b * p.o_batch_stride;
+  float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      const int row = i * 32 + q * 8 + rsub;           // row inside the wave tile
+      const int m = row_base + row;
+      const bool mok = lane_on && m < p.Lout;
+      float v[8];
+      {
+        const int rs = lane_on ? rsub : 0;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8]);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8 + 4]);
+        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+        v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bia[e];
+        if (glu) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8]);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8 + 4]);
+          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= sigmoid_f(g[e] + big[e]);
+        }
+      }
+      if (p.gn_partial && mok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
+      }
+      switch (p.epi) {
+        case EPI_SWISH:
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = swish_f(v[e]);
+          break;
+        case EPI_GELU:
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+          break;
+        case EPI_SIGMOID:
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
+          break;
+        case EPI_TANH_SCALE:
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = p.alpha * tanhf(v[e]);
+          break;
+        case EPI_SIGMA:
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = expf(0.5f * fminf(fmaxf(v[e], -10.f), 10.f));
+          break;
+        case EPI_CPEA:
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (ncol0 + e < p.nsplit) ? sigmoid_f(v[e]) : p.alpha * tanhf(v[e]);
+          break;
+        default: break;
+      }
+      if (mok) {
+        const long long orow = obase + (long long)m * p.ldo + ncol0;
+        if (p.vec_ok && ncol0 + 8 <= p.N) {
+          if (p.epi == EPI_RESID) {
+            if (p.p_drop > 0.f) {
+              const float ik = 1.0f / (1.0f - p.p_drop);
+              const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik);
+            }
+            const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
+            const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
+            const f32x4 r1v = *reinterpret_cast<const f32x4*>(rp + 4);
+            v[0] = r0v[0] + p.alpha * v[0]; v[1] = r0v[1] + p.alpha * v[1];
+            v[2] = r0v[2] + p.alpha * v[2]; v[3] = r0v[3] + p.alpha * v[3];
+            v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
+            v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
+          }
+          if (p.out_f32) {
+            float* op = reinterpret_cast<float*>(p.out) + orow;
+            f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4*>(op) = a;
+            *reinterpret_cast<f32x4*>(op + 4) = c;
+          } else {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (ncol0 + e < p.N) {
+              float y = v[e];
+              if (p.epi == EPI_RESID) {
+                if (p.p_drop > 0.f)
+                  y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
+                y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
+              }
+              if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
+              else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
+            }
+          }
+        }
+      }
+    }
+  if (p.gn_partial) {
+    for (int o = cpr; o < 64; o <<= 1) {               // lanes with the same column chunk hold different rows
+      gsum += __shfl_xor(gsum, o, 64);
+      gsq += __shfl_xor(gsq, o, 64);
+    }
+    const int cpg = p.gn_group >> 3;
+    for (int o = 1; o < cpg; o <<= 1) {
+      gsum += __shfl_xor(gsum, o, 64);
+      gsq += __shfl_xor(gsq, o, 64);
+    }
+    if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N && (row_base >> 6) < p.gn_slots) {
+      const int ngroups = p.N / p.gn_group;
+      const long long sl = ((long long)b * p.gn_slots + (row_base >> 6)) * ngroups + ncol0 / p.gn_group;
+      p.gn_partial[sl * 2 + 0] = gsum;
+      p.gn_partial[sl * 2 + 1] = gsq;
+    }
+  }
+
+}
+
 template <class T, int BN>
 __global__ __launch_bounds__(256) void gemm16p_kernel(Gemm2Params p, int total_tiles) {
   constexpr int BM = 128, BKB = 128;
@@ -459,150 +613,7 @@ __global__ __launch_bounds__(256) void gemm16p_kernel(Gemm2Params p, int total_t
       stage ^= 1;
     }
 
-    // ------------------------------ epilogue: 8 passes of 8 rows through the wave's LDS strip ------------------------------
-    const int row_base = l0 + wm * 64;
-    const bool glu = (p.epi == EPI_GLU);
-    const int ecols = glu ? 32 : WN;
-    const int cpr = ecols >> 3;
-    const int c8 = (lane % cpr) * 8, rsub = lane / cpr;
-    const bool lane_on = rsub < 8;
-    const int colb = n0 + wn * WN;
-    const int ncol0 = glu ? ((colb >> 1) + c8) : (colb + c8);
-    float bia[8], big[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;
-      big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
-    }
-    const long long obase = (long long)b * p.o_batch_stride;
-    float gsum = 0.f, gsq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        const int row = i * 32 + q * 8 + rsub;           // row inside the wave tile
-        const int m = row_base + row;
-        const bool mok = lane_on && m < p.Lout;
-        float v[8];
-        {
-          const int rs = lane_on ? rsub : 0;
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8]);
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8 + 4]);
-          v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
-          v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bia[e];
-          if (glu) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8]);
-            const f32x4 g1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8 + 4]);
-            const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= sigmoid_f(g[e] + big[e]);
-          }
-        }
-        if (p.gn_partial && mok) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
-        }
-        switch (p.epi) {
-          case EPI_SWISH:
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = swish_f(v[e]);
-            break;
-          case EPI_GELU:
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-            break;
-          case EPI_SIGMOID:
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
-            break;
-          case EPI_TANH_SCALE:
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = p.alpha * tanhf(v[e]);
-            break;
-          case EPI_SIGMA:
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = expf(0.5f * fminf(fmaxf(v[e], -10.f), 10.f));
-            break;
-          case EPI_CPEA:
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (ncol0 + e < p.nsplit) ? sigmoid_f(v[e]) : p.alpha * tanhf(v[e]);
-            break;
-          default: break;
-        }
-        if (mok) {
-          const long long orow = obase + (long long)m * p.ldo + ncol0;
-          if (p.vec_ok && ncol0 + 8 <= p.N) {
-            if (p.epi == EPI_RESID) {
-              if (p.p_drop > 0.f) {
-                const float ik = 1.0f / (1.0f - p.p_drop);
-                const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik);
-              }
-              const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
-              const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
-              const f32x4 r1v = *reinterpret_cast<const f32x4*>(rp + 4);
-              v[0] = r0v[0] + p.alpha * v[0]; v[1] = r0v[1] + p.alpha * v[1];
-              v[2] = r0v[2] + p.alpha * v[2]; v[3] = r0v[3] + p.alpha * v[3];
-              v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
-              v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
-            }
-            if (p.out_f32) {
-              float* op = reinterpret_cast<float*>(p.out) + orow;
-              f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
-              *reinterpret_cast<f32x4*>(op) = a;
-              *reinterpret_cast<f32x4*>(op + 4) = c;
-            } else {
-              u32x4 pk;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-              *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              if (ncol0 + e < p.N) {
-                float y = v[e];
-                if (p.epi == EPI_RESID) {
-                  if (p.p_drop > 0.f)
-                    y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
-                  y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
-                }
-                if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
-                else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
-              }
-            }
-          }
-        }
-      }
-    if (p.gn_partial) {
-      for (int o = cpr; o < 64; o <<= 1) {               // lanes with the same column chunk hold different rows
-        gsum += __shfl_xor(gsum, o, 64);
-        gsq += __shfl_xor(gsq, o, 64);
-      }
-      const int cpg = p.gn_group >> 3;
-      for (int o = 1; o < cpg; o <<= 1) {
-        gsum += __shfl_xor(gsum, o, 64);
-        gsq += __shfl_xor(gsq, o, 64);
-      }
-      if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N && (row_base >> 6) < p.gn_slots) {
-        const int ngroups = p.N / p.gn_group;
-        const long long sl = ((long long)b * p.gn_slots + (row_base >> 6)) * ngroups + ncol0 / p.gn_group;
-        p.gn_partial[sl * 2 + 0] = gsum;
-        p.gn_partial[sl * 2 + 1] = gsq;
-      }
-    }
+    gemm16_epilogue_strips<T, NJ>(p, acc, img, lane, b, n0 + wn * WN, l0 + wm * 64);
   }
   wait_vmcnt<0>();                                     // nothing of the ring is in flight when the workgroup retires
 }
@@ -620,6 +631,139 @@ static int launch_p(const Gemm2Params& p, hipStream_t stream) {
   int nblk = 512;                                      // 2 workgroups on each of the 256 CUs
   if (total < nblk) nblk = (total + 7) / 8 * 8;
   SFM_LAUNCH((gemm16p_kernel<T, BN>), dim3(nblk), dim3(256), lds, stream, p, total);
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide form (variant 9): 256 x BN tiles computed by NW = 8 (BN 128) or 16 (BN 256) waves, each wave a 64 x 64 tile as in the
+// default kernel, 2-stage ring, one workgroup per CU.  The path's GEMMs stream their operands L2 -> LDS at 8-13 TB/s whatever
+// the schedule (tools/gemm_probe.py); a 128 x 128 tile needs 15.6 B per kFLOP of that stream, 256 x 128 needs 11.7 and
+// 256 x 256 needs 7.8.
+template <class T, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm16w_kernel(Gemm2Params p) {
+  constexpr int BM = 256, BKB = 128;
+  constexpr int WGN = NW / 4;                          // waves along N (4 along M)
+  constexpr int WN = BN / WGN, NJ = WN / 32;
+  static_assert(WN == 64, "wave tile is 64 x 64");
+  constexpr int A_STAGE = BM * BKB, B_STAGE = BN * BKB, STAGE = A_STAGE + B_STAGE;
+  constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;    // LDS-DMA instructions (8 rows x 128 B) per wave per k-tile
+  constexpr int IMG_LD = WN + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, hl = lane >> 5;
+
+  const int total = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int ntile = id % p.nNt;
+  const int rest = id / p.nNt;
+  const int mtile = rest % p.nMt;
+  const int b = rest / p.nMt;
+  const int n0 = ntile * BN, l0 = mtile * BM;
+
+  auto a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)b * p.a_batch_stride), 0, p.a_records, 0x00020000);
+  auto w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_records, 0x00020000);
+
+  int a_rowoff[NA], a_swz[NA], b_rowoff[NB], b_swz[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (wave * NA + i) * 8 + (lane >> 3);
+    const int pos0 = (l0 + row) * p.stride - p.pad;
+    a_rowoff[i] = pos0 * p.lda * 2;
+    a_swz[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (wave * NB + i) * 8 + (lane >> 3);
+    b_rowoff[i] = (n0 + row) * p.Kpad * 2;
+    b_swz[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  const bool contiguous = (p.lda == p.Cin) || (p.cin_shift >= 30);
+
+  auto issue = [&](int kt, int stage) {
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + A_STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = kt * 64 + a_swz[i];
+      const int eoff = contiguous ? j : ((j >> p.cin_shift) * p.lda + (j & (p.Cin - 1)));
+      int voff = a_rowoff[i] + eoff * 2;
+      if (j >= p.K) voff = -1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(sa + (wave * NA + i) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int voff = b_rowoff[i] + (kt * 64 + b_swz[i]) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(sb + (wave * NB + i) * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int fa_off[2][4], fb_off[NJ][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fa_off[i][s] = row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wn * WN + j * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb_off[j][s] = A_STAGE + row * BKB + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+
+  const int nt = p.Kpad >> 6;
+  issue(0, 0);
+  int stage = 0;
+  for (int t = 0; t < nt; ++t) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) issue(t + 1, stage ^ 1);
+    const unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 fa[2], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sbase + fa_off[i][s]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sbase + fb_off[j][s]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    stage ^= 1;
+  }
+  __syncthreads();                                     // every wave is done reading the ring: it becomes the epilogue strips
+  float* img = reinterpret_cast<float*>(smem) + wave * (8 * IMG_LD);
+  gemm16_epilogue_strips<T, NJ>(p, acc, img, lane, b, n0 + wn * WN, l0 + wm * 64);
+}
+
+template <class T, int BN, int NW>
+static int launch_w(const Gemm2Params& p, hipStream_t stream) {
+  constexpr int lds = 2 * (256 + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm16w_kernel<T, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(p.nMt * p.nNt * p.B), block(NW * 64);
+  SFM_LAUNCH((gemm16w_kernel<T, BN, NW>), grid, block, lds, stream, p);
   return SFM_OK;
 }
 
@@ -690,20 +834,28 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   const bool o_al = (((uintptr_t)out) % 16 == 0) && ((ldo * osz) % 16 == 0) && ((o_batch_stride * osz) % 16 == 0);
   const bool r_al = (epi != EPI_RESID) || ((((uintptr_t)resid) % 16 == 0) && ((ldr * 4) % 16 == 0) && ((r_batch_stride * 4) % 16 == 0));
   p.vec_ok = (o_al && r_al) ? 1 : 0;
-  const bool bn128 = (Npad % 128 == 0);
+  const bool bn128 = (Npad % 128 == 0) && variant != 7 && variant != 8;   // 7 / 8: 64-column tiles with a 3- / 2-stage ring
   const int BNv = bn128 ? 128 : 64;
   // variants 4 / 5: 256-row tiles (wave tile 128 x 64), 2 / 3 stages, 128-column tiles only
   const bool big = (variant == 4 || variant == 5) && bn128;
-  const int BMv = big ? 256 : 128;
+  // 256-row tiles, 8 or 16 waves (variant 9); auto picks the 256 x 256 form when the columns allow it and there are at
+  // least two tiles per CU: +15..37 % on those shapes, the 256 x 128 form (one 8-wave workgroup per CU) is slower than
+  // the default (tools/gemm_bench.py)
+  const long long tiles256 = (long long)((Lout + 255) / 256) * (Npad / 256) * B;
+  const bool auto_wide = (variant == 0) && (Npad % 256 == 0) && tiles256 >= 512;
+  const bool wide = ((variant == 9) && bn128) || auto_wide;
+  const bool wide256 = wide && (Npad % 256 == 0);
+  const int BMv = (big || wide) ? 256 : 128;
   p.nMt = (Lout + BMv - 1) / BMv;
-  p.nNt = Npad / BNv;
+  p.nNt = wide256 ? Npad / 256 : Npad / BNv;
   p.gn_slots = 2 * ((Lout + 127) / 128);               // partial slots per batch entry: one per 64 output rows (padded to 128)
   hipStream_t st = (hipStream_t)stream;
-  const bool s3 = (variant == 3 || variant == 5);
+  const bool s3 = (variant == 3 || variant == 5 || variant == 7);
   // the persistent kernel is 5-20 % faster than variant 2 on isolated launches of the path's skinny GEMMs
   // (tools/gemm_bench.py) but 2 % slower inside the forward pass (bench.py, same box, A/B/A/B): not the default
   const bool persistent = (variant == 6);
 #define GO(TT)                                                                                            \
+  if (wide) return wide256 ? launch_w<TT, 256, 16>(p, st) : launch_w<TT, 128, 8>(p, st);                 \
   if (persistent) return bn128 ? launch_p<TT, 128>(p, st) : launch_p<TT, 64>(p, st);                    \
   if (big) return s3 ? launch_v2<TT, 128, 3, 256>(p, st) : launch_v2<TT, 128, 2, 256>(p, st);           \
   if (bn128) return s3 ? launch_v2<TT, 128, 3, 128>(p, st) : launch_v2<TT, 128, 2, 128>(p, st);          \
