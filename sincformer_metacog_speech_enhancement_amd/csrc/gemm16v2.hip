@@ -639,10 +639,10 @@ static int launch_p(const Gemm2Params& p, hipStream_t stream) {
 // default kernel, 2-stage ring, one workgroup per CU.  The path's GEMMs stream their operands L2 -> LDS at 8-13 TB/s whatever
 // the schedule (tools/gemm_probe.py); a 128 x 128 tile needs 15.6 B per kFLOP of that stream, 256 x 128 needs 11.7 and
 // 256 x 256 needs 7.8.
-template <class T, int BN, int NW>
+template <class T, int BM, int BN, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm16w_kernel(Gemm2Params p) {
-  constexpr int BM = 256, BKB = 128;
-  constexpr int WGN = NW / 4;                          // waves along N (4 along M)
+  constexpr int BKB = 128;
+  constexpr int WGN = NW / (BM / 64);                  // waves along N (BM / 64 along M)
   constexpr int WN = BN / WGN, NJ = WN / 32;
   static_assert(WN == 64, "wave tile is 64 x 64");
   constexpr int A_STAGE = BM * BKB, B_STAGE = BN * BKB, STAGE = A_STAGE + B_STAGE;
@@ -753,17 +753,17 @@ __global__ __launch_bounds__(NW * 64) void gemm16w_kernel(Gemm2Params p) {
   gemm16_epilogue_strips<T, NJ>(p, acc, img, lane, b, n0 + wn * WN, l0 + wm * 64);
 }
 
-template <class T, int BN, int NW>
+template <class T, int BM, int BN, int NW>
 static int launch_w(const Gemm2Params& p, hipStream_t stream) {
-  constexpr int lds = 2 * (256 + BN) * 128;
+  constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm16w_kernel<T, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm16w_kernel<T, BM, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SFM_ERR_LAUNCH;
     attr_set = true;
   }
   dim3 grid(p.nMt * p.nNt * p.B), block(NW * 64);
-  SFM_LAUNCH((gemm16w_kernel<T, BN, NW>), grid, block, lds, stream, p);
+  SFM_LAUNCH((gemm16w_kernel<T, BM, BN, NW>), grid, block, lds, stream, p);
   return SFM_OK;
 }
 
@@ -843,9 +843,14 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   // the default (tools/gemm_bench.py)
   const long long tiles256 = (long long)((Lout + 255) / 256) * (Npad / 256) * B;
   const bool auto_wide = (variant == 0) && (Npad % 256 == 0) && tiles256 >= 512;
+  // 512 x 128 tiles on 16 waves (variant 10; 9.8 B of operand stream per kFLOP): auto for the 128-column GEMMs with a short
+  // K (the first PerceptionAgent convs: +11..25 %; with 14 k-tiles the default kernel is already at 700 TF/s and wins)
+  const long long tiles512 = (long long)((Lout + 511) / 512) * B;
+  const bool auto_tall = (variant == 0) && Npad == 128 && Kpad <= 512 && tiles512 >= 512;
+  const bool tall = ((variant == 10) && bn128) || auto_tall;
   const bool wide = ((variant == 9) && bn128) || auto_wide;
   const bool wide256 = wide && (Npad % 256 == 0);
-  const int BMv = (big || wide) ? 256 : 128;
+  const int BMv = tall ? 512 : ((big || wide) ? 256 : 128);
   p.nMt = (Lout + BMv - 1) / BMv;
   p.nNt = wide256 ? Npad / 256 : Npad / BNv;
   p.gn_slots = 2 * ((Lout + 127) / 128);               // partial slots per batch entry: one per 64 output rows (padded to 128)
@@ -855,7 +860,8 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   // (tools/gemm_bench.py) but 2 % slower inside the forward pass (bench.py, same box, A/B/A/B): not the default
   const bool persistent = (variant == 6);
 #define GO(TT)                                                                                            \
-  if (wide) return wide256 ? launch_w<TT, 256, 16>(p, st) : launch_w<TT, 128, 8>(p, st);                 \
+  if (tall) return launch_w<TT, 512, 128, 16>(p, st);                                                   \
+  if (wide) return wide256 ? launch_w<TT, 256, 256, 16>(p, st) : launch_w<TT, 256, 128, 8>(p, st);      \
   if (persistent) return bn128 ? launch_p<TT, 128>(p, st) : launch_p<TT, 64>(p, st);                    \
   if (big) return s3 ? launch_v2<TT, 128, 3, 256>(p, st) : launch_v2<TT, 128, 2, 256>(p, st);           \
   if (bn128) return s3 ? launch_v2<TT, 128, 3, 128>(p, st) : launch_v2<TT, 128, 2, 128>(p, st);          \

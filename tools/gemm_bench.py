@@ -25,7 +25,7 @@ for (B, Lout, Cin, k, s, N, of32, gn) in SHAPES:
     part = torch.empty(B, 2 * ((Lout + 127) // 128), 8, 2, device="cuda") if gn else None
     row = {"shape": "B%d Lout%d Cin%d k%d s%d N%d %s" % (B, Lout, Cin, k, s, N, "f32" if of32 else "16b")}
     ref = None
-    for v in (2, 6, 9):
+    for v in (2, 9, 10):
         ops.set_gemm_variant(v)
         def run():
             ops.gemm16(x, pw, out, B=B, Lout=Lout, Lin=Lin, a_batch_stride=Lin * Cin, ldo=N, o_batch_stride=Lout * N,
