@@ -248,6 +248,25 @@ int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32,
                      int x2_f32, const float* sc2, const float* sh2, const float* mean2, const float* rstd2,
                      const float* coef2, void* dx2, int dx2_f32, int B, int L, int C, int G, int act, int dtype,
                      void* stream);
+/* SURVEY 8f N4.  MetacognitiveArbitrationAgent (agents/maa.py:70-135) on N = B * T uncertainty values; stats = (running_mean,
+ * running_var) fp32 on the device; params = W1[64] b1[64] W2[64*64] b2[64] W3[4*64] b3[4] fp32 (the decision_net).
+ * update_stats: train()-mode EMA (momentum 0.1, unbiased batch variance; acc = 2 zeroed doubles, re-zeroed on return);
+ * forward: logits / probs [N,4], decisions int64 [N], confidence [N];  backward: dsigma [N] and the 16-bit operands of the
+ * weight-gradient GEMMs (H1, H2, dZ1, dZ2 [N,64]; GL [N,8] = total logit gradient; XN [N,8], column 0 = normalised sigma). */
+int sfm_maa_update_stats(const float* sigma, long long n, double* acc, float* stats, long long* num_updates, float momentum,
+                         void* stream);
+int sfm_maa_forward(const float* sigma, const float* stats, const float* params, float* logits, float* probs,
+                    long long* decisions, float* confidence, long long n, void* stream);
+int sfm_maa_backward(const float* sigma, const float* stats, const float* params, const float* g_logits, const float* g_probs,
+                     const float* g_conf, float* dsigma, void* H1, void* H2, void* dZ1, void* dZ2, void* GL, void* XN,
+                     long long n, int dtype, void* stream);
+/* VectorQuantizer (models/vq.py:54-96), M <= 16 scalar centroids: q = nearest centroid (first minimum), idx int64,
+ * acc[0] += sum (x - q)^2 (double, zeroed by the caller);  backward: dx = g_q + g_loss beta 2 (x - q) / n (straight-through +
+ * commitment term), dcent[k] += g_loss 2 (q - x) / n over the elements assigned to k (codebook term; zeroed by the caller). */
+int sfm_vq_forward(const float* x, const float* centroids, int M, float* q, long long* idx, double* acc, long long n,
+                   void* stream);
+int sfm_vq_backward(const float* x, const long long* idx, const float* centroids, int M, const float* g_q,
+                    const float* g_loss, float beta, float* dx, float* dcent, long long n, void* stream);
 /* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
  * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
  * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */

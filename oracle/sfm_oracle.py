@@ -607,3 +607,41 @@ def stoi_simplified(clean, enhanced, fs):
         corr = np.sum(cs * en) / (np.sqrt(np.sum(cs ** 2) * np.sum(en ** 2)) + 1e-10)
         corrs.append(min(max(corr, -1.0), 1.0))
     return float(min(max(np.mean(corrs), 0.0), 1.0))
+
+
+# ----------------------------------------------------------------------------
+# MetacognitiveArbitrationAgent (agents/maa.py:26-143) and VectorQuantizer (models/vq.py:28-122)
+# ----------------------------------------------------------------------------
+def maa_forward(sd, sigma, training=False, momentum=0.1):
+    """agents/maa.py:70-124.  sigma [B,1,T] or [B,T].  Returns (dict, new_stats) where new_stats = (running_mean,
+    running_var, num_updates) after the train-mode EMA update of :126-135 (unbiased batch variance), else the inputs."""
+    sigma = _t(sigma)
+    if sigma.dim() == 3:
+        sigma = sigma.squeeze(1)
+    rm, rv, nu = _t(sd["running_mean"]), _t(sd["running_var"]), sd["num_updates"]
+    if training:
+        with torch.no_grad():
+            rm = (1 - momentum) * rm + momentum * sigma.mean()
+            rv = (1 - momentum) * rv + momentum * sigma.var()
+            nu = nu + 1
+    norm = (sigma - rm) / (torch.sqrt(rv) + 1e-8)
+    h = norm.unsqueeze(-1)
+    h = torch.relu(linear(h, sd["decision_net.0.weight"], sd["decision_net.0.bias"]))
+    h = torch.relu(linear(h, sd["decision_net.2.weight"], sd["decision_net.2.bias"]))
+    logits = linear(h, sd["decision_net.4.weight"], sd["decision_net.4.bias"])
+    probs = torch.softmax(logits, dim=-1)
+    decisions = (probs if training else logits).argmax(dim=-1)
+    out = {"decisions": decisions, "probs": probs, "logits": logits, "threshold": sd["threshold"],
+           "confidence": torch.sigmoid(-norm)}
+    return out, (rm, rv, nu)
+
+
+def vq_forward(centroids, x, beta=0.25):
+    """models/vq.py:54-96: nearest-centroid quantisation with the straight-through estimator; returns (quantized,
+    indices, commitment + codebook loss)."""
+    centroids, x = _t(centroids), _t(x)
+    d = (x.reshape(-1, 1) - centroids.reshape(1, -1)) ** 2
+    idx = torch.argmin(d, dim=-1)
+    q = centroids[idx].reshape(x.shape)
+    loss = beta * F.mse_loss(x, q.detach()) + F.mse_loss(x.detach(), q)
+    return x + (q - x).detach(), idx.reshape(x.shape), loss

@@ -16,3 +16,8 @@ CONFORMER_DROPOUT = 0.1
 CPEA_HIDDEN_SIZE = 128
 CPEA_NUM_LAYERS = 2
 PA_ENCODER_CHANNELS = 256
+
+# SURVEY 8f N4 (config.py:101-108 of the reference)
+VQ_NUM_CENTROIDS = 3
+VQ_COMMITMENT_WEIGHT = 0.25
+MAA_THRESHOLD_INIT = 0.5

@@ -80,6 +80,11 @@ SIGNATURES = {
     "sfm_gn_bwd_coefs": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_gn_bwd_apply": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp,
                          c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_maa_update_stats": [c_vp, c_ll, c_vp, c_vp, c_vp, c_f, c_vp],
+    "sfm_maa_forward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
+    "sfm_maa_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_vp],
+    "sfm_vq_forward": [c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_ll, c_vp],
+    "sfm_vq_backward": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_vp],
     "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp],
     "sfm_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp],
     "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],

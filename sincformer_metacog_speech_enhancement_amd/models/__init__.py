@@ -1,0 +1,1 @@
+from .vq import VectorQuantizer, VQMaskQuantizer

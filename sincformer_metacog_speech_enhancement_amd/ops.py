@@ -845,3 +845,74 @@ def istft_matrix(n_fft, win, device):
     M = np.concatenate([br, bi], axis=0)
     win2 = torch.from_numpy((w * w).astype(np.float32)).to(device)
     return pack_f32_matrix(torch.from_numpy(M.astype(np.float32)).to(device)), win2
+
+
+# ---------------------------------------------------------------------------
+# MetacognitiveArbitrationAgent / VectorQuantizer kernels (routing.hip)
+# ---------------------------------------------------------------------------
+def maa_update_stats(sigma, stats, num_updates, momentum=0.1):
+    """train()-mode EMA of agents/maa.py:126-135, in place on the device tensors stats [2] fp32 and num_updates int64 []"""
+    L = _lib.load()
+    acc = torch.zeros(2, device=sigma.device, dtype=torch.float64)
+    _call("maa", L.sfm_maa_update_stats, (_p(sigma), sigma.numel(), _p(acc), _p(stats), _p(num_updates), float(momentum), _stream()),
+          0.0, 4.0 * sigma.numel())
+
+
+def maa_forward(sigma, stats, params):
+    L = _lib.load()
+    n = sigma.numel()
+    dev = sigma.device
+    logits = torch.empty(n, 4, device=dev, dtype=torch.float32)
+    probs = torch.empty(n, 4, device=dev, dtype=torch.float32)
+    dec = torch.empty(n, device=dev, dtype=torch.int64)
+    conf = torch.empty(n, device=dev, dtype=torch.float32)
+    _call("maa", L.sfm_maa_forward, (_p(sigma), _p(stats), _p(params), _p(logits), _p(probs), _p(dec), _p(conf), n, _stream()),
+          2.0 * n * (64 + 64 * 64 + 4 * 64), n * 52.0)
+    return logits, probs, dec, conf
+
+
+def maa_backward(sigma, stats, params, g_logits, g_probs, g_conf):
+    """-> dsigma [N] fp32, dparams fp32 [4548] in the layout of `params` (weight gradients as three TN GEMMs)"""
+    L = _lib.load()
+    n = sigma.numel()
+    dev, dt = sigma.device, _state["dtype"]
+    dsig = torch.empty(n, device=dev, dtype=torch.float32)
+    H = torch.empty(4, n, 64, device=dev, dtype=dt)                     # H1, H2, dZ1, dZ2
+    S = torch.empty(2, n, 8, device=dev, dtype=dt)                      # GL, XN
+    _call("maa", L.sfm_maa_backward, (_p(sigma), _p(stats), _p(params), _p(g_logits), _p(g_probs), _p(g_conf), _p(dsig), _p(H[0]),
+                                      _p(H[1]), _p(H[2]), _p(H[3]), _p(S[0]), _p(S[1]), n, _dt(), _stream()),
+          4.0 * n * (64 * 64 * 2 + 8 * 64), n * (16.0 + 4 * 128 + 32))
+    buf = torch.zeros(64 * 8 + 64 + 64 * 64 + 64 + 8 * 64 + 8, device=dev, dtype=torch.float32)
+    o = 0
+    dW1 = buf[o:o + 512].view(64, 8); o += 512
+    db1 = buf[o:o + 64]; o += 64
+    dW2 = buf[o:o + 4096].view(64, 64); o += 4096
+    db2 = buf[o:o + 64]; o += 64
+    dW3 = buf[o:o + 512].view(8, 64); o += 512
+    db3 = buf[o:o + 8]
+    gemm16_tn(H[2], S[1], dW1, db1)                                      # dZ1^T x [norm | 0...]: column 0 is dW1
+    gemm16_tn(H[3], H[0], dW2, db2)
+    gemm16_tn(S[0], H[1], dW3, db3)
+    dparams = torch.cat([dW1[:, 0], db1, dW2.reshape(-1), db2, dW3[:4].reshape(-1), db3[:4]])
+    return dsig, dparams
+
+
+def vq_forward(x, centroids):
+    """-> quantized fp32 (shape of x), indices int64, sum of squared distances (device double [1])"""
+    L = _lib.load()
+    x = x.contiguous()
+    q = torch.empty_like(x)
+    idx = torch.empty(x.shape, device=x.device, dtype=torch.int64)
+    acc = torch.zeros(1, device=x.device, dtype=torch.float64)
+    _call("vq", L.sfm_vq_forward, (_p(x), _p(centroids), centroids.numel(), _p(q), _p(idx), _p(acc), x.numel(), _stream()),
+          0.0, 16.0 * x.numel())
+    return q, idx, acc
+
+
+def vq_backward(x, idx, centroids, g_q, g_loss, beta):
+    L = _lib.load()
+    dx = torch.empty_like(x)
+    dcent = torch.zeros(centroids.numel(), device=x.device, dtype=torch.float32)
+    _call("vq", L.sfm_vq_backward, (_p(x), _p(idx), _p(centroids), centroids.numel(), _p(g_q), _p(g_loss), float(beta), _p(dx),
+                                     _p(dcent), x.numel(), _stream()), 0.0, 20.0 * x.numel())
+    return dx, dcent

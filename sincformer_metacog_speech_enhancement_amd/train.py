@@ -970,3 +970,66 @@ def perception_train_forward(pa, waveform):
     D = zcat.shape[-1] // 2
     z = zcat.transpose(1, 2)
     return z[:, :D], z[:, D:], sigma.reshape(sigma.shape[0], 1, -1)
+
+
+# ---------------------------------------------------------------------------
+# MetacognitiveArbitrationAgent (agents/maa.py) and VectorQuantizer (models/vq.py) under autograd
+# ---------------------------------------------------------------------------
+def maa_pack_params(net):
+    """decision_net (Linear(1,64), ReLU, Linear(64,64), ReLU, Linear(64,4)) -> the flat fp32 layout of routing.hip"""
+    return torch.cat([_f32(net[0].weight).reshape(-1), _f32(net[0].bias), _f32(net[2].weight).reshape(-1), _f32(net[2].bias),
+                      _f32(net[4].weight).reshape(-1), _f32(net[4].bias)]).contiguous()
+
+
+class MaaFunction(torch.autograd.Function):
+    """sigma [N], stats (running_mean, running_var), the six decision_net tensors -> logits, probs [N,4], confidence [N],
+    decisions int64 [N] (not differentiable)"""
+
+    @staticmethod
+    def forward(ctx, sigma, stats, w1, b1, w2, b2, w3, b3):
+        s = sigma.detach().float().contiguous()
+        params = torch.cat([_f32(w1).reshape(-1), _f32(b1), _f32(w2).reshape(-1), _f32(b2), _f32(w3).reshape(-1), _f32(b3)]).contiguous()
+        logits, probs, dec, conf = ops.maa_forward(s, stats, params)
+        ctx.saved = (s, stats.clone(), params)
+        ctx.meta = (sigma.dtype, [t.dtype for t in (w1, b1, w2, b2, w3, b3)], [tuple(t.shape) for t in (w1, b1, w2, b2, w3, b3)])
+        ctx.mark_non_differentiable(dec)
+        return logits, probs, conf, dec
+
+    @staticmethod
+    def backward(ctx, g_logits, g_probs, g_conf, _g_dec):
+        s, stats, params = ctx.saved
+        ctx.saved = None
+        c = lambda g: None if g is None else g.detach().float().contiguous()
+        dsig, dp = ops.maa_backward(s, stats, params, c(g_logits), c(g_probs), c(g_conf))
+        sdt, pdts, shapes = ctx.meta
+        outs, o = [], 0
+        for dt_, shp in zip(pdts, shapes):
+            n = int(torch.Size(shp).numel())
+            outs.append(dp[o:o + n].view(shp).to(dt_))
+            o += n
+        return (dsig.to(sdt), None) + tuple(outs)
+
+
+class VQFunction(torch.autograd.Function):
+    """x, centroids -> quantized (straight-through gradient), indices, beta * commitment + codebook loss (models/vq.py:54-96)"""
+
+    @staticmethod
+    def forward(ctx, x, centroids, beta):
+        xf = x.detach().float().contiguous()
+        cf = centroids.detach().float().contiguous()
+        q, idx, acc = ops.vq_forward(xf, cf)
+        loss = (acc[0] * ((1.0 + beta) / xf.numel())).float()
+        ctx.saved = (xf, idx, cf)
+        ctx.meta = (float(beta), x.dtype, centroids.dtype)
+        ctx.mark_non_differentiable(idx)
+        return q.to(x.dtype), idx, loss
+
+    @staticmethod
+    def backward(ctx, g_q, _g_idx, g_loss):
+        xf, idx, cf = ctx.saved
+        ctx.saved = None
+        beta, xdt, cdt = ctx.meta
+        gq = None if g_q is None else g_q.detach().float().contiguous()
+        gl = None if g_loss is None else g_loss.detach().float().reshape(1).contiguous()
+        dx, dcent = ops.vq_backward(xf, idx, cf, gq, gl, beta)
+        return dx.to(xdt), dcent.to(cdt), None

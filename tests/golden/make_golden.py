@@ -268,8 +268,67 @@ def main_metrics():
     save("g12_metrics", **out)
 
 
+def main_routing():
+    """MetacognitiveArbitrationAgent (agents/maa.py) and VectorQuantizer (models/vq.py): state tables, eval and
+    train() outputs (running-statistics update), gradients for fixed cotangents."""
+    import json
+    from agents.maa import MetacognitiveArbitrationAgent
+    from models.vq import VectorQuantizer
+    path = os.path.join(HERE, "state_shapes.json")
+    tables = json.load(open(path))
+    for name, mod in (("MetacognitiveArbitrationAgent", MetacognitiveArbitrationAgent()), ("VectorQuantizer", VectorQuantizer())):
+        tables[name] = {"params": sum(p.numel() for p in mod.parameters() if p.requires_grad),
+                        "state": {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in mod.state_dict().items()}}
+    with open(path, "w") as fh:
+        json.dump(tables, fh, indent=0, sort_keys=True)
+
+    def maa_with_weights(seed):
+        m = MetacognitiveArbitrationAgent()
+        sd = m.state_dict()
+        new = {}
+        for k, v in sd.items():
+            if k.startswith("decision_net"):
+                new[k] = torch.from_numpy(syn.synth_array("maa." + k, tuple(v.shape), seed, 0.6 if k.endswith("weight") else 0.3))
+            else:
+                new[k] = v.clone()
+        new["running_mean"] = torch.tensor(0.8)
+        new["running_var"] = torch.tensor(0.09)
+        m.load_state_dict(new)
+        return m
+    sigma = torch.from_numpy(np.abs(syn.synth_array("g13_sigma", (3, 1, 47), 131)) + 0.4).float()
+    out = {"sigma": sigma}
+    m = maa_with_weights(130).eval()
+    with torch.no_grad():
+        r = m(sigma)
+    out.update({"eval." + k: (v if k != "threshold" else v.detach()) for k, v in r.items()})
+    m = maa_with_weights(130).train()
+    sg = sigma.clone().requires_grad_(True)
+    r = m(sg)
+    cl = torch.from_numpy(syn.synth_array("g13_cl", tuple(r["logits"].shape), 132))
+    cp_ = torch.from_numpy(syn.synth_array("g13_cp", tuple(r["probs"].shape), 133))
+    cc = torch.from_numpy(syn.synth_array("g13_cc", tuple(r["confidence"].shape), 134))
+    ((r["logits"] * cl).sum() + (r["probs"] * cp_).sum() + (r["confidence"] * cc).sum() + 3.0 * r["threshold"].sum()).backward()
+    out.update({"train." + k: v.detach() for k, v in r.items()})
+    out.update(train_running_mean=m.running_mean, train_running_var=m.running_var, train_num_updates=m.num_updates,
+               train_dsigma=sg.grad)
+    out.update({"train.grad." + k: p.grad for k, p in m.named_parameters()})
+    # vector quantiser: forward values, indices, loss; STE + loss gradients
+    vq = VectorQuantizer()
+    with torch.no_grad():
+        vq.centroids.copy_(torch.tensor([0.07, 0.46, 0.93]))
+    x = torch.from_numpy(np.clip(0.5 + 0.35 * syn.synth_array("g13_x", (2, 9, 13), 135), -0.2, 1.2)).float().requires_grad_(True)
+    q, idx, loss = vq(x)
+    cq = torch.from_numpy(syn.synth_array("g13_cq", tuple(q.shape), 136))
+    ((q * cq).sum() + 1.7 * loss).backward()
+    out.update(vq_x=x.detach(), vq_q=q.detach(), vq_idx=idx, vq_loss=loss.detach(), vq_dx=x.grad, vq_dcentroids=vq.centroids.grad,
+               vq_utilization=vq.get_utilization(idx), vq_sorted=vq.get_centroids().detach())
+    save("g13_routing", **out)
+
+
 if __name__ == "__main__":
-    if "--train-only" in sys.argv:
+    if "--routing-only" in sys.argv:
+        main_routing()
+    elif "--train-only" in sys.argv:
         main_train()
     elif "--metrics-only" in sys.argv:
         main_metrics()
@@ -277,3 +336,4 @@ if __name__ == "__main__":
         main()
         main_train()
         main_metrics()
+        main_routing()

@@ -39,6 +39,10 @@ def test_state_dict_contract_matches_the_reference():
     _check(ComplexConformer(n_freq=32, d_model=64, num_blocks=2, num_heads=4, d_ff=128, kernel_size=7, dropout=0.0),
            "ComplexConformerSmall")
     _check(cp.SpeechEnhancer(n_freq=129), "SpeechEnhancer")
+    from sincformer_metacog_speech_enhancement_amd.agents import MetacognitiveArbitrationAgent
+    from sincformer_metacog_speech_enhancement_amd.models import VectorQuantizer
+    _check(MetacognitiveArbitrationAgent(), "MetacognitiveArbitrationAgent")
+    _check(VectorQuantizer(), "VectorQuantizer")
 
 
 def test_reference_checkpoints_load_strict():

@@ -220,3 +220,51 @@ def test_quality_metrics_ssnr_stoi():
     name, fs, c, e = metric_cases()[0]
     noisy, _ = syn.synth_wave(1, 8000, 120)
     assert abs((orc.ssnr(c, e) - orc.ssnr(c, noisy[0])) - float(g["ssnr_improvement.pair0"])) < 1e-9
+
+
+def _maa_sd(seed=130):
+    from helpers import STATE_TABLES
+    shapes = {k: tuple(v[0]) for k, v in STATE_TABLES["MetacognitiveArbitrationAgent"]["state"].items()}
+    sd = {}
+    for k, shp in shapes.items():
+        if k.startswith("decision_net"):
+            sd[k] = torch.from_numpy(syn.synth_array("maa." + k, shp, seed, 0.6 if k.endswith("weight") else 0.3))
+    sd.update(threshold=torch.tensor([0.5]), running_mean=torch.tensor(0.8), running_var=torch.tensor(0.09),
+              num_updates=torch.tensor(0))
+    return sd
+
+
+def test_g13_routing_maa_and_vq():
+    """the oracle's MetacognitiveArbitrationAgent / VectorQuantizer vs the reference's outputs and autograd
+    gradients (eval, and train() with its running-statistics update)."""
+    g = gold("g13_routing")
+    sigma = torch.from_numpy(g["sigma"])
+    sd = _maa_sd()
+    r, _ = orc.maa_forward(sd, sigma)
+    for k in ("probs", "logits", "confidence"):
+        assert maxerr(r[k], g["eval." + k]) < 2e-5, k
+    assert np.array_equal(r["decisions"].numpy(), g["eval.decisions"])
+    ref = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+    sg = sigma.clone().requires_grad_(True)
+    r, (rm, rv, nu) = orc.maa_forward(ref, sg, training=True)
+    cl = torch.from_numpy(syn.synth_array("g13_cl", tuple(r["logits"].shape), 132))
+    cp_ = torch.from_numpy(syn.synth_array("g13_cp", tuple(r["probs"].shape), 133))
+    cc = torch.from_numpy(syn.synth_array("g13_cc", tuple(r["confidence"].shape), 134))
+    ((r["logits"] * cl).sum() + (r["probs"] * cp_).sum() + (r["confidence"] * cc).sum() + 3.0 * r["threshold"].sum()).backward()
+    for k in ("probs", "logits", "confidence"):
+        assert maxerr(r[k].detach(), g["train." + k]) < 2e-5, k
+    assert abs(float(rm) - float(g["train_running_mean"])) < 1e-6 and abs(float(rv) - float(g["train_running_var"])) < 1e-6
+    assert int(nu) == int(g["train_num_updates"])
+    assert maxerr(sg.grad, g["train_dsigma"]) < 1e-4 * float(np.abs(g["train_dsigma"]).max())
+    for k in ref:
+        if ref[k].dtype.is_floating_point and "running" not in k:
+            e = g["train.grad." + k]
+            assert maxerr(ref[k].grad, e) < 1e-4 * float(np.abs(e).max()) + 1e-6, k
+    x = torch.from_numpy(g["vq_x"]).requires_grad_(True)
+    cen = torch.tensor([0.07, 0.46, 0.93], requires_grad=True)
+    q, idx, loss = orc.vq_forward(cen, x)
+    cq = torch.from_numpy(syn.synth_array("g13_cq", tuple(q.shape), 136))
+    ((q * cq).sum() + 1.7 * loss).backward()
+    assert maxerr(q.detach(), g["vq_q"]) == 0 and np.array_equal(idx.numpy(), g["vq_idx"])
+    assert abs(float(loss) - float(g["vq_loss"])) < 1e-8
+    assert maxerr(x.grad, g["vq_dx"]) < 1e-6 and maxerr(cen.grad, g["vq_dcentroids"]) < 1e-7
