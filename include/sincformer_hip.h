@@ -136,6 +136,10 @@ int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, i
  * output (glue G1 applied to agents/perception.py:244-246 without materialising the full-rate normalised tensor) */
 int sfm_pool_time_affine(const float* src, const float* scale, const float* shift, void* dst16, float* dst32, int B,
                          int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype, void* stream);
+/* mean over time (glue G2: episodic-memory key), src fp32 [B, T, ld_src] cols [0, C) -> dst fp32 [B, C]; deterministic
+ * two-pass sum, scratch: sfm_mean_time_scratch_floats floats */
+long long sfm_mean_time_scratch_floats(int B, int T, int C);
+int sfm_mean_time(const float* src, float* dst, float* scratch, int B, int T, int C, long long ld_src, void* stream);
 /* adjoint of sfm_pool_time (training: gradient of the pooled latents back to the full-rate latents), fp32 */
 int sfm_pool_time_bwd(const float* dout, float* dsrc, int B, int Tin, int Tout, int C, long long ld_dout,
                       long long ld_dsrc, void* stream);

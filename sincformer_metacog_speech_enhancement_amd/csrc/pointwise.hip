@@ -545,6 +545,42 @@ extern "C" int sfm_pool_time_bwd(const float* dout, float* dsrc, int B, int Tin,
   return SFM_OK;
 }
 
+// mean over time (glue G2: the episodic-memory key is the mean latent of the utterance): src fp32 [B, T, ld] cols [0, C) ->
+// dst fp32 [B, C].  Two deterministic passes: 64-row partial sums, then their sum in a fixed order (a single workgroup per
+// (utterance, 256 channels) walking all T rows is latency-bound: 3.4 ms at T 6001).
+__global__ __launch_bounds__(256) void mean_time_partial_kernel(const float* __restrict__ src, float* __restrict__ part, int T, int C,
+                                                                long long ld, int nchunk) {
+  const int b = blockIdx.z, k = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int t0 = k * 64, t1 = min(T, t0 + 64);
+  float acc = 0.f;
+  for (int t = t0; t < t1; ++t) acc += src[((long long)b * T + t) * ld + c];
+  part[((long long)b * nchunk + k) * C + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void mean_time_final_kernel(const float* __restrict__ part, float* __restrict__ dst, int T, int C,
+                                                              int nchunk) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int k = 0; k < nchunk; ++k) acc += part[((long long)b * nchunk + k) * C + c];
+  dst[(long long)b * C + c] = acc / (float)T;
+}
+
+extern "C" long long sfm_mean_time_scratch_floats(int B, int T, int C) { return (long long)B * ((T + 63) / 64) * C; }
+
+extern "C" int sfm_mean_time(const float* src, float* dst, float* scratch, int B, int T, int C, long long ld_src, void* stream) {
+  if (!src || !dst || !scratch) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || C <= 0 || B > 65535) return SFM_ERR_SHAPE;
+  const int nchunk = (T + 63) / 64;
+  SFM_LAUNCH(mean_time_partial_kernel, dim3((C + 255) / 256, nchunk, B), dim3(256), 0, (hipStream_t)stream, src, scratch, T, C, ld_src,
+             nchunk);
+  SFM_LAUNCH(mean_time_final_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scratch, dst, T, C, nchunk);
+  return SFM_OK;
+}
+
 // log1p-magnitude normalisation of the noisy STFT (agents/msa.py:134-137) written as
 // 16-bit into the fusion operand: cols [0,F) real, [F,2F) imag, [2F, 2F+zpad) zero.
 template <class T>

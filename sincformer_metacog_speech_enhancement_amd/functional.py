@@ -525,7 +525,6 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     zsrc, zsc, zsh = (zcat, None, None) if want_lat else zcat
     Tpa = zsrc.shape[1]
     fused = torch.empty(M, FUSE_LD, device=dev, dtype=dt)
-    zpool = torch.empty(B, T, 2 * D, device=dev, dtype=torch.float32) if use_memory else None
     ops.pool_time(zsrc, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD, scale=zsc, shift=zsh)   # G1 -> fused[:, :2D]
     oc4 = 4 * packs["cpea"]["oc"]
     cpea_forward(fused, packs["cpea"], B, T, out=fused[:, 2 * D:2 * D + oc4])   # CPEA(z_real pooled) -> fused cols
@@ -535,11 +534,10 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     bias = None
     out = {}
     if use_memory:
-        ops.pool_time(zsrc, None, zpool, B, Tpa, T, 2 * D, 2 * D, 2 * D, scale=zsc, shift=zsh)
-        emb = torch.empty(B, 1, 2 * D, device=dev, dtype=torch.float32)
-        ops.pool_time(zpool, None, emb, B, T, 1, 2 * D, 2 * D, 2 * D)   # G2: key = mean over frames
         params, kd, vd, slots, temp = packs["memory"]
-        emb_r = emb.reshape(B, 2 * D)[:, :kd].contiguous()
+        zpool = torch.empty(B, T, kd, device=dev, dtype=torch.float32)  # fp32 pooled z_real columns the key is made of
+        ops.pool_time(zsrc, None, zpool, B, Tpa, T, kd, 2 * D, kd, scale=zsc[:, :kd].contiguous(), shift=zsh[:, :kd].contiguous())
+        emb_r = ops.mean_time(zpool, B, T, kd, kd)                      # G2: key = mean over frames
         bias, gate, top, sim = ops.memory_fwd(emb_r, params, kd, vd, slots, temp)
         out.update(mem_bias=bias, mem_gate=gate, mem_top=top, mem_sim=sim)
     lm, lp = msa_logits(fused, packs["msa"], B, T, H)

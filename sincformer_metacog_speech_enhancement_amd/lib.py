@@ -42,6 +42,8 @@ SIGNATURES = {
     "sfm_convert_rows": [c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_transpose": [c_vp, c_vp, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_vp],
     "sfm_pool_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
+    "sfm_mean_time_scratch_floats": [c_i, c_i, c_i],
+    "sfm_mean_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_vp],
     "sfm_pool_time_bwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_vp],
     "sfm_pool_time_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_stft_lognorm_pack": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_i, c_vp],

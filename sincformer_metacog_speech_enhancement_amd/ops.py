@@ -404,6 +404,15 @@ def transpose(src, dst, B, R, C, src_batch, src_row, dst_batch, dst_row):
           *_cost_of("transpose", locals()))
 
 
+def mean_time(src32, B, T, C, ld_src):
+    """mean over time of fp32 [B, T, ld_src] cols [0, C) -> [B, C] (glue G2)"""
+    L = _lib.load()
+    out = torch.empty(B, C, device=src32.device, dtype=torch.float32)
+    scratch = torch.empty(int(L.sfm_mean_time_scratch_floats(B, T, C)), device=src32.device, dtype=torch.float32)
+    _call("pool_time", L.sfm_mean_time, (_p(src32), _p(out), _p(scratch), B, T, C, ld_src, _stream()), 0.0, 4.0 * B * T * C)
+    return out
+
+
 def pool_time_bwd(dout32, B, Tin, Tout, C):
     """adjoint of pool_time: dout fp32 [B, Tout, C] -> dsrc fp32 [B, Tin, C]"""
     L = _lib.load()
