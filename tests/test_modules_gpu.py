@@ -342,3 +342,18 @@ def test_hipgraph_replay_equals_eager(pkg):
         for k in ("mask_real", "mask_imag", "enhanced"):
             assert torch.equal(out[k], eager[k]), k
     assert len(graphed._cache) == 2
+
+
+def test_empty_batch_is_a_loud_error():
+    """no silent empty results: a zero-length batch or a zero-length waveform is refused by the entry points' shape checks"""
+    from sincformer_metacog_speech_enhancement_amd.models.conformer import ConformerBlock
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    blk = ConformerBlock(256, 4, 1024, 31, 0.1).cuda().eval()
+    with torch.no_grad():
+        with pytest.raises((RuntimeError, ValueError)):
+            blk(torch.zeros(0, 16, 256, device="cuda"))
+        path = EnhancementPath(sample_rate=16000).cuda().eval()
+        with pytest.raises((RuntimeError, ValueError)):
+            path(torch.zeros(0, 1600, device="cuda"))
+        with pytest.raises((RuntimeError, ValueError)):
+            path(torch.zeros(2, 0, device="cuda"))
