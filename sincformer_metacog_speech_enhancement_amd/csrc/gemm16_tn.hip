@@ -175,6 +175,127 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
   }
 }
 
+// Wide form: 256 (n) x 256 (k) output tile on 16 waves (4 x 4, each wave the same 64 x 64 tile and fragment reads as
+// above), plain row-major operands with N % 256 == 0 and K % 256 == 0.  Per 64-row step a workgroup stages 64 KB for 8.4 MFLOP
+// (7.8 B per kFLOP of the L2 -> LDS operand stream instead of 15.6).  LDS: four [64][128] sub-tiles per operand pair
+// (G0, G1, X0, X1), each with the 320-byte rows of the narrow kernel = 80 KB, one workgroup per CU.
+template <class T>
+__global__ __launch_bounds__(1024) void gemm16_tn_wide_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
+                                                              float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                              int K, int ldg, int ldx, int ldw, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) u16 tn_smem[];
+  u16* Gs = tn_smem;                                   // [2][64][TN_ROW]
+  u16* Xs = tn_smem + 2 * 64 * TN_ROW;                 // [2][64][TN_ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 2, wk = wave & 3;             // 64-column block of the wave inside the 256 x 256 tile
+  int bx, by, bz;
+  {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bx = id % gridDim.x;
+    const int rest = id / gridDim.x;
+    by = rest % gridDim.y;
+    bz = rest / gridDim.y;
+  }
+  const int n0 = bx * 256, k0 = by * 256;
+  const int m_begin = bz * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: 64 rows x 32 chunks (16 B) per operand -> 2 chunks per thread per operand
+  int srow[2], scol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 1024 * i;
+    srow[i] = c >> 5;
+    scol[i] = (c & 31) * 8;
+  }
+  u32x4 rg[2], rx[2];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mt + srow[i];
+      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+      if (m < m_end) {
+        a = *reinterpret_cast<const u32x4*>(G + (long long)m * ldg + n0 + scol[i]);
+        b = *reinterpret_cast<const u32x4*>(X + (long long)m * ldx + k0 + scol[i]);
+      }
+      rg[i] = a;
+      rx[i] = b;
+    }
+  };
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  const int trow = 4 * (g16 >> 1) + qq;
+  const int tcol = (g16 & 1) * 16 + 4 * pp;
+  const bool do_bias = (db != nullptr) && (by == 0);
+  float bsum = 0.f;
+  const u16* Gw = Gs + (wn >> 1) * 64 * TN_ROW + (wn & 1) * 64;   // the wave's 64 columns inside its 128-column sub-tile
+  const u16* Xw = Xs + (wk >> 1) * 64 * TN_ROW + (wk & 1) * 64;
+  load_tile(m_begin);
+  for (int mt = m_begin; mt < m_end; mt += 64) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sub = scol[i] >> 7, col = scol[i] & 127;
+      *reinterpret_cast<u32x4*>(&Gs[sub * 64 * TN_ROW + srow[i] * TN_ROW + col]) = rg[i];
+      *reinterpret_cast<u32x4*>(&Xs[sub * 64 * TN_ROW + srow[i] * TN_ROW + col]) = rx[i];
+    }
+    __syncthreads();
+    if (mt + 64 < m_end) load_tile(mt + 64);
+    if (do_bias && tid < 256) {                              // thread = column of the 256-column G tile: 64 rows
+      const u16* col = Gs + (tid >> 7) * 64 * TN_ROW + (tid & 127);
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) bsum += T::to_f32(col[r * TN_ROW]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u16* base = &Gw[(16 * s + trow) * TN_ROW + i * 32 + tcol];
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 8 * TN_ROW));
+        const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
+        fa[i] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u16* base = &Xw[(16 * s + trow) * TN_ROW + j * 32 + tcol];
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 8 * TN_ROW));
+        const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
+        fb[j] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + mfma_row(r, lane);
+        atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+      }
+    }
+  if (do_bias && tid < 256) atomicAdd(&db[n0 + tid], bsum);
+}
+
 // out[n] += sum_m G[m, n]   (bias gradient); G fp32 or 16-bit
 template <class T>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, float* __restrict__ out, int M, int N,
@@ -239,6 +360,33 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
                             int dtype, void* stream, TnConv cv) {
   if (!G || !X || !dW) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (cv.Lout == 0 && (ldx % 8) != 0)) return SFM_ERR_SHAPE;
+  static const int wide_on = getenv("SFM_TN_WIDE") ? atoi(getenv("SFM_TN_WIDE")) : 1;          // A/B knob
+  if (wide_on && cv.Lout == 0 && cv.toeplitz == 0 && (N % 256) == 0 && (K % 256) == 0 && M >= 8192) {
+    const int tiles_w = (N / 256) * (K / 256);
+    int splits = 256 / tiles_w;                                // one 16-wave workgroup per CU: one full round
+    if (splits < 1) splits = 1;
+    const int max_splits = (M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    int rows = (M + splits - 1) / splits;
+    rows = (rows + 63) / 64 * 64;
+    splits = (M + rows - 1) / rows;
+    dim3 grid(N / 256, K / 256, splits), block(1024);
+    const size_t lds = 4 * 64 * TN_ROW * sizeof(u16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)gemm16_tn_wide_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm16_tn_wide_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SFM_ERR_LAUNCH;
+      attr_set = true;
+    }
+    if (dtype == SFM_DT_F16)
+      SFM_LAUNCH((gemm16_tn_wide_kernel<F16>), grid, block, lds, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
+                 ldg, ldx, ldw, rows);
+    else
+      SFM_LAUNCH((gemm16_tn_wide_kernel<BF16>), grid, block, lds, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
+                 ldg, ldx, ldw, rows);
+    return SFM_OK;
+  }
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // 142 registers -> 3 workgroups per CU: aim at ONE full round of 768 resident workgroups (1024 was 1.3 rounds: the
   // second round ran on a third of the chip)

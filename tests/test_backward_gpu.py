@@ -302,3 +302,20 @@ def test_pool_time_adjoint(Tin, Tout):
     (y * cot.cuda()).sum().backward()
     assert maxerr(y.detach().cpu(), yr.detach()) < 1e-6
     assert maxerr(xg.grad.cpu(), xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (20001, 512, 256), (9000, 256, 1024)])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_weight_gradient_gemm_wide_tiles(ops, dt, M, N, K):
+    """dW[n,k] += sum_m G[m,n] X[m,k] and the fused bias gradient on the 256 x 256-tile kernel (N, K multiples of 256,
+    M >= 8192), incl. a ragged M and accumulation into a non-zero dW, vs fp64"""
+    ops.set_compute_dtype(dt)
+    G = q16(arr("wg", (M, N), 700 + N, 0.5), dt)
+    X = q16(arr("wx", (M, K), 701 + K, 0.5), dt)
+    init = arr("wi", (N, K), 702)
+    dW = init.clone().cuda()
+    db = torch.zeros(N, device="cuda")
+    ops.gemm16_tn(G.cuda().to(dt), X.cuda().to(dt), dW, db)
+    ref = init.double() + G.double().t() @ X.double()
+    assert maxerr(dW.cpu(), ref) < 2e-4 * float(ref.abs().max())
+    assert maxerr(db.cpu(), G.double().sum(0)) < 2e-4 * float(G.double().sum(0).abs().max())

@@ -37,6 +37,12 @@ def main():
         X = torch.randn(M, K, device="cuda").bfloat16()
         dW = torch.zeros(N, K, device="cuda")
         db = torch.zeros(N, device="cuda")
+        dW.zero_(); db.zero_()
+        ops.gemm16_tn(G, X, dW, db)
+        ref = G.float().t() @ X.float()
+        err = float((dW - ref).abs().max() / ref.abs().max())
+        berr = float((db - G.float().sum(0)).abs().max() / G.float().sum(0).abs().max())
+        assert err < 2e-3 and berr < 2e-3, (M, N, K, err, berr)
         ms = timeit(lambda: ops.gemm16_tn(G, X, dW, db))
         print("tn M%-7d N%-5d K%-5d %7.3f ms %7.1f TF/s  %6.0f GB/s (unique bytes)" %
               (M, N, K, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * (N + K) / ms / 1e6))
