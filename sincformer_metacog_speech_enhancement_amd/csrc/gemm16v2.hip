@@ -21,6 +21,8 @@
 #define EPI_TANH_SCALE 6
 #define EPI_SIGMA 7
 #define EPI_CPEA 8
+#define EPI_SWISH_DUAL 9     // training forward of an FFN's first Linear: out2 = z (16-bit pre-activation), out = drop * swish(z)
+#define EPI_SWISH_BWD 10     // training backward: out = v * drop * swish'(aux), aux = the saved 16-bit pre-activation
 
 struct Gemm2Params {
   const u16* A;
@@ -35,8 +37,10 @@ struct Gemm2Params {
   float alpha;
   int epi, out_f32, gn_group, nsplit;
   int nMt, nNt, a_records, w_records, vec_ok, gn_slots;
-  float p_drop;                                   // EPI_RESID only: out = resid + alpha * keep(m*N + n) * v  (training)
+  float p_drop;                                   // EPI_RESID: out = resid + alpha * keep(m*N + n) * v; EPI_SWISH_*: hidden dropout
   unsigned int seed;
+  const u16* aux;                                 // EPI_SWISH_BWD: saved pre-activation, layout of `out`
+  u16* out2;                                      // EPI_SWISH_DUAL: second output (pre-activation), layout of `out`
 };
 
 template <int N>
@@ -426,7 +430,38 @@ __device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32
           break;
         default: break;
       }
-      if (mok) {
+      if (mok && (p.epi == EPI_SWISH_DUAL || p.epi == EPI_SWISH_BWD)) {
+        // fused Swish of the FFN (training): vector path only (the launcher guarantees N % 8 == 0, aligned rows, 16-bit out)
+        const long long orow = obase + (long long)m * p.ldo + ncol0;
+        if (ncol0 + 8 <= p.N) {
+          float zz[8];
+          u32x4 pz;
+          if (p.epi == EPI_SWISH_DUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pz[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(p.out2 + orow) = pz;
+          } else {
+            pz = *reinterpret_cast<const u32x4*>(p.aux + orow);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {                     // forward and backward both see the ROUNDED pre-activation
+            zz[2 * e] = T::to_f32((u16)(pz[e] & 0xffffu));
+            zz[2 * e + 1] = T::to_f32((u16)(pz[e] >> 16));
+          }
+          const float ik = (p.p_drop > 0.f) ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+          const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dr = (p.p_drop > 0.f) ? sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik) : 1.0f;
+            const float sg = sigmoid_f(zz[e]);
+            v[e] = (p.epi == EPI_SWISH_DUAL) ? zz[e] * sg * dr : v[e] * dr * sg * (1.0f + zz[e] * (1.0f - sg));
+          }
+          u32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
+        }
+      } else if (mok) {
         const long long orow = obase + (long long)m * p.ldo + ncol0;
         if (p.vec_ok && ncol0 + 8 <= p.N) {
           if (p.epi == EPI_RESID) {
@@ -793,20 +828,29 @@ extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, vo
 // 6 = persistent 2-stage kernel (tile loop inside the workgroup, next tile prefetched under the epilogue)
 // sfm_gemm16_train = sfm_gemm16_ex + residual-branch dropout in the EPI_RESID epilogue (training forward):
 // out = resid + alpha * keep(seed, m*N + n) / (1 - p_drop) * (A W^T + bias)
-extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out, const float* resid,
-                                float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
-                                long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
-                                int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
-                                int nsplit, int dtype, int variant, float p_drop, unsigned int seed, void* stream) {
+static int gemm16_impl(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                       float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                       long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                       int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                       int nsplit, int dtype, int variant, float p_drop, unsigned int seed, const void* aux, void* out2,
+                       void* stream) {
   if (!A || !W || !out) return SFM_ERR_ARG;
-  if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && epi != EPI_RESID)) return SFM_ERR_SHAPE;
+  const bool swish = (epi == EPI_SWISH_DUAL || epi == EPI_SWISH_BWD);
+  if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && epi != EPI_RESID && !swish)) return SFM_ERR_SHAPE;
+  if (swish) {                                         // strip-epilogue kernels only; 16-bit, 16-byte aligned row vectors
+    if ((epi == EPI_SWISH_DUAL && !out2) || (epi == EPI_SWISH_BWD && !aux)) return SFM_ERR_ARG;
+    if (out_f32 || (N % 8) != 0 || (ldo % 8) != 0 || (o_batch_stride % 8) != 0 || gn_partial) return SFM_ERR_SHAPE;
+    if ((((uintptr_t)out) % 16) != 0 || (out2 && (((uintptr_t)out2) % 16) != 0) || (aux && (((uintptr_t)aux) % 16) != 0))
+      return SFM_ERR_SHAPE;
+    if (variant == 1 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 8) variant = 0;
+  }
   if (B <= 0 || Lout <= 0 || N <= 0) return SFM_ERR_SHAPE;
   const long long a_rec = ((long long)(Lin - 1) * lda + Cin) * 2;
   const long long w_rec = (long long)Npad * Kpad * 2;
   const bool v2_ok = (Kpad % 64 == 0) && (Npad % 64 == 0) && a_rec < (1LL << 31) && w_rec < (1LL << 31) &&
                      (!gn_partial || gn_group == 8 || gn_group == 16 || gn_group == 32) &&
                      ((long long)Lout * stride * lda * 2 < (1LL << 31)) && (epi != EPI_GLU || Npad % 128 == 0);
-  if ((variant == 1 || !v2_ok) && p_drop > 0.f) return SFM_ERR_SHAPE;
+  if ((variant == 1 || !v2_ok) && (p_drop > 0.f || swish)) return SFM_ERR_SHAPE;
   if (variant == 1 || !v2_ok)
     return sfm_gemm16_v1(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
                          Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
@@ -829,6 +873,7 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   p.B = B; p.Lout = Lout; p.Lin = Lin; p.Cin = Cin; p.lda = lda; p.stride = stride; p.pad = pad; p.cin_shift = shift;
   p.K = K; p.Kpad = Kpad; p.N = N; p.Npad = Npad; p.ldo = ldo; p.ldr = ldr; p.alpha = alpha; p.epi = epi;
   p.out_f32 = out_f32; p.gn_group = gn_group; p.nsplit = nsplit; p.p_drop = p_drop; p.seed = seed;
+  p.aux = (const u16*)aux; p.out2 = (u16*)out2;
   p.a_records = (int)a_rec; p.w_records = (int)w_rec;
   const int osz = out_f32 ? 4 : 2;
   const bool o_al = (((uintptr_t)out) % 16 == 0) && ((ldo * osz) % 16 == 0) && ((o_batch_stride * osz) % 16 == 0);
@@ -858,7 +903,7 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   const bool s3 = (variant == 3 || variant == 5 || variant == 7);
   // the persistent kernel is 5-20 % faster than variant 2 on isolated launches of the path's skinny GEMMs
   // (tools/gemm_bench.py) but 2 % slower inside the forward pass (bench.py, same box, A/B/A/B): not the default
-  const bool persistent = (variant == 6);
+  const bool persistent = (variant == 6) || (swish && !wide && !tall);   // the fused-Swish modes live in the strip epilogue
 #define GO(TT)                                                                                            \
   if (tall) return launch_w<TT, 512, 128, 16>(p, st);                                                   \
   if (wide) return wide256 ? launch_w<TT, 256, 256, 16>(p, st) : launch_w<TT, 256, 128, 8>(p, st);      \
@@ -870,6 +915,27 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
   if (dtype == SFM_DT_F16) { GO(F16) }
 #undef GO
   return SFM_ERR_ARG;
+}
+
+extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                                float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
+                                long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
+                                int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
+                                int nsplit, int dtype, int variant, float p_drop, unsigned int seed, void* stream) {
+  if (epi == EPI_SWISH_DUAL || epi == EPI_SWISH_BWD) return SFM_ERR_ARG;       // those need sfm_gemm16_swish
+  return gemm16_impl(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride, Kpad, N,
+                     Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit, dtype, variant,
+                     p_drop, seed, nullptr, nullptr, stream);
+}
+
+// Linear with the FFN's Swish (+ hidden dropout) fused into the epilogue (training; models/conformer.py:44-46 and its backward):
+//   backward == 0: out2 [M, N] 16-bit = z = A W^T + bias (saved for the backward), out 16-bit = keep/(1-p) * swish(z)
+//   backward != 0: out 16-bit = (A W^T) * keep/(1-p) * swish'(aux),  aux = the saved z          (counters: m * N + n, as sfm_ew_train)
+extern "C" int sfm_gemm16_swish(const void* A, const void* W, const float* bias, void* out, const void* aux, void* out2, int M,
+                                int Cin, int lda, int Kpad, int N, int Npad, int ldo, int backward, float p_drop,
+                                unsigned int seed, int dtype, void* stream) {
+  return gemm16_impl(A, W, bias, out, nullptr, nullptr, 1, M, M, Cin, lda, 1, 1, 0, 0, Kpad, N, Npad, ldo, 0, 0, 0, 1.0f,
+                     backward ? EPI_SWISH_BWD : EPI_SWISH_DUAL, 0, 0, 0, dtype, 0, p_drop, seed, aux, out2, stream);
 }
 
 extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "sfm_sinc_shift_len": [c_i],
     "sfm_sinc_shift_pack": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "sfm_sinc_wgrad16": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_gemm16_swish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_i, c_vp],
     "sfm_gn_bwd_reduce": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i,
                           c_i, c_i, c_i, c_vp],
     "sfm_gn_bwd_coefs": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],

@@ -268,6 +268,22 @@ def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=N
     return out
 
 
+def linear16_swish(x16, pw, p_drop=0.0, seed=0, aux=None):
+    """FFN Linear with the Swish (+ hidden dropout) in the GEMM epilogue (training).
+    aux is None: forward -> (z [M, N] 16-bit pre-activation, u = drop * swish(z));  aux = saved z: backward -> g * drop * swish'(z)
+    where g = x16 @ W^T (pw = the transposed pack, no bias)."""
+    L = _lib.load()
+    M, ld = x16.shape[0], x16.stride(0)
+    dt = _state["dtype"]
+    out = torch.empty(M, pw.N, device=x16.device, dtype=dt)
+    out2 = torch.empty(M, pw.N, device=x16.device, dtype=dt) if aux is None else None
+    _call("gemm16", L.sfm_gemm16_swish, (_p(x16), _p(pw.w), _p(pw.bias), _p(out), _p(aux), _p(out2), M, pw.cin, ld, pw.Kpad, pw.N,
+                                         pw.Npad, pw.N, 0 if aux is None else 1, float(p_drop), int(seed) & 0xffffffff, _dt(),
+                                         _stream()), 2.0 * M * pw.N * pw.K, M * (pw.cin + 2.0 * pw.N) * 2.0 + pw.Npad * pw.Kpad * 2.0,
+          tag="M%d N%d K%d swish%s" % (M, pw.N, pw.K, "" if aux is None else "_bwd"))
+    return (out2, out) if aux is None else out
+
+
 def framed_gemm(sig, Wt, out, *, B, M, Ls, sig_batch_stride, hop, padl, K, N, o_batch_stride, ldm, ldn, mode=0,
                 bias=None, out2=None, nsplit=0, gn_partial=None, gn_group=0):
     _need_dev(sig, Wt, out)

@@ -9,6 +9,7 @@ bit-identical: SURVEY H5); with p = 0 the gradients match torch autograd of the 
 compute dtype where they feed the matrix cores.
 """
 import math
+import os
 import torch
 
 from . import ops
@@ -61,6 +62,9 @@ class _Seeds:
 # ---------------------------------------------------------------------------
 # FeedForwardModule (models/conformer.py:41-49)
 # ---------------------------------------------------------------------------
+FUSE_FFN_SWISH = os.environ.get("SFM_FUSE_FFN_SWISH", "1") != "0"     # Swish (+ hidden dropout) of the FFN in the epilogues of its GEMMs (forward: dual output; backward)
+
+
 def _ffn_fwd(x, P, pre, p, seeds):
     dt = ops.compute_dtype()
     M, D = x.shape
@@ -68,10 +72,13 @@ def _ffn_fwd(x, P, pre, p, seeds):
     f1, b1 = _lin_pack(_f32(P[pre + "linear1.weight"]), _f32(P[pre + "linear1.bias"]))
     f2, b2 = _lin_pack(_f32(P[pre + "linear2.weight"]), _f32(P[pre + "linear2.bias"]))
     h16 = _ln16(x, lw, lb)
-    z1 = ops.linear16(h16, f1)                                            # [M, FF] 16-bit pre-activation
     s1, s2 = seeds.next(), seeds.next()
-    u = torch.empty_like(z1)
-    ops.ew_train(ops.EW_SWISH_FWD, u, z=z1, p=p, seed=s1)
+    if FUSE_FFN_SWISH and f1.N % 8 == 0:
+        z1, u = ops.linear16_swish(h16, f1, p_drop=p, seed=s1)            # pre-activation + dropout(swish) from one epilogue
+    else:
+        z1 = ops.linear16(h16, f1)                                        # [M, FF] 16-bit pre-activation
+        u = torch.empty_like(z1)
+        ops.ew_train(ops.EW_SWISH_FWD, u, z=z1, p=p, seed=s1)
     y = _resid_gemm(u, f2, x, 0.5, p, s2)                                 # x + 0.5 * dropout(linear2(u)), one launch
     return y, dict(x=x, lw=lw, h16=h16, z1=z1, u=u, b1=b1, b2=b2, s1=s1, s2=s2, p=p)
 
@@ -83,9 +90,12 @@ def _ffn_bwd(dy, c, G, pre):
     do = torch.empty(M, D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=0.5, p=c["p"], seed=c["s2"])
     ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"], G[pre + "linear2.bias"])
-    du = ops.linear16(do, c["b2"], out_dtype=torch.float32)                 # [M, FF]
-    dz = torch.empty(M, FF, device=dy.device, dtype=dt)
-    ops.ew_train(ops.EW_SWISH_BWD, dz, z=c["z1"], g=du, p=c["p"], seed=c["s1"])
+    if FUSE_FFN_SWISH and FF % 8 == 0:
+        dz = ops.linear16_swish(do, c["b2"], p_drop=c["p"], seed=c["s1"], aux=c["z1"])   # (do W2) * drop * swish'(z1): one launch
+    else:
+        du = ops.linear16(do, c["b2"], out_dtype=torch.float32)             # [M, FF]
+        dz = torch.empty(M, FF, device=dy.device, dtype=dt)
+        ops.ew_train(ops.EW_SWISH_BWD, dz, z=c["z1"], g=du, p=c["p"], seed=c["s1"])
     ops.gemm16_tn(dz, c["h16"], G[pre + "linear1.weight"], G[pre + "linear1.bias"])
     dh = ops.linear16(dz, c["b1"], out_dtype=torch.float32)                 # [M, D]
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G[pre + "layer_norm.weight"], G[pre + "layer_norm.bias"])
