@@ -357,3 +357,31 @@ def test_empty_batch_is_a_loud_error():
             path(torch.zeros(0, 1600, device="cuda"))
         with pytest.raises((RuntimeError, ValueError)):
             path(torch.zeros(2, 0, device="cuda"))
+
+
+def test_two_passes_in_flight_equal_sequential_passes():
+    """bench.py keeps two forward passes in flight on two HIP streams: the results must be those of strictly sequential
+    passes, bit for bit (no shared scratch between passes)"""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    ops.set_compute_dtype(torch.bfloat16)
+    path = EnhancementPath(sample_rate=16000, use_memory=True)
+    sds = {"perception": synth_sd("PerceptionAgent", 991, sinc_scale=2000.0), "cpea": synth_sd("CorrelationPhaseEstimationAgent", 992),
+           "msa": synth_sd("MaskSynthesisAgent", 993), "memory": synth_sd("EpisodicMemory", 994)}
+    for n, sd in sds.items():
+        getattr(path, n).load_state_dict(sd)
+    path = path.cuda().eval()
+    waves = [torch.from_numpy(syn.synth_wave(3, 6400 + 160 * i, 995 + i)[0]).cuda() for i in range(6)]
+    with torch.no_grad():
+        ref = [path(w) for w in waves]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got = [None] * len(waves)
+        for rep in range(3):
+            for i, w in enumerate(waves):
+                with torch.cuda.stream(streams[i % 2]):
+                    got[i] = path(w)
+        torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        for k in ("mask_real", "mask_imag", "enhanced"):
+            assert torch.equal(r[k], g[k]), k
