@@ -85,3 +85,87 @@ def test_stft_istft_identity_at_full_size(path_and_out):
     spec_e = (re[:, 101] ** 2 + im[:, 101] ** 2)
     full = spec_e[:, 0] + spec_e[:, 128] + 2.0 * spec_e[:, 1:128].sum(-1)
     assert float(((full / 256.0) - (fr ** 2).sum(-1)).abs().max()) < 1e-3
+
+
+def _central_difference_along_gradient(params, objective, eps):
+    """objective() -> scalar tensor with grad; returns (|g|, central-difference slope of the objective along g / |g|)"""
+    total = objective()
+    total.backward()
+    params = [p_ for p_ in params if p_.grad is not None]
+    gnorm = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in params)))
+    assert math.isfinite(gnorm) and gnorm > 0
+    base = [p_.detach().clone() for p_ in params]
+    vals = []
+    for sign in (1.0, -1.0):
+        with torch.no_grad():
+            for p_, b0 in zip(params, base):
+                p_.copy_(b0 + sign * eps * p_.grad / gnorm)
+        vals.append(float(objective().detach()))
+    with torch.no_grad():
+        for p_, b0 in zip(params, base):
+            p_.copy_(b0)
+    return float(total.detach()), gnorm, (vals[0] - vals[1]) / (2 * eps)
+
+
+def test_training_backward_directional_derivative_at_full_size():
+    """BASELINE configs[2] size (B 256 x 4 s, SpeechEnhancer in train() mode), where autograd of the oracle is out of reach:
+    for f(theta) = <cotangent, model(theta)> the HIP backward's gradient g must predict the change of f along its own
+    direction, f(theta + e d) - f(theta - e d) = 2 e |g| with d = g / |g| (dropout off: f is a deterministic function).
+    A fixed cotangent is used instead of the objective because the objective's own gradient (1 / |STFT bin| terms) turns the
+    16-bit rounding noise of the forward into tens of per cent of gradient noise (tools/grad_repro2.py); the objective's
+    backward is checked on identical inputs in tests/test_train_gpu.py."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft
+    ops.set_compute_dtype(torch.float16)
+    Bt, Lt = 256, 64000
+    model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.0)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, 4321).items()})
+    model.cuda().train()
+    noisy, _ = syn.synth_wave(Bt, Lt, 777)
+    nr, ni = batch_stft(torch.from_numpy(noisy).cuda(), 256, 80, 160)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cot_r = torch.randn(nr.shape, device="cuda", generator=g) * 1e-3
+    cot_i = torch.randn(nr.shape, device="cuda", generator=g) * 1e-3
+
+    def objective():
+        er, ei, _ = model(nr, ni)
+        return (er * cot_r).sum() + (ei * cot_i).sum()
+
+    val, gnorm, slope = _central_difference_along_gradient(list(model.parameters()), objective, eps=0.02)
+    print("full-size SpeechEnhancer backward: f %.5f, |g| %.4f, central-difference slope along g %.4f" % (val, gnorm, slope))
+    assert abs(slope - gnorm) < 0.05 * gnorm, (slope, gnorm)
+
+
+def test_path_backward_directional_derivative_at_full_size():
+    """the same check for the whole composition (PerceptionAgent + CPEA + MaskSynthesisAgent) at B 64 x 4 s, cotangent on
+    the enhanced spectrum"""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    ops.set_compute_dtype(torch.float16)
+    path = EnhancementPath(sample_rate=16000)
+    path.perception.load_state_dict(synth_sd("PerceptionAgent", 291, sinc_scale=2000.0))
+    path.cpea.load_state_dict(synth_sd("CorrelationPhaseEstimationAgent", 292))
+    path.msa.load_state_dict(synth_sd("MaskSynthesisAgent", 293))
+    for mod in path.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    path.cpea.lstm.dropout = 0.0
+    path = path.cuda().train()
+    noisy, _ = syn.synth_wave(B, L, 778)
+    wave = torch.from_numpy(noisy).cuda()
+    T = 1 + L // 80
+    g = torch.Generator(device="cuda").manual_seed(6)
+    cot_r = torch.randn(B, T, 129, device="cuda", generator=g) * 1e-3
+    cot_i = torch.randn(B, T, 129, device="cuda", generator=g) * 1e-3
+
+    def objective():
+        out = path(wave, want=("mask", "spectrum"))
+        return (out["enh_real"] * cot_r).sum() + (out["enh_imag"] * cot_i).sum()
+
+    params = [p_ for n, p_ in path.named_parameters() if "uncertainty_head" not in n]
+    val, gnorm, slope = _central_difference_along_gradient(params, objective, eps=0.01)
+    print("full-size path backward: f %.5f, |g| %.4f, central-difference slope along g %.4f" % (val, gnorm, slope))
+    assert abs(slope - gnorm) < 0.05 * gnorm, (slope, gnorm)
