@@ -652,8 +652,64 @@ def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, s
 # ---------------------------------------------------------------------------
 # training path (ConformerBlock backward)
 # ---------------------------------------------------------------------------
+_WGRAD = {"stream": None}
+
+
+class wgrad_side_stream:
+    """inside this context the weight-gradient GEMMs are enqueued on a second HIP stream: they are off the critical path of
+    the backward pass (nothing but the optimiser reads dW), so they fill the CUs the input-gradient chain leaves idle; on
+    exit the current stream waits for them."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and _os.environ.get("SFM_WGRAD_STREAM", "1") != "0"
+
+    def __enter__(self):
+        if self.enabled:
+            if "side" not in _WGRAD:
+                _WGRAD["side"] = torch.cuda.Stream()
+            _WGRAD["stream"] = _WGRAD["side"]
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(_WGRAD["side"])
+            _WGRAD["stream"] = None
+        return False
+
+
+class after_wgrad:
+    """host ops that post-process a weight gradient (e.g. rescaling rows) must run where the GEMM that produces it runs:
+    on the side stream when wgrad_side_stream is active (the listed temporaries are kept alive for it), else in place."""
+
+    def __init__(self, *temporaries):
+        self.ws = _WGRAD["stream"]
+        self.tmp = temporaries
+        self.ctx = None
+
+    def __enter__(self):
+        if self.ws is not None:
+            self.ctx = torch.cuda.stream(self.ws)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ws is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.tmp:
+                t.record_stream(self.ws)
+        return False
+
+
 def gemm16_tn(G16, X16, dW, db=None):
     """dW[n,k] += sum_m G16[m,n] * X16[m,k]   (dW fp32, accumulated); db[n] += sum_m G16[m,n] when given."""
+    ws = _WGRAD["stream"]
+    if ws is not None and torch.cuda.current_stream() != ws:
+        ws.wait_stream(torch.cuda.current_stream())          # operands (and the zero-filled dW) are ready
+        with torch.cuda.stream(ws):
+            gemm16_tn(G16, X16, dW, db)
+        for t in (G16, X16):
+            t.record_stream(ws)                                # the allocator must not hand their memory out before ws is done
+        return
     L = _lib.load()
     M, N = G16.shape
     K = X16.shape[1]
@@ -664,6 +720,14 @@ def gemm16_tn(G16, X16, dW, db=None):
 def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
     """Conv1d weight / bias gradient from dY [B*Lout, N] and the channels-last input x [B, Lin, Cin] (both 16-bit):
     returns dW in torch's Conv1d layout [N, Cin, ksize] and db [N] (fp32)."""
+    ws = _WGRAD["stream"]
+    if ws is not None and torch.cuda.current_stream() != ws:   # off the critical path: see wgrad_side_stream
+        ws.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws):
+            out = conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad)
+        for t in (dy16, x16):
+            t.record_stream(ws)
+        return out
     L = _lib.load()
     buf = torch.zeros(N * ksize * Cin + N, device=x16.device, dtype=torch.float32)       # dW | db: one fill
     dW, db = buf[:N * ksize * Cin].view(N, ksize * Cin), buf[N * ksize * Cin:]
