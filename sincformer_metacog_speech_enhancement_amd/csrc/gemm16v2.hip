@@ -887,6 +887,8 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   // least two tiles per CU: +15..37 % on those shapes, the 256 x 128 form (one 8-wave workgroup per CU) is slower than
   // the default (tools/gemm_bench.py)
   const long long tiles256 = (long long)((Lout + 255) / 256) * (Npad / 256) * B;
+  // (the fused-Swish epilogues also run best on the wide tiles: 52.3 ms per training step against 55.4 ms on the persistent
+  // 128 x 128 kernel, A/B/A/B in one call)
   const bool auto_wide = (variant == 0) && (Npad % 256 == 0) && tiles256 >= 512;
   // 512 x 128 tiles on 16 waves (variant 10; 9.8 B of operand stream per kFLOP): auto for the 128-column GEMMs with a short
   // K (the first PerceptionAgent convs: +11..25 %; with 14 k-tiles the default kernel is already at 700 TF/s and wins)

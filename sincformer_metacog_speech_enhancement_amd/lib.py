@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (device memory / stream plumbing; see ops.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsincformer_hip.so")
+LIB_PATH = os.environ.get("SFM_LIB_PATH") or os.path.join(_HERE, "libsincformer_hip.so")   # override: A/B of two builds
 
 c_vp = ctypes.c_void_p
 c_i = ctypes.c_int
