@@ -13,13 +13,19 @@
 #define RS_ROW 72     // u16 per row, row-read tiles (144 B)
 #define TS_ROW 96     // u16 per row, transposed-read tiles (192 B)
 
-__device__ __forceinline__ uint32_t attn_hash(uint32_t seed, unsigned long long idx) {
-  uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
+// Attention dropout: keep(row, key) = finalise(rowhash(row) + key * golden), rowhash = the full counter hash of the probability
+// row (b, h, q), computed once per row; per score one multiply-add, one xorshift-multiply round and an integer compare
+// (~9 VALU instructions instead of ~16).  The same function in attention.hip (forward) and attention_bwd.hip.
+__device__ __forceinline__ uint32_t attn_row_hash(uint32_t seed, unsigned long long row) {
+  uint32_t x = (uint32_t)row * 0x9E3779B1u ^ (uint32_t)(row >> 32) * 0x85EBCA77u ^ seed;
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float attn_keep(uint32_t seed, unsigned long long idx, float p, float inv_keep) {
-  return ((attn_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+__device__ __forceinline__ uint32_t attn_keep_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }
+__device__ __forceinline__ float attn_keep_rk(uint32_t rowh, int key, uint32_t thr24, float inv_keep) {
+  uint32_t x = rowh + (uint32_t)key * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return ((x >> 8) >= thr24) ? inv_keep : 0.f;
 }
 
 __device__ __forceinline__ u32x4 tr_frag(const u16* tile, int row0, int col0, int lane) {
@@ -90,6 +96,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const u16* __restrict_
   const long long rowid = ((long long)b * H + h) * Tlen + (q < Tlen ? q : 0);
   const float lse_q = (q < Tlen) ? lse[rowid] : 1e30f;
   const float dl_q = (q < Tlen) ? delta[rowid] : 0.f;
+  const uint32_t drop_rowh = attn_row_hash(seed, (unsigned long long)rowid);   // the lane's probability row is fixed
+  const uint32_t drop_thr = attn_keep_threshold(p_drop);
 
   f32x16 dq[2];
 #pragma unroll
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const u16* __restrict_
         const int key = kt * 64 + kj * 32 + mfma_row(r, lane);
         float pv = (key < Tlen) ? __builtin_amdgcn_exp2f(s[kj][r] - lse_q) : 0.f;
         float dpv = dp[kj][r];
-        if (p_drop > 0.f) dpv *= attn_keep(seed, (unsigned long long)rowid * Tlen + key, p_drop, inv_keep);
+        if (p_drop > 0.f) dpv *= attn_keep_rk(drop_rowh, key, drop_thr, inv_keep);
         s[kj][r] = 0.69314718056f * pv * (dpv - dl_q);
       }
 #pragma unroll
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
                                                            int koff, int voff, int nkt, float p_drop, uint32_t seed) {
   __shared__ __attribute__((aligned(16))) u16 smem[2 * 64 * RS_ROW + 2 * 64 * TS_ROW];
   __shared__ float sl[64], sd[64];
+  __shared__ uint32_t srh[64];                         // row hashes of the staged query tile (attention dropout)
   u16* Qr = smem;                               // Q rows   (S  = Q K^T)
   u16* Dr = smem + 64 * RS_ROW;                 // dO rows  (dP = dO V^T)
   u16* Qt = smem + 2 * 64 * RS_ROW;             // Q, transposed-read layout  (dK^T += Q^T dS)
@@ -242,6 +251,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
   const int nqtiles = (Tlen + 63) / 64;
   u32x4 rq[2], rd[2];                                 // next query tile, global -> registers under the current tile's math
   float rl = 1e30f, rdl = 0.f;
+  uint32_t rrh = 0u;
+  const uint32_t drop_thr = DROP ? attn_keep_threshold(p_drop) : 0u;
   auto load_tile = [&](int qt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -258,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
       const int q = qt * 64 + tid;
       rl = (q < Tlen) ? lse[bh * Tlen + q] : 1e30f;             // rows past T get P = 0
       rdl = (q < Tlen) ? delta[bh * Tlen + q] : 0.f;
+      if (DROP) rrh = attn_row_hash(seed, (unsigned long long)(bh * Tlen + (q < Tlen ? q : 0)));
     }
   };
   load_tile(0);
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
     if (tid < 64) {
       sl[tid] = rl;
       sd[tid] = rdl;
+      if (DROP) srh[tid] = rrh;
     }
     __syncthreads();
     if (qt + 1 < nqtiles) load_tile(qt + 1);
@@ -294,10 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
         const int ql = qi * 32 + mfma_row(r, lane);
         const float pv = __builtin_amdgcn_exp2f(s[r] - sl[ql]);
         float keep = 1.0f;
-        if (DROP) {
-          const int q = qt * 64 + ql;
-          keep = attn_keep(seed, (unsigned long long)(bh * Tlen + (q < Tlen ? q : 0)) * Tlen + key, p_drop, inv_keep);
-        }
+        if (DROP) keep = attn_keep_rk(srh[ql], key, drop_thr, inv_keep);
         const float dsv = 0.69314718056f * pv * (dp[r] * keep - sd[ql]);
         s[r] = pv * keep;                // P~ (dropped, rescaled) for dV
         dp[r] = dsv;                     // dS2 for dK
@@ -381,7 +391,8 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const u16* __rest
   const float delta = wave_sum(part);
   const float lse_q = lse[((long long)b * nheads + h) * Tlen + q];
   const float inv_keep = (p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
-  const unsigned long long rowbase = (((unsigned long long)b * nheads + h) * Tlen + q) * Tlen;
+  const uint32_t drop_rowh = attn_row_hash(seed, ((unsigned long long)b * nheads + h) * Tlen + q);
+  const uint32_t drop_thr = attn_keep_threshold(p_drop);
   for (int key = 0; key < Tlen; ++key) {
     const u16* kr = base + (long long)key * ldqkv;
     float kv[4], vv[4];
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const u16* __rest
     }
     const float s2 = wave_sum(ps), dp = wave_sum(pd);
     const float pv = exp2f(s2 - lse_q);
-    const float keep = (p_drop > 0.f) ? attn_keep(seed, rowbase + key, p_drop, inv_keep) : 1.0f;
+    const float keep = (p_drop > 0.f) ? attn_keep_rk(drop_rowh, key, drop_thr, inv_keep) : 1.0f;
     const float ds = 0.69314718056f * pv * (dp * keep - delta);
     float* dkr = dkv32 + ((long long)b * Tlen + key) * (2LL * D) + h * hd;
 #pragma unroll

@@ -652,7 +652,7 @@ def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, s
 # ---------------------------------------------------------------------------
 # training path (ConformerBlock backward)
 # ---------------------------------------------------------------------------
-_WGRAD = {"stream": None}
+_WGRAD = {"stream": None, "keep": []}
 
 
 class wgrad_side_stream:
@@ -674,6 +674,10 @@ class wgrad_side_stream:
         if self.enabled:
             torch.cuda.current_stream().wait_stream(_WGRAD["side"])
             _WGRAD["stream"] = None
+            # operands of the side-stream GEMMs were kept alive until the join is enqueued: whoever reuses their memory on the
+            # main stream now runs after it.  (tensor.record_stream() instead defers the reuse to an event query; with the host
+            # several steps ahead of the GPU the allocator then grows by hipMalloc: sporadic 1 s stalls in bench.py)
+            _WGRAD["keep"].clear()
         return False
 
 
@@ -695,8 +699,7 @@ class after_wgrad:
     def __exit__(self, *exc):
         if self.ws is not None:
             self.ctx.__exit__(*exc)
-            for t in self.tmp:
-                t.record_stream(self.ws)
+            _WGRAD["keep"].extend(self.tmp)
         return False
 
 
@@ -707,8 +710,7 @@ def gemm16_tn(G16, X16, dW, db=None):
         ws.wait_stream(torch.cuda.current_stream())          # operands (and the zero-filled dW) are ready
         with torch.cuda.stream(ws):
             gemm16_tn(G16, X16, dW, db)
-        for t in (G16, X16):
-            t.record_stream(ws)                                # the allocator must not hand their memory out before ws is done
+        _WGRAD["keep"].extend((G16, X16))                      # alive until the join (see wgrad_side_stream.__exit__)
         return
     L = _lib.load()
     M, N = G16.shape
@@ -725,8 +727,7 @@ def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
         ws.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ws):
             out = conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad)
-        for t in (dy16, x16):
-            t.record_stream(ws)
+        _WGRAD["keep"].extend((dy16, x16))
         return out
     L = _lib.load()
     buf = torch.zeros(N * ksize * Cin + N, device=x16.device, dtype=torch.float32)       # dW | db: one fill

@@ -157,16 +157,22 @@ def _attn_ref(qkv, B, T, H, hd, keep=None):
 
 
 def _keep_mask(seed, B, H, T, p):
-    """numpy replica of the counter-based keep function (attention.hip / attention_bwd.hip)"""
-    idx = np.arange(B * H * T * T, dtype=np.uint64)
-    x = ((idx & np.uint64(0xFFFFFFFF)) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
-    x ^= ((idx >> np.uint64(32)) * np.uint64(0x85EBCA77)) & np.uint64(0xFFFFFFFF)
+    """numpy replica of the counter-based keep function (attention.hip / attention_bwd.hip): full hash of the probability row
+    (b, h, q), then one multiply-add + xorshift-multiply round per key"""
+    M32 = np.uint64(0xFFFFFFFF)
+    row = np.arange(B * H * T, dtype=np.uint64)
+    x = ((row & M32) * np.uint64(0x9E3779B1)) & M32
+    x ^= ((row >> np.uint64(32)) * np.uint64(0x85EBCA77)) & M32
     x ^= np.uint64(seed)
-    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
     x ^= x >> np.uint64(16)
-    u = (x >> np.uint64(8)).astype(np.float64) / 16777216.0
-    keep = (u >= p).astype(np.float32) / (1.0 - p)
+    key = np.arange(T, dtype=np.uint64)
+    y = (x[:, None] + ((key * np.uint64(0x9E3779B1)) & M32)[None, :]) & M32
+    y ^= y >> np.uint64(15); y = (y * np.uint64(0x846CA68B)) & M32
+    y ^= y >> np.uint64(16)
+    thr = np.uint64(math.ceil(float(np.float32(p)) * 16777216.0))
+    keep = ((y >> np.uint64(8)) >= thr).astype(np.float32) / (1.0 - p)
     return torch.from_numpy(keep.reshape(B, H, T, T))
 
 
