@@ -299,8 +299,11 @@ def main():
 
     if args.graph:
         from sincformer_metacog_speech_enhancement_amd.graph import GraphedForward
-        graphed = GraphedForward(lambda w: path(w))
-        graphed(wave)                                     # capture outside the timed region
+        # one captured graph (with its own static buffers) per pass in flight: a graph is never replayed concurrently with itself
+        graphs = [GraphedForward(lambda w: path(w)) for _ in range(max(args.streams, 1))]
+        for g_ in graphs:
+            g_(wave)                                      # capture outside the timed region
+        graphed = graphs[0]
 
     # the current (default) stream + S-1 new ones: as few HIP streams as possible, so that they never have to share one of
     # the process's hardware queues (5 streams on 4 queues ran SLOWER than a single stream: 12.9 vs 11.0 ms)
@@ -312,7 +315,7 @@ def main():
             st = streams[counter[0] % len(streams)]
             counter[0] += 1
             with torch.cuda.stream(st):
-                return graphed(wave) if args.graph else path(wave)
+                return graphs[(counter[0] - 1) % len(streams)](wave) if args.graph else path(wave)
         return graphed(wave) if args.graph else path(wave)
 
     def barrier():
