@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void ew_train_vec_kernel(const void* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       gv[i] = 1.0f;
-      dr[i] = (p > 0.f && MODE != 2 && MODE != 3) ? sfm_keep_scale(seed, (unsigned long long)(e0 + i), p, inv_keep) : 1.0f;
+      dr[i] = 1.0f;
     }
+    if (p > 0.f && MODE != 2 && MODE != 3) sfm_keep_scale8(seed, (unsigned long long)e0, p, inv_keep, dr);
     if (g) {
       if (g_f32) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + e0);

@@ -275,8 +275,10 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
         if (p.p_drop > 0.f) {                           // residual-branch dropout, same counters as sfm_ew_train mode 4
           const float ik = 1.0f / (1.0f - p.p_drop);
           const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+float kp[8];
+          sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik);
+          for (int e = 0; e < 8; ++e) v[e] *= kp[e];
         }
         const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
         const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
@@ -450,9 +452,11 @@ __device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32
           }
           const float ik = (p.p_drop > 0.f) ? 1.0f / (1.0f - p.p_drop) : 1.0f;
           const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+          float kp[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+          if (p.p_drop > 0.f) sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float dr = (p.p_drop > 0.f) ? sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik) : 1.0f;
+            const float dr = kp[e];
             const float sg = sigmoid_f(zz[e]);
             v[e] = (p.epi == EPI_SWISH_DUAL) ? zz[e] * sg * dr : v[e] * dr * sg * (1.0f + zz[e] * (1.0f - sg));
           }
@@ -468,8 +472,10 @@ __device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32
             if (p.p_drop > 0.f) {
               const float ik = 1.0f / (1.0f - p.p_drop);
               const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+float kp[8];
+              sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= sfm_keep_scale(p.seed, e0 + e, p.p_drop, ik);
+              for (int e = 0; e < 8; ++e) v[e] *= kp[e];
             }
             const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
             const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);

@@ -78,9 +78,28 @@ __device__ __forceinline__ uint32_t sfm_hash(uint32_t seed, unsigned long long i
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
+// keep(seed, idx): full hash of the 8-element group idx >> 3, then one multiply-add + one xorshift-multiply round per element
+// (the epilogues and ew_train handle 8 consecutive elements per thread: 1 full hash + 8 cheap rounds instead of 8 full hashes).
+__device__ __forceinline__ uint32_t sfm_keep_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }
+__device__ __forceinline__ float sfm_keep_from_group(uint32_t gh, uint32_t j, uint32_t thr24, float inv_keep) {
+  uint32_t x = gh + j * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return ((x >> 8) >= thr24) ? inv_keep : 0.f;
+}
 __device__ __forceinline__ float sfm_keep_scale(uint32_t seed, unsigned long long idx, float p, float inv_keep) {
   // 0 if dropped, 1/(1-p) if kept
-  return ((sfm_hash(seed, idx) >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+  return sfm_keep_from_group(sfm_hash(seed, idx >> 3), (uint32_t)(idx & 7ull), sfm_keep_threshold(p), inv_keep);
+}
+// the same decisions for 8 consecutive elements; one group hash when e0 is a multiple of 8
+__device__ __forceinline__ void sfm_keep_scale8(uint32_t seed, unsigned long long e0, float p, float inv_keep, float (&k)[8]) {
+  if (e0 & 7ull) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = sfm_keep_scale(seed, e0 + i, p, inv_keep);
+    return;
+  }
+  const uint32_t gh = sfm_hash(seed, e0 >> 3), thr = sfm_keep_threshold(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = sfm_keep_from_group(gh, (uint32_t)i, thr, inv_keep);
 }
 
 
