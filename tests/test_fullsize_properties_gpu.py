@@ -169,3 +169,41 @@ def test_path_backward_directional_derivative_at_full_size():
     val, gnorm, slope = _central_difference_along_gradient(params, objective, eps=0.01)
     print("full-size path backward: f %.5f, |g| %.4f, central-difference slope along g %.4f" % (val, gnorm, slope))
     assert abs(slope - gnorm) < 0.05 * gnorm, (slope, gnorm)
+
+
+def test_long_utterances_with_memory_vs_oracle_and_batch_independence():
+    """BASELINE configs[4] sequence length (30 s: L 480 000, T 6001, T_pa 30 000) with the episodic memory: the 64-rows-per-wave
+    attention kernel, 94 key tiles per row, the two-pass memory key.  One utterance against the oracle (fp32 attention over the
+    full 6001 x 6001 score matrix on the CPU), bounds, and independence of the other utterances of the batch."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    ops.set_compute_dtype(torch.float16)
+    Bl, Ll = 3, 480000
+    sds = {"pa": synth_sd("PerceptionAgent", 391, sinc_scale=2000.0), "cpea": synth_sd("CorrelationPhaseEstimationAgent", 392),
+           "msa": synth_sd("MaskSynthesisAgent", 393), "memory": synth_sd("EpisodicMemory", 394)}
+    path = EnhancementPath(sample_rate=16000, use_memory=True)
+    path.perception.load_state_dict(sds["pa"])
+    path.cpea.load_state_dict(sds["cpea"])
+    path.msa.load_state_dict(sds["msa"])
+    path.memory.load_state_dict(sds["memory"])
+    path = path.cuda().eval()
+    noisy, _ = syn.synth_wave(Bl, Ll, 396)
+    wave = torch.from_numpy(noisy).cuda()
+    with torch.no_grad():
+        out = path(wave)
+        one = path(wave[1:2].contiguous())
+    T = 1 + Ll // 80
+    assert tuple(out["mask_real"].shape) == (Bl, T, 129) and tuple(out["enhanced"].shape) == (Bl, Ll)
+    assert all(bool(torch.isfinite(v).all()) for v in out.values() if isinstance(v, torch.Tensor) and v.dtype.is_floating_point)
+    mag = torch.sqrt(out["mask_real"] ** 2 + out["mask_imag"] ** 2)
+    assert float(mag.max()) <= 1.0 + 1e-5
+    for k in ("mask_real", "mask_imag", "enhanced"):
+        assert rmse(one[k].cpu(), out[k][1:2].cpu()) < 2e-5, k
+    ref = orc.enhance_path(sds, noisy[1:2], 16000, use_memory=True)
+    got = torch.cat([out["mask_real"][1:2], out["mask_imag"][1:2]], -1).cpu()
+    want = torch.cat([ref["mask_real"], ref["mask_imag"]], -1)
+    r = rmse(got, want)
+    print("30 s utterance vs oracle: mask RMSE %.3e, wave RMSE %.3e, memory slot %d (oracle %d)" %
+          (r, rmse(out["enhanced"][1:2].cpu(), ref["enhanced"]), int(out["mem_top"][1]), int(ref["memory"]["top_indices"][0])))
+    assert r <= 1e-3
+    assert int(out["mem_top"][1]) == int(ref["memory"]["top_indices"][0])
