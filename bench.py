@@ -273,8 +273,9 @@ def main():
     ap.add_argument("--breakdown", default=None, help="write the per-kernel-family breakdown JSON here")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound small batches)")
-    ap.add_argument("--streams", type=int, default=2, help="forward passes in flight: consecutive steps alternate over this many "
-                    "HIP streams (each step is still one whole pass over its own buffers; 1 = strictly one pass at a time)")
+    ap.add_argument("--streams", type=int, default=0, help="forward passes in flight: consecutive steps alternate over this many "
+                    "HIP streams (each step is still one whole pass over its own buffers; 1 = strictly one pass at a time; "
+                    "0 = auto: 2 unless a short calibration during warm-up finds one pass at a time faster on this machine)")
     args = ap.parse_args()
     if args.workload in ("c3se", "c2t"):
         return main_train(args)
@@ -305,6 +306,9 @@ def main():
             g_(wave)                                      # capture outside the timed region
         graphed = graphs[0]
 
+    auto_streams = args.streams == 0
+    if auto_streams:
+        args.streams = 2
     # the current (default) stream + S-1 new ones: as few HIP streams as possible, so that they never have to share one of
     # the process's hardware queues (5 streams on 4 queues ran SLOWER than a single stream: 12.9 vs 11.0 ms)
     streams = ([torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(args.streams - 1)]) if args.streams > 1 else None
@@ -326,6 +330,29 @@ def main():
     if rank == 0:
         print("[bench] %s, dtype %s, world %d" % (desc, args.dtype, world), file=sys.stderr, flush=True)
     with torch.no_grad():
+        if auto_streams and not args.graph:
+            # calibration (untimed, part of the warm-up): 4 passes one at a time against 4 passes with two in flight
+            keep = streams
+
+            def timed(n):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    step()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n
+            step(); step()
+            t2 = timed(4)
+            streams = None
+            step()
+            t1 = timed(4)
+            if t1 <= t2:
+                args.streams = 1
+            else:
+                streams = keep
+            if rank == 0:
+                print("[bench] calibration: %.2f ms/pass one at a time, %.2f ms/pass with two in flight -> --streams %d" %
+                      (t1 * 1e3, t2 * 1e3, args.streams), file=sys.stderr, flush=True)
         # warm-up; the last warm-up step is instrumented per kernel family to find the dominant one
         for i in range(max(args.warmup, 1)):
             if i == max(args.warmup, 1) - 1:
