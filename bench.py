@@ -275,7 +275,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound small batches)")
     ap.add_argument("--streams", type=int, default=0, help="forward passes in flight: consecutive steps alternate over this many "
                     "HIP streams (each step is still one whole pass over its own buffers; 1 = strictly one pass at a time; "
-                    "0 = auto: 2 unless a short calibration during warm-up finds one pass at a time faster on this machine)")
+                    "0 = auto: a short calibration during warm-up picks the fastest of 1, 2 and 3 on this machine)")
     args = ap.parse_args()
     if args.workload in ("c3se", "c2t"):
         return main_train(args)
@@ -331,9 +331,8 @@ def main():
         print("[bench] %s, dtype %s, world %d" % (desc, args.dtype, world), file=sys.stderr, flush=True)
     with torch.no_grad():
         if auto_streams and not args.graph:
-            # calibration (untimed, part of the warm-up): 4 passes one at a time against 4 passes with two in flight
-            keep = streams
-
+            # calibration (untimed, part of the warm-up): 6 passes each with 1, 2 and 3 passes in flight; the fastest wins
+            # (more streams than the process has hardware queues run SLOWER than one: never assume, measure)
             def timed(n):
                 torch.cuda.synchronize()
                 t = time.perf_counter()
@@ -341,18 +340,19 @@ def main():
                     step()
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / n
-            step(); step()
-            t2 = timed(4)
-            streams = None
-            step()
-            t1 = timed(4)
-            if t1 <= t2:
-                args.streams = 1
-            else:
-                streams = keep
+            pool = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+            res = {}
+            for cand in (3, 2, 1):
+                streams = pool[:cand] if cand > 1 else None
+                for _ in range(cand):
+                    step()
+                res[cand] = timed(6)
+            best = min(res, key=lambda c: res[c] * (1.0 + 0.01 * c))          # prefer fewer passes in flight on a tie
+            args.streams = best
+            streams = pool[:best] if best > 1 else None
             if rank == 0:
-                print("[bench] calibration: %.2f ms/pass one at a time, %.2f ms/pass with two in flight -> --streams %d" %
-                      (t1 * 1e3, t2 * 1e3, args.streams), file=sys.stderr, flush=True)
+                print("[bench] calibration (ms/pass): %s -> --streams %d" %
+                      (", ".join("%d in flight %.2f" % (c, res[c] * 1e3) for c in (1, 2, 3)), best), file=sys.stderr, flush=True)
         # warm-up; the last warm-up step is instrumented per kernel family to find the dominant one
         for i in range(max(args.warmup, 1)):
             if i == max(args.warmup, 1) - 1:
