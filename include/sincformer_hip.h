@@ -74,9 +74,10 @@ int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out,
                   int nsplit, int dtype, int variant, float p_drop, unsigned int seed,
                      void* stream);
 /* Linear (A [M, Cin] 16-bit, row stride lda) with the FeedForwardModule's Swish and hidden dropout fused into the epilogue
- * (training; models/conformer.py:44-46 and its backward).  backward == 0: out2 [M, N] 16-bit = z = A W^T + bias (kept for
- * the backward), out 16-bit = keep/(1-p) * swish(z);  backward != 0: out 16-bit = (A W^T) * keep/(1-p) * swish'(aux), aux = the
- * saved z.  Dropout counters m * N + n, the same as sfm_ew_train modes 0 / 1.  N % 8 == 0, 16-byte aligned rows. */
+ * (training; models/conformer.py:44-46 and its backward).  backward == 0: z = A W^T + bias; out 16-bit = keep/(1-p) * swish(z),
+ * out2 [M, N] 16-bit = d = keep/(1-p) * swish'(z), the derivative factor kept for the backward;  backward != 0: out 16-bit =
+ * (A W^T) * aux with aux = the saved d.  Dropout counters m * N + n, the same as sfm_ew_train modes 0 / 1.  N % 8 == 0,
+ * 16-byte aligned rows. */
 int sfm_gemm16_swish(const void* A, const void* W, const float* bias, void* out, const void* aux, void* out2, int M, int Cin,
                      int lda, int Kpad, int N, int Npad, int ldo, int backward, float p_drop, unsigned int seed, int dtype,
                      void* stream);

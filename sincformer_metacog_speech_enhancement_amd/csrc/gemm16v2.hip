@@ -21,8 +21,8 @@
 #define EPI_TANH_SCALE 6
 #define EPI_SIGMA 7
 #define EPI_CPEA 8
-#define EPI_SWISH_DUAL 9     // training forward of an FFN's first Linear: out2 = z (16-bit pre-activation), out = drop * swish(z)
-#define EPI_SWISH_BWD 10     // training backward: out = v * drop * swish'(aux), aux = the saved 16-bit pre-activation
+#define EPI_SWISH_DUAL 9     // training forward of an FFN's first Linear: out = keep * swish(z), out2 = d = keep * swish'(z) (16-bit)
+#define EPI_SWISH_BWD 10     // training backward: out = v * aux, aux = the saved derivative factor d
 
 struct Gemm2Params {
   const u16* A;
@@ -39,8 +39,8 @@ struct Gemm2Params {
   int nMt, nNt, a_records, w_records, vec_ok, gn_slots;
   float p_drop;                                   // EPI_RESID: out = resid + alpha * keep(m*N + n) * v; EPI_SWISH_*: hidden dropout
   unsigned int seed;
-  const u16* aux;                                 // EPI_SWISH_BWD: saved pre-activation, layout of `out`
-  u16* out2;                                      // EPI_SWISH_DUAL: second output (pre-activation), layout of `out`
+  const u16* aux;                                 // EPI_SWISH_BWD: saved derivative factor keep * swish'(z), layout of `out`
+  u16* out2;                                      // EPI_SWISH_DUAL: second output (that derivative factor), layout of `out`
 };
 
 template <int N>
@@ -436,29 +436,31 @@ __device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32
         // fused Swish of the FFN (training): vector path only (the launcher guarantees N % 8 == 0, aligned rows, 16-bit out)
         const long long orow = obase + (long long)m * p.ldo + ncol0;
         if (ncol0 + 8 <= p.N) {
-          float zz[8];
-          u32x4 pz;
           if (p.epi == EPI_SWISH_DUAL) {
+            // forward: u = keep * swish(z) and, for the backward, the derivative factor d = keep * swish'(z) (NOT z itself:
+            // the backward's epilogue is then a single multiply instead of exp + rcp + the dropout hash per element)
+            const float ik = (p.p_drop > 0.f) ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+            const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
+            float kp[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (p.p_drop > 0.f) sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
+            float dd[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pz[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-            *reinterpret_cast<u32x4*>(p.out2 + orow) = pz;
+            for (int e = 0; e < 8; ++e) {
+              const float sg = sigmoid_f(v[e]);
+              dd[e] = kp[e] * sg * (1.0f + v[e] * (1.0f - sg));
+              v[e] = v[e] * sg * kp[e];
+            }
+            u32x4 pd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pd[e] = pack2<T>(dd[2 * e], dd[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(p.out2 + orow) = pd;
           } else {
-            pz = *reinterpret_cast<const u32x4*>(p.aux + orow);
-          }
+            const u32x4 pd = *reinterpret_cast<const u32x4*>(p.aux + orow);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {                     // forward and backward both see the ROUNDED pre-activation
-            zz[2 * e] = T::to_f32((u16)(pz[e] & 0xffffu));
-            zz[2 * e + 1] = T::to_f32((u16)(pz[e] >> 16));
-          }
-          const float ik = (p.p_drop > 0.f) ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-          const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
-          float kp[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-          if (p.p_drop > 0.f) sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dr = kp[e];
-            const float sg = sigmoid_f(zz[e]);
-            v[e] = (p.epi == EPI_SWISH_DUAL) ? zz[e] * sg * dr : v[e] * dr * sg * (1.0f + zz[e] * (1.0f - sg));
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] *= T::to_f32((u16)(pd[e] & 0xffffu));
+              v[2 * e + 1] *= T::to_f32((u16)(pd[e] >> 16));
+            }
           }
           u32x4 pk;
 #pragma unroll
@@ -937,8 +939,8 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
 }
 
 // Linear with the FFN's Swish (+ hidden dropout) fused into the epilogue (training; models/conformer.py:44-46 and its backward):
-//   backward == 0: out2 [M, N] 16-bit = z = A W^T + bias (saved for the backward), out 16-bit = keep/(1-p) * swish(z)
-//   backward != 0: out 16-bit = (A W^T) * keep/(1-p) * swish'(aux),  aux = the saved z          (counters: m * N + n, as sfm_ew_train)
+//   backward == 0: z = A W^T + bias; out 16-bit = keep/(1-p) * swish(z), out2 [M, N] 16-bit = d = keep/(1-p) * swish'(z) (saved)
+//   backward != 0: out 16-bit = (A W^T) * aux,  aux = the saved d                                (counters: m * N + n, as sfm_ew_train)
 extern "C" int sfm_gemm16_swish(const void* A, const void* W, const float* bias, void* out, const void* aux, void* out2, int M,
                                 int Cin, int lda, int Kpad, int N, int Npad, int ldo, int backward, float p_drop,
                                 unsigned int seed, int dtype, void* stream) {

@@ -270,8 +270,8 @@ def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=N
 
 def linear16_swish(x16, pw, p_drop=0.0, seed=0, aux=None):
     """FFN Linear with the Swish (+ hidden dropout) in the GEMM epilogue (training).
-    aux is None: forward -> (z [M, N] 16-bit pre-activation, u = drop * swish(z));  aux = saved z: backward -> g * drop * swish'(z)
-    where g = x16 @ W^T (pw = the transposed pack, no bias)."""
+    aux is None: forward -> (d [M, N] 16-bit = drop * swish'(z), the derivative factor the backward needs, u = drop * swish(z));
+    aux = saved d: backward -> g * d where g = x16 @ W^T (pw = the transposed pack, no bias)."""
     L = _lib.load()
     M, ld = x16.shape[0], x16.stride(0)
     dt = _state["dtype"]

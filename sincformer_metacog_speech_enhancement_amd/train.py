@@ -74,7 +74,9 @@ def _ffn_fwd(x, P, pre, p, seeds):
     h16 = _ln16(x, lw, lb)
     s1, s2 = seeds.next(), seeds.next()
     if FUSE_FFN_SWISH and f1.N % 8 == 0:
-        z1, u = ops.linear16_swish(h16, f1, p_drop=p, seed=s1)            # pre-activation + dropout(swish) from one epilogue
+        # one epilogue writes u = dropout(swish(z)) and, in the slot of the pre-activation, the derivative factor
+        # d = keep * swish'(z): the backward's epilogue is then a single multiply
+        z1, u = ops.linear16_swish(h16, f1, p_drop=p, seed=s1)
     else:
         z1 = ops.linear16(h16, f1)                                        # [M, FF] 16-bit pre-activation
         u = torch.empty_like(z1)
@@ -91,7 +93,7 @@ def _ffn_bwd(dy, c, G, pre):
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=0.5, p=c["p"], seed=c["s2"])
     ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"], G[pre + "linear2.bias"])
     if FUSE_FFN_SWISH and FF % 8 == 0:
-        dz = ops.linear16_swish(do, c["b2"], p_drop=c["p"], seed=c["s1"], aux=c["z1"])   # (do W2) * drop * swish'(z1): one launch
+        dz = ops.linear16_swish(do, c["b2"], p_drop=c["p"], seed=c["s1"], aux=c["z1"])   # (do W2) * d, d saved by the forward
     else:
         du = ops.linear16(do, c["b2"], out_dtype=torch.float32)             # [M, FF]
         dz = torch.empty(M, FF, device=dy.device, dtype=dt)
