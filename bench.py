@@ -156,10 +156,10 @@ def main_train(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if os.environ.get("SFM_SINGLE_DEVICE") else local_rank)   # rehearsal of N ranks on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("SFM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
     from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
@@ -285,10 +285,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if os.environ.get("SFM_SINGLE_DEVICE") else local_rank)   # rehearsal of N ranks on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("SFM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
     B, L, desc = WORKLOADS[args.workload]
