@@ -233,6 +233,10 @@ def main_train(args):
         else:
             ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
         st = opt.stats()
+        traffic = None                                  # HBM bytes per launch of the dominant family from the committed PMC passes
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
         line = {
             "metric": "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref",
             "value": frames / elapsed, "unit": "STFT frames/s trained (whole job)", "n_gpus": world, "steps": args.steps,
@@ -243,7 +247,8 @@ def main_train(args):
                                    "overlapped with backward", "optimizer": "AdamW lr 5e-4 betas (0.9, 0.98) wd 0.01, clip 5.0",
                        "dropout": "module defaults (0.1 / 0.15)" if whole_path else 0.15},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
+                         "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)",
+                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
                          "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]},
             "frames_per_s_per_gpu": frames / elapsed / world,
             "final_loss": float(loss.detach()), "optimizer_state": st,
