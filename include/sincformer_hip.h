@@ -51,6 +51,8 @@ int sfm_abi_version(void);
  *   out row (b, l) = epi( sum_{tap,ci} A[b, l*stride-pad+tap, ci] W[n,(tap,ci)] + bias[n] )
  *   gn_partial (optional): per (batch, row-half-tile, group) {sum, sumsq} of the
  *       pre-activation outputs, [B][2*ceil(Lout/128)][N/gn_group][2] floats.
+ *   out_f32: 0 = 16-bit result in the operands' format `dtype`, 1 = fp32, 2 = 16-bit in the OTHER format (bf16 <-> fp16:
+ *       a stage boundary of the host's precision policy; one rounding of the fp32 accumulators).
  */
 int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const float* resid,
                float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
@@ -109,6 +111,11 @@ int sfm_attention_set_variant(int v);
 int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                       int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
                       float scale, int dtype, void* stream);
+/* Same, with the result written in `out_dtype` (SFM_DT_BF16 / SFM_DT_F16) when it differs from the operands' `dtype`
+ * (precision policy: a bf16 attention core behind fp16 projections; head_dim 64 kernels only). */
+int sfm_attention_fwd_ex(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
+                         int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
+                         float scale, int dtype, int out_dtype, void* stream);
 
 /* nn.LayerNorm (+ optional erf GELU when act==1): models/conformer.py:43,68,107,150;
  * agents/msa.py:44-47; training/conformer_pipeline.py:274,282. */

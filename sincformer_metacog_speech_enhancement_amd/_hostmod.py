@@ -11,7 +11,7 @@ class HipModule(torch.nn.Module):
     until a parameter changes) and enqueues kernels through the C ABI."""
 
     def _pack_key(self):
-        sig = [ops.compute_dtype()]
+        sig = [ops.policy_key()]
         for t in list(self.parameters()) + list(self.buffers()):
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)

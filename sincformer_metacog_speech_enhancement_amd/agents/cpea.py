@@ -31,15 +31,17 @@ class CorrelationPhaseEstimationAgent(HipModule):
             return train.cpea_train_forward(self, z_t)
         pk = self._packed(lambda sd: Fn.pack_cpea(sd, self.num_layers))
         z = z_t.float()
-        dt = ops.compute_dtype()
+        dt = ops.stage_dtype("front")
         if z.dim() == 3 and z.shape[-1] != self.input_dim:        # agents/cpea.py:94-96
             B, D, T = z.shape
             z16 = torch.empty(B * T, D, device=z.device, dtype=dt)
-            ops.transpose(z.contiguous(), z16, B, D, T, D * T, T, T * D, D)
+            with ops.stage("front"):
+                ops.transpose(z.contiguous(), z16, B, D, T, D * T, T, T * D, D)
         else:
             B, T, D = z.shape
             z16 = torch.empty(B * T, D, device=z.device, dtype=dt)
-            ops.convert_rows(z.contiguous(), z16, B * T, D, D, D, D)
+            with ops.stage("front"):
+                ops.convert_rows(z.contiguous(), z16, B * T, D, D, D, D)
         out = Fn.cpea_forward(z16, pk, B, T).reshape(B, T, -1)
         oc = self.output_channels
         return {"rho_s": out[..., :oc], "rho_n": out[..., oc:2 * oc], "phi1": out[..., 2 * oc:3 * oc],

@@ -26,7 +26,7 @@ class EpisodicMemory(HipModule):
         self.register_buffer("num_queries", torch.tensor(0))
 
     def _pack_key(self):      # usage counters must not invalidate the packed parameters
-        return tuple([ops.compute_dtype()] + [(p.data_ptr(), p._version) for p in self.parameters()])
+        return tuple([ops.policy_key()] + [(p.data_ptr(), p._version) for p in self.parameters()])
 
     def forward(self, environment_embedding):
         self._require_device(environment_embedding)

@@ -40,12 +40,21 @@ __device__ __forceinline__ float attn_keep_rk(uint32_t rowh, int key, uint32_t t
   return ((x >> 8) >= thr24) ? inv_keep : 0.f;
 }
 
+// O is written in the operands' format T, or (out_other) in the other 16-bit format: the attention core may run in bf16 behind
+// fp16 projections (precision policy, ops.STAGES)
+template <class T>
+__device__ __forceinline__ uint32_t pack2_o(float lo, float hi, bool other) {
+  if (T::id == SFM_DT_BF16) return other ? F16::pack(lo, hi) : BF16::pack(lo, hi);
+  return other ? BF16::pack(lo, hi) : F16::pack(lo, hi);
+}
+
 template <class T, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
                                                             int Tlen, int ldqkv, int ldo, int koff, int voff,
                                                             long long qkv_batch_stride, long long o_batch_stride,
                                                             float scale_log2e, int nqt, int nheads,
-                                                            float* __restrict__ lse_out, float p_drop, uint32_t seed) {
+                                                            float* __restrict__ lse_out, float p_drop, uint32_t seed,
+                                                            int out_other) {
   constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
 
@@ -262,8 +271,8 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     for (int rq = 0; rq < 4; ++rq) {
       int d0 = dj * 32 + 8 * rq + 4 * hl;
       u32x2 w;
-      w[0] = pack2<T>(o[dj][4 * rq + 0] * inv, o[dj][4 * rq + 1] * inv);
-      w[1] = pack2<T>(o[dj][4 * rq + 2] * inv, o[dj][4 * rq + 3] * inv);
+      w[0] = pack2_o<T>(o[dj][4 * rq + 0] * inv, o[dj][4 * rq + 1] * inv, out_other != 0);
+      w[1] = pack2_o<T>(o[dj][4 * rq + 2] * inv, o[dj][4 * rq + 3] * inv, out_other != 0);
       *reinterpret_cast<u32x2*>(&Os[l31 * OS_ROW + d0]) = w;
     }
   __syncthreads();
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd64x2_kernel(const u16* __re
                                                                  int Tlen, int ldqkv, int ldo, int koff, int voff,
                                                                  long long qkv_batch_stride, long long o_batch_stride,
                                                                  float scale_log2e, int nqt, int nheads,
-                                                                 float* __restrict__ lse_out) {
+                                                                 float* __restrict__ lse_out, int out_other) {
   constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
 
@@ -555,8 +564,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd64x2_kernel(const u16* __re
       for (int rq = 0; rq < 4; ++rq) {
         const int d0 = dj * 32 + 8 * rq + 4 * hl;
         u32x2 w;
-        w[0] = pack2<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv);
-        w[1] = pack2<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv);
+        w[0] = pack2_o<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv, out_other != 0);
+        w[1] = pack2_o<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv, out_other != 0);
         *reinterpret_cast<u32x2*>(&Os[(32 * u + l31) * OS_ROW + d0]) = w;
       }
   }
@@ -572,6 +581,332 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd64x2_kernel(const u16* __re
       *reinterpret_cast<u32x4*>(ob + (long long)q * ldo + ch) = v;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// attn_fwd_hd64r: persistent form for the headline shape (batch 256 x 512-frame utterances: 8 key tiles per row, where the
+// per-workgroup costs of the kernels above - Q fetch, first K/V tile, one barrier per key tile, O transpose and store tail -
+// are 15-20 % of the launch).  Same arithmetic and fragment layouts as attn_fwd_hd64x2 (64 query rows per wave, software
+// pipeline over (sub-block, 32-key step) items, augmented k-step, ones-row sums, deferred running-max raise); what differs:
+//   * one workgroup per CU: 8 waves = 512 query rows of one (batch, head), 2 waves per SIMD; the grid is persistent, each
+//     workgroup walks its list of (batch, head, 512-row query tile) items;
+//   * K and V go HBM -> LDS by LDS-DMA (`buffer_load ... lds`: no staging registers, no ds_write) into a ring of 6 key-tile
+//     slots (96 KB) = two groups of 3 tiles.  ONE workgroup barrier per 3 key tiles: at the start of group g every wave has
+//     finished group g-1, so the half it occupied is refilled with group g+1 - of this item or of the workgroup's NEXT item, so
+//     the K/V stream never stops at an item boundary;
+//   * the NEXT item's Q rows (64 KB) are prefetched by LDS-DMA into the rest of the LDS (each wave its own 64 rows: no
+//     cross-wave ordering needed), so an item starts with LDS reads instead of a global round trip;
+//   * the descriptor's range check zero-fills keys >= T (their scores are pushed to -BIG by the augmented k-step) and drops
+//     the stores of query rows >= T: no predicates in the loop;
+//   * 128-byte LDS rows; 16-byte chunk c of K row r sits at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments), of V row
+//     r at c ^ (((r >> 1) & 1) << 2) (the four rows x 64 B of a transposed read tile the 256-byte bank row); the swizzle is
+//     applied to the SOURCE address, since LDS-DMA writes lane-linear;
+//   * O leaves the registers directly: v_permlane32_swap pairs the 8-byte fragments of the lane halves into 16-byte row
+//     segments (no LDS transpose), issued after the next item's first barrier so the stores drain under its math.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void attn_fwd_hd64r_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen,
+                                                                int ldqkv, int ldo, int koff, int voff,
+                                                                long long qkv_batch_stride, long long o_batch_stride,
+                                                                float scale_log2e, int nqt, int nheads, int n_items,
+                                                                float* __restrict__ lse_out, int out_other) {
+  constexpr int SLOT = 16384;                                       // one key tile: K 64 x 128 B, then V 64 x 128 B
+  constexpr int GT = 3;                                             // key tiles per group (ring = 2 groups)
+  constexpr int QBASE = 2 * GT * SLOT;                              // Q prefetch region: 8 waves x 64 rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l31 = lane & 31;
+  const int nkt = (Tlen + 63) >> 6, ngrp = (nkt + GT - 1) / GT, nsteps = 2 * nkt;
+  const int rec_bytes = Tlen * ldqkv * 2;                          // keys / queries >= Tlen are out of range: read as zero
+  const int orec_bytes = Tlen * ldo * 2;
+
+  // ---- LDS-DMA lane constants: an instruction moves 8 rows x 128 B; this wave owns rows 8*wave .. 8*wave+7 of every tile ----
+  const int prow = wave * 8 + (lane >> 3);
+  const int kconst = prow * ldqkv * 2 + koff * 2 + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+  const int vconst = prow * ldqkv * 2 + voff * 2 + (((lane & 7) ^ (((prow >> 1) & 1) << 2)) << 4);
+  auto issue_group = [&](int item, int g, int half) {              // K/V tiles GT g .. GT g + GT-1 of `item` -> ring half `half`
+    const int bh = item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (long long)b * qkv_batch_stride), 0, rec_bytes, 0x00020000);
+#pragma unroll
+    for (int tl = 0; tl < GT; ++tl) {
+      const int kt = g * GT + tl;
+      if (kt < nkt) {
+        const int off = kt * 64 * ldqkv * 2 + h * 128;
+        unsigned char* dst = rsm + (half * GT + tl) * SLOT + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attn_lds_ptr_t)dst, 16, kconst + off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attn_lds_ptr_t)(dst + 8192), 16, vconst + off, 0, 0, 0);
+      }
+    }
+  };
+
+  // Q rows of `item` for this wave (64 rows x 128 B, same chunk swizzle as a K tile) -> the wave's 8 KB of the Q region
+  auto issue_q = [&](int item) {
+    const int qt = item % nqt, bh = item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (long long)b * qkv_batch_stride), 0, rec_bytes, 0x00020000);
+    const int off = (qt * 512 + wave * 64) * ldqkv * 2 + h * 128;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // LDS chunk position lane&7 of row 8j + lane/8 holds logical chunk (lane&7) ^ ((4j + lane/16) & 7)
+      const int c = ((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 4;
+      const int voff = off + (8 * j + (lane >> 3)) * ldqkv * 2 + c;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attn_lds_ptr_t)(rsm + QBASE + wave * 8192 + j * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment read lane constants ----
+  int klane[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) klane[ks] = l31 * 128 + (((2 * ks + hl) ^ ((l31 >> 1) & 7)) << 4);
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int vrow0 = 4 * (g16 >> 1) + (i16 >> 2);
+  int vlane[2];
+#pragma unroll
+  for (int dj = 0; dj < 2; ++dj) {
+    const int chunk = dj * 4 + (g16 & 1) * 2 + ((i16 & 3) >> 1);
+    vlane[dj] = 8192 + vrow0 * 128 + ((chunk ^ (((vrow0 >> 1) & 1) << 2)) << 4) + (i16 & 1) * 8;
+  }
+
+  const uint32_t one16 = T::from_f32(1.0f);
+  const uint32_t ones2 = one16 | (one16 << 16);
+  const uint32_t negbig = (uint32_t)T::from_f32(T::id == SFM_DT_F16 ? -60000.0f : -3.0e38f);
+  const u32x4 vones = {ones2, ones2, ones2, ones2};
+
+  u32x4 kf[4];
+  u32x2 vt[2][2][2];                                                // V^T fragment halves [s2][dj][first / second 4 keys]
+  auto load_kf = [&](int sbase) {                                  // K rows of one 32-key step (sbase: byte offset of its rows)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(rsm + sbase + klane[ks]);
+  };
+  // The transposed V reads are issued as inline asm: behind an LDS-DMA the compiler guards every ds_read_b64_tr_b16 builtin
+  // with `s_waitcnt vmcnt(0)` (it cannot prove the read does not alias the DMA's destination), which would make every step
+  // wait for the next group's K/V prefetch and for the previous item's O stores.  The ring protocol (vmcnt + barrier at the
+  // group boundary) is what orders reads against fills; `vt_wait` is the lgkmcnt wait the compiler no longer inserts, tied
+  // to the fragment registers so that their consumers stay behind it.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lds_ptr_t)rsm;
+  auto load_vf = [&](int sbase) {
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj) {
+      const uint32_t a = lds0 + sbase + vlane[dj];
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[0][dj][0]) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vt[0][dj][1]) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vt[1][dj][0]) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(vt[1][dj][1]) : "v"(a) : "memory");
+    }
+  };
+  auto vt_wait = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[1][0][0]),
+                   "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1])
+                 :
+                 : "memory");
+  };
+#define SFM_VF(S2, DJ) (u32x4{vt[S2][DJ][0][0], vt[S2][DJ][0][1], vt[S2][DJ][1][0], vt[S2][DJ][1][1]})
+
+  u32x4 qf[2][4];
+  uint32_t qaug[2];
+  float m_run[2];
+  f32x16 o[2][2], lacc[2], s[2];
+
+#define SFM_ATTN_RITEM(U, STEP, HAS_PREV, FIRST, WAITV)                                                                    \
+  {                                                                                                                   \
+    constexpr int V_ = 1 - (U);                                                                                       \
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
+    const bool pad_ = (STEP) * 32 + l31 >= Tlen;                                                                      \
+    const u32x4 ka = {hl == 0 ? ones2 : 0u, (hl == 0 && pad_) ? one16 : 0u, 0u, 0u};                                  \
+    const u32x4 qa = {qaug[U], hl == 0 ? negbig : 0u, 0u, 0u};                                                        \
+    f32x16 sn = T::mfma(ka, qa, zero);                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) sn = T::mfma(kf[ks], qf[U][ks], sn);                             \
+    if (WAITV) vt_wait();                                                                                             \
+    if (HAS_PREV) {                                                                                                   \
+      u32x4 pf[2];                                                                                                    \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+        float e_[8];                                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[V_][8 * s2 + r]);              \
+        pf[s2][0] = pack2<T>(e_[0], e_[1]);                                                                           \
+        pf[s2][1] = pack2<T>(e_[2], e_[3]);                                                                           \
+        pf[s2][2] = pack2<T>(e_[4], e_[5]);                                                                           \
+        pf[s2][3] = pack2<T>(e_[6], e_[7]);                                                                           \
+      }                                                                                                               \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+        lacc[V_] = T::mfma(vones, pf[s2], lacc[V_]);                                                                  \
+        o[V_][0] = T::mfma(SFM_VF(s2, 0), pf[s2], o[V_][0]);                                                              \
+        o[V_][1] = T::mfma(SFM_VF(s2, 1), pf[s2], o[V_][1]);                                                              \
+      }                                                                                                               \
+    }                                                                                                                 \
+    float mx = fmaxf(sn[0], sn[1]);                                                                                   \
+    _Pragma("unroll") for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sn[r]);                                             \
+    mx = xhalf_max(mx);                                                                                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < 11; ++g_) {                                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                              \
+    }                                                                                                                 \
+    if ((FIRST) || __any(mx > DEFER_THR)) {                                                                           \
+      const float want = m_run[U] + mx;                                                                               \
+      const float hi = T::to_f32(T::from_f32(want));                                                                  \
+      const float lo = T::to_f32(T::from_f32(want - hi));                                                             \
+      const float m_new = hi + lo;                                                                                    \
+      const float delta = m_new - m_run[U];                                                                           \
+      if (!(FIRST)) {                                                                                                 \
+        const float alpha = __builtin_amdgcn_exp2f(-delta);                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
+          o[U][0][r] *= alpha;                                                                                        \
+          o[U][1][r] *= alpha;                                                                                        \
+          lacc[U][r] *= alpha;                                                                                        \
+        }                                                                                                             \
+      }                                                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) sn[r] -= delta;                                                  \
+      m_run[U] = m_new;                                                                                               \
+      qaug[U] = (hl == 0) ? pack2<T>(-hi, -lo) : 0u;                                                                  \
+    }                                                                                                                 \
+    s[U] = sn;                                                                                                        \
+  }
+
+  // ---- O of the finished item, held until the next item's first barrier has been passed ----
+  uint32_t ow[2][2][4][2];                                          // [sub-block][dj][rq][2 dwords] = 4 consecutive d, 16-bit
+  int st_item = -1;
+  auto store_o = [&]() {
+    if (st_item < 0) return;
+    const int qt = st_item % nqt, bh = st_item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    auto ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * o_batch_stride), 0, orec_bytes, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = qt * 512 + wave * 64 + 32 * u + l31;
+      const int rowoff = q * ldo * 2 + h * 128 + hl * 16;
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // lanes 0-31 keep fragment 2j and receive the upper half's fragment 2j (d + 4): 16 contiguous bytes; lanes 32-63
+          // likewise for fragment 2j+1
+          const auto x = __builtin_amdgcn_permlane32_swap(ow[u][dj][2 * j][0], ow[u][dj][2 * j + 1][0], false, false);
+          const auto y = __builtin_amdgcn_permlane32_swap(ow[u][dj][2 * j][1], ow[u][dj][2 * j + 1][1], false, false);
+          const u32x4 v = {x[0], y[0], x[1], y[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(v, ors, rowoff + dj * 64 + j * 32, 0, 0);
+        }
+    }
+    st_item = -1;
+  };
+
+  int gcount = 0;                                                   // groups consumed so far by this workgroup (ring parity)
+  if ((int)blockIdx.x < n_items) {
+    issue_q(blockIdx.x);
+    issue_group(blockIdx.x, 0, 0);
+  }
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int qt = item % nqt, bh = item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    const int q0 = qt * 512 + wave * 64;
+    // ---- Q fragments (B operand: col = query, k = d) from the prefetched LDS rows; rows >= Tlen were zero-filled ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's own Q pieces (issued an item ago)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        qf[u][ks] = *reinterpret_cast<const u32x4*>(rsm + QBASE + wave * 8192 + u * 4096 + klane[ks]);
+    if (scale_log2e != 1.0f) {                                     // callers normally fold the scale into W_q (scale_log2e == 1)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t w = qf[u][ks][e];
+            qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
+          }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      qaug[u] = 0u;
+      m_run[u] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[u][0][r] = 0.f;
+        o[u][1][r] = 0.f;
+        lacc[u][r] = 0.f;
+        s[u][r] = 0.f;
+      }
+    }
+
+    for (int g = 0; g < ngrp; ++g) {
+      // ---- group boundary: this wave's pieces of group g have landed (vmcnt), everyone's have and everyone is done with
+      //      group g-1 (barrier): refill that half with the next group of this item or group 0 of the next item ----
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int half = gcount & 1;
+      if (g + 1 < ngrp) issue_group(item, g + 1, half ^ 1);
+      else if (item + (int)gridDim.x < n_items) issue_group(item + gridDim.x, 0, half ^ 1);
+      ++gcount;
+      if (g == 0) store_o();                                        // the previous item's O: drains under this item's math
+      // the next item's Q rows: this wave's own region, free since its Q fragments are in registers (the barrier above
+      // also waited for those LDS reads)
+      if (g == (ngrp > 1 ? 1 : 0) && item + (int)gridDim.x < n_items) issue_q(item + gridDim.x);
+      const int step_end = min(nsteps, (g + 1) * 2 * GT);
+      int step = g * 2 * GT;
+      if (g == 0) {
+        // ---- first step of the item, peeled: the running maxima are initialised, A(0) has no predecessor ----
+        const int sb = (half * GT) * SLOT;
+        load_kf(sb);
+        SFM_ATTN_RITEM(0, 0, false, true, false)
+        load_vf(sb);
+        SFM_ATTN_RITEM(1, 0, true, true, true)
+        step = 1;
+      }
+      for (; step < step_end; ++step) {
+        const int sb = (half * GT + ((step >> 1) - g * GT)) * SLOT + (step & 1) * 4096;
+        load_kf(sb);
+        SFM_ATTN_RITEM(0, step, true, false, false)
+        load_vf(sb);
+        SFM_ATTN_RITEM(1, step, true, false, true)
+      }
+    }
+    // ---- drain: the last item B(last step) still has to be exponentiated and multiplied into O ----
+    {
+      u32x4 pf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float e_[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[1][8 * s2 + r]);
+        pf[s2][0] = pack2<T>(e_[0], e_[1]);
+        pf[s2][1] = pack2<T>(e_[2], e_[3]);
+        pf[s2][2] = pack2<T>(e_[4], e_[5]);
+        pf[s2][3] = pack2<T>(e_[6], e_[7]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        lacc[1] = T::mfma(vones, pf[s2], lacc[1]);
+        o[1][0] = T::mfma(SFM_VF(s2, 0), pf[s2], o[1][0]);
+        o[1][1] = T::mfma(SFM_VF(s2, 1), pf[s2], o[1][1]);
+      }
+    }
+    // ---- normalise and pack; the stores themselves are issued after the next barrier (store_o) ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float l = lacc[u][0];
+      const float inv = 1.0f / l;
+      const int q = q0 + 32 * u + l31;
+      if (lse_out && hl == 0 && q < Tlen)
+        lse_out[((long long)b * nheads + h) * Tlen + q] = m_run[u] + __builtin_amdgcn_logf(l);
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          ow[u][dj][rq][0] = pack2_o<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv, out_other != 0);
+          ow[u][dj][rq][1] = pack2_o<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv, out_other != 0);
+        }
+    }
+    st_item = item;
+  }
+#undef SFM_ATTN_RITEM
+#undef SFM_VF
+  store_o();
 }
 
 // ---------------------------------------------------------------------------
@@ -633,61 +968,81 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
 
 // kernel selection for the head_dim 64 no-dropout path: 0 = by sequence length (64 query rows per wave from T >= 1024,
 // where the software-pipelined kernel wins; 32 rows per wave below, where its shorter prologue does), 1 = always 32 rows
-// per wave, 2 = always 64 rows per wave
+// per wave, 2 = always 64 rows per wave, 3 = always the persistent ring kernel (attn_fwd_hd64r)
 static int sfm_attn_variant = 0;
 extern "C" int sfm_attention_set_variant(int v) {
-  if (v < 0 || v > 2) return SFM_ERR_ARG;
+  if (v < 0 || v > 3) return SFM_ERR_ARG;
   sfm_attn_variant = v;
   return SFM_OK;
 }
 
 // qkv: [B, T, ldqkv] 16-bit with q at column h*hd, k at koff + h*hd, v at voff + h*hd.
-extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
-                                       int ldo, int koff, int voff, long long qkv_batch_stride,
-                                       long long o_batch_stride, float scale, float p_drop, unsigned int seed,
-                                       int dtype, void* stream);
-
-extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
-                                 int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
-                                 float scale, int dtype, void* stream) {
-  return sfm_attention_fwd_train(qkv, out, nullptr, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride,
-                                 scale, 0.f, 0u, dtype, stream);
-}
-
-// training-mode forward: also writes lse [B,H,T] (log2 domain) and applies attention dropout
-extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
-                                       int ldo, int koff, int voff, long long qkv_batch_stride,
-                                       long long o_batch_stride, float scale, float p_drop, unsigned int seed,
-                                       int dtype, void* stream) {
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv, int ldo, int koff,
+                              int voff, long long qkv_batch_stride, long long o_batch_stride, float scale, float p_drop,
+                              unsigned int seed, int dtype, int out_dtype, void* stream) {
   if (!qkv || !out) return SFM_ERR_ARG;
   if (p_drop < 0.f || p_drop >= 1.f) return SFM_ERR_SHAPE;
   if ((lse || p_drop > 0.f) && (qkv_batch_stride != (long long)T * ldqkv)) return SFM_ERR_SHAPE;
   if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 256) return SFM_ERR_SHAPE;
+  if ((dtype != SFM_DT_BF16 && dtype != SFM_DT_F16) || (out_dtype != SFM_DT_BF16 && out_dtype != SFM_DT_F16)) return SFM_ERR_ARG;
+  const int out_other = (out_dtype != dtype) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (hd == 64 && (ldqkv % 8) == 0 && (ldo % 8) == 0 && (koff % 8) == 0 && (voff % 8) == 0 &&
       (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
     // scale <= 0: Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
     float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
+    // persistent ring kernel: one 512-row query tile per item; auto for 256 < T <= 512 with at least one item per CU
+    // (the headline shape, batch 256 x 512 frames x 4 heads = 1024 items), variant 3 forces it for any T
+    const long long bytes_q = (long long)T * ldqkv * 2, bytes_o = (long long)T * ldo * 2;
+    if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) &&
+        (sfm_attn_variant == 3 || (sfm_attn_variant == 0 && T > 256 && T <= 512 && (long long)B * H >= 256))) {
+      const int nqt5 = (T + 511) / 512;
+      const int n_items = nqt5 * H * B;
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SFM_ERR_LAUNCH;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      constexpr int lds = 6 * 16384 + 65536;                        // K/V ring + Q prefetch region = 160 KB
+      static bool attr_set[2] = {false, false};
+      const int ti = dtype == SFM_DT_F16 ? 1 : 0;
+      if (!attr_set[ti]) {
+        const void* fn = ti ? (const void*)attn_fwd_hd64r_kernel<F16> : (const void*)attn_fwd_hd64r_kernel<BF16>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SFM_ERR_LAUNCH;
+        attr_set[ti] = true;
+      }
+      dim3 gridr(n_items < ncu ? n_items : ncu), blockr(512);
+      if (dtype == SFM_DT_F16)
+        SFM_LAUNCH((attn_fwd_hd64r_kernel<F16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
+                   qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
+      else
+        SFM_LAUNCH((attn_fwd_hd64r_kernel<BF16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
+                   qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
+      return SFM_OK;
+    }
     if (p_drop == 0.f && (sfm_attn_variant == 2 || (sfm_attn_variant == 0 && T >= 1024))) {   // 64 query rows per wave
       const int nqt2 = (T + 255) / 256;
       dim3 grid2(nqt2 * H * B), block2(256);
       if (dtype == SFM_DT_F16)
         SFM_LAUNCH((attn_fwd_hd64x2_kernel<F16>), grid2, block2, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
-                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse);
+                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse, out_other);
       else
         SFM_LAUNCH((attn_fwd_hd64x2_kernel<BF16>), grid2, block2, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
-                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse);
+                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse, out_other);
       return SFM_OK;
     }
     const int nqt = (T + 127) / 128;
     dim3 grid(nqt * H * B), block(256);
 #define ATTN_GO(TT, DD)                                                                                            \
   SFM_LAUNCH((attn_fwd_hd64_kernel<TT, DD>), grid, block, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff, \
-             qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed)
+             qkv_batch_stride, o_batch_stride, sl2, nqt, H, lse, p_drop, seed, out_other)
     if (dtype == SFM_DT_F16) { if (p_drop > 0.f) ATTN_GO(F16, true); else ATTN_GO(F16, false); }
     else { if (p_drop > 0.f) ATTN_GO(BF16, true); else ATTN_GO(BF16, false); }
 #undef ATTN_GO
   } else {
+    if (out_other) return SFM_ERR_SHAPE;                  // the small-shape kernel writes the operands' format only
     dim3 grid((T + 3) / 4, H, B), block(256);
     if (scale <= 0.f) scale = 0.69314718055994530942f;      // pre-scaled Q carries log2(e): exp(x ln2) = 2^x
     if (dtype == SFM_DT_F16)
@@ -699,4 +1054,28 @@ extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, i
   }
   SFM_CHECK_LAUNCH();
   return SFM_OK;
+}
+
+extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
+                                 int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
+                                 float scale, int dtype, void* stream) {
+  return attention_fwd_impl(qkv, out, nullptr, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride,
+                            scale, 0.f, 0u, dtype, dtype, stream);
+}
+
+// sfm_attention_fwd with the result written in `out_dtype` (SFM_DT_BF16 / SFM_DT_F16), which may differ from the operands' `dtype`
+extern "C" int sfm_attention_fwd_ex(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
+                                    int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
+                                    float scale, int dtype, int out_dtype, void* stream) {
+  return attention_fwd_impl(qkv, out, nullptr, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride,
+                            scale, 0.f, 0u, dtype, out_dtype, stream);
+}
+
+// training-mode forward: also writes lse [B,H,T] (log2 domain) and applies attention dropout
+extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv,
+                                       int ldo, int koff, int voff, long long qkv_batch_stride,
+                                       long long o_batch_stride, float scale, float p_drop, unsigned int seed,
+                                       int dtype, void* stream) {
+  return attention_fwd_impl(qkv, out, lse, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale,
+                            p_drop, seed, dtype, dtype, stream);
 }

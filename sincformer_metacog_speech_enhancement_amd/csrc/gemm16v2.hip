@@ -43,6 +43,19 @@ struct Gemm2Params {
   u16* out2;                                      // EPI_SWISH_DUAL: second output (that derivative factor), layout of `out`
 };
 
+// 16-bit results are written in the operands' format T (out_f32 == 0) or in the OTHER 16-bit format (out_f32 == 2: a stage
+// boundary of the precision policy, e.g. fp16 projections feeding a bf16 attention core); out_f32 == 1 is fp32.
+template <class T>
+__device__ __forceinline__ uint32_t pack2_out(float lo, float hi, bool other) {
+  if (T::id == SFM_DT_BF16) return other ? F16::pack(lo, hi) : BF16::pack(lo, hi);
+  return other ? BF16::pack(lo, hi) : F16::pack(lo, hi);
+}
+template <class T>
+__device__ __forceinline__ u16 from_f32_out(float v, bool other) {
+  if (T::id == SFM_DT_BF16) return other ? F16::from_f32(v) : BF16::from_f32(v);
+  return other ? BF16::from_f32(v) : F16::from_f32(v);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -288,7 +301,7 @@ float kp[8];
         v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
         v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
       }
-      if (p.out_f32) {
+      if (p.out_f32 == 1) {
         float* op = reinterpret_cast<float*>(p.out) + orow;
         f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
         *reinterpret_cast<f32x4*>(op) = a;
@@ -296,7 +309,7 @@ float kp[8];
       } else {
         u32x4 pk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(v[2 * e], v[2 * e + 1], p.out_f32 == 2);
         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
       }
     } else {
@@ -309,8 +322,8 @@ float kp[8];
               y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
             y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
           }
-          if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
-          else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
+          if (p.out_f32 == 1) reinterpret_cast<float*>(p.out)[orow + e] = y;
+          else reinterpret_cast<u16*>(p.out)[orow + e] = from_f32_out<T>(y, p.out_f32 == 2);
         }
       }
     }
@@ -487,7 +500,7 @@ float kp[8];
             v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
             v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
           }
-          if (p.out_f32) {
+          if (p.out_f32 == 1) {
             float* op = reinterpret_cast<float*>(p.out) + orow;
             f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
             *reinterpret_cast<f32x4*>(op) = a;
@@ -495,7 +508,7 @@ float kp[8];
           } else {
             u32x4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(v[2 * e], v[2 * e + 1], p.out_f32 == 2);
             *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
           }
         } else {
@@ -508,8 +521,8 @@ float kp[8];
                   y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
                 y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
               }
-              if (p.out_f32) reinterpret_cast<float*>(p.out)[orow + e] = y;
-              else reinterpret_cast<u16*>(p.out)[orow + e] = T::from_f32(y);
+              if (p.out_f32 == 1) reinterpret_cast<float*>(p.out)[orow + e] = y;
+              else reinterpret_cast<u16*>(p.out)[orow + e] = from_f32_out<T>(y, p.out_f32 == 2);
             }
           }
         }
@@ -847,18 +860,18 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && epi != EPI_RESID && !swish)) return SFM_ERR_SHAPE;
   if (swish) {                                         // strip-epilogue kernels only; 16-bit, 16-byte aligned row vectors
     if ((epi == EPI_SWISH_DUAL && !out2) || (epi == EPI_SWISH_BWD && !aux)) return SFM_ERR_ARG;
-    if (out_f32 || (N % 8) != 0 || (ldo % 8) != 0 || (o_batch_stride % 8) != 0 || gn_partial) return SFM_ERR_SHAPE;
+    if (out_f32 != 0 || (N % 8) != 0 || (ldo % 8) != 0 || (o_batch_stride % 8) != 0 || gn_partial) return SFM_ERR_SHAPE;
     if ((((uintptr_t)out) % 16) != 0 || (out2 && (((uintptr_t)out2) % 16) != 0) || (aux && (((uintptr_t)aux) % 16) != 0))
       return SFM_ERR_SHAPE;
     if (variant == 1 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 8) variant = 0;
   }
-  if (B <= 0 || Lout <= 0 || N <= 0) return SFM_ERR_SHAPE;
+  if (B <= 0 || Lout <= 0 || N <= 0 || out_f32 < 0 || out_f32 > 2) return SFM_ERR_SHAPE;
   const long long a_rec = ((long long)(Lin - 1) * lda + Cin) * 2;
   const long long w_rec = (long long)Npad * Kpad * 2;
   const bool v2_ok = (Kpad % 64 == 0) && (Npad % 64 == 0) && a_rec < (1LL << 31) && w_rec < (1LL << 31) &&
                      (!gn_partial || gn_group == 8 || gn_group == 16 || gn_group == 32) &&
                      ((long long)Lout * stride * lda * 2 < (1LL << 31)) && (epi != EPI_GLU || Npad % 128 == 0);
-  if ((variant == 1 || !v2_ok) && (p_drop > 0.f || swish)) return SFM_ERR_SHAPE;
+  if ((variant == 1 || !v2_ok) && (p_drop > 0.f || swish || out_f32 == 2)) return SFM_ERR_SHAPE;
   if (variant == 1 || !v2_ok)
     return sfm_gemm16_v1(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
                          Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
@@ -883,7 +896,7 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   p.out_f32 = out_f32; p.gn_group = gn_group; p.nsplit = nsplit; p.p_drop = p_drop; p.seed = seed;
   p.aux = (const u16*)aux; p.out2 = (u16*)out2;
   p.a_records = (int)a_rec; p.w_records = (int)w_rec;
-  const int osz = out_f32 ? 4 : 2;
+  const int osz = out_f32 == 1 ? 4 : 2;
   const bool o_al = (((uintptr_t)out) % 16 == 0) && ((ldo * osz) % 16 == 0) && ((o_batch_stride * osz) % 16 == 0);
   const bool r_al = (epi != EPI_RESID) || ((((uintptr_t)resid) % 16 == 0) && ((ldr * 4) % 16 == 0) && ((r_batch_stride * 4) % 16 == 0));
   p.vec_ok = (o_al && r_al) ? 1 : 0;

@@ -178,9 +178,12 @@ def pack_convmod(sd):
             "pw2": ops.pack_linear(sd["pointwise2.weight"].reshape(D, D), sd["pointwise2.bias"])}
 
 
-def pack_block(sd, num_heads=4):
-    return {"ff1": pack_ffn(sub(sd, "ff1")), "mhsa": pack_mhsa(sub(sd, "mhsa"), num_heads), "conv": pack_convmod(sub(sd, "conv")),
-            "ff2": pack_ffn(sub(sd, "ff2")), "fn_w": _f32(sd["final_norm.weight"]), "fn_b": _f32(sd["final_norm.bias"])}
+def pack_block(sd, num_heads=4, index=None):
+    """index: position of the block in its stack (precision policy overrides "block<i>" / "attn<i>", ops.STAGES)"""
+    with ops.stage("block", index):
+        return {"ff1": pack_ffn(sub(sd, "ff1")), "mhsa": pack_mhsa(sub(sd, "mhsa"), num_heads), "conv": pack_convmod(sub(sd, "conv")),
+                "ff2": pack_ffn(sub(sd, "ff2")), "fn_w": _f32(sd["final_norm.weight"]), "fn_b": _f32(sd["final_norm.bias"]),
+                "index": index}
 
 
 def _ln16(x32, w, b, act=0):
@@ -209,15 +212,23 @@ def ffn_forward(x32, pk):
     return ops.linear16(u, pk["w2"], epi=ops.EPI_RESID, resid=x32, alpha=0.5)
 
 
-def mhsa_forward(x32, pk, B, T, H, h=None):
-    """h: LN(x32) in 16-bit when the producer already normalised (fused into the preceding FFN's epilogue)"""
+def mhsa_forward(x32, pk, B, T, H, h=None, index=None):
+    """h: LN(x32) in 16-bit when the producer already normalised (fused into the preceding FFN's epilogue).
+    The projections run in the caller's ("block") operand format, the Q | K | V buffer and the attention core in the
+    "attn" stage's format: the in-projection's epilogue writes that format, the attention epilogue writes the block's."""
     D = x32.shape[1]
     if h is None:
         h = _ln16(x32, pk["ln_w"], pk["ln_b"])
-    qkv = ops.linear16(h, pk["win"])
+    bdt = ops.compute_dtype()
+    adt = ops.stage_dtype("attn", index) if D // H == 64 else bdt      # the small-shape attention kernel keeps one format
     if pk["heads"] != H:
         raise RuntimeError("packed attention weights were scaled for %d heads, got %d" % (pk["heads"], H))
-    o = ops.attention(qkv, B, T, H, D // H, prescaled=True)
+    qkv = ops.linear16(h, pk["win"], out_dtype=adt)
+    if adt is bdt:
+        o = ops.attention(qkv, B, T, H, D // H, prescaled=True)
+    else:
+        with ops.stage("attn", index):
+            o = ops.attention(qkv, B, T, H, D // H, prescaled=True, out_dtype=bdt)
     return ops.linear16(o, pk["wout"], epi=ops.EPI_RESID, resid=x32, alpha=1.0)
 
 
@@ -234,17 +245,22 @@ def convmod_forward(x32, pk, B, T):
 
 def block_forward(x32, pk, B, T, H, want16=False):
     """ConformerBlock.forward (eval) on the flattened [B*T, D] fp32 stream."""
+    with ops.stage("block", pk.get("index")):
+        return _block_forward(x32, pk, B, T, H, want16)
+
+
+def _block_forward(x32, pk, B, T, H, want16):
     if _ffn_fusable(x32, pk["ff1"]) and x32.shape[1] == 256:
         # ff1 and mhsa.layer_norm in one launch; likewise ff2 and final_norm below (the sum ff2 produces is not kept)
         x, h = ffn_forward_ln(x32, pk["ff1"], pk["mhsa"]["ln_w"], pk["mhsa"]["ln_b"], False, True)
-        x = mhsa_forward(x, pk["mhsa"], B, T, H, h=h)
+        x = mhsa_forward(x, pk["mhsa"], B, T, H, h=h, index=pk.get("index"))
         x = convmod_forward(x, pk["conv"], B, T)
         if not want16 and _ffn_fusable(x, pk["ff2"]):
             return ffn_forward_ln(x, pk["ff2"], pk["fn_w"], pk["fn_b"], True, False)[1]
         x = ffn_forward(x, pk["ff2"])
     else:
         x = ffn_forward(x32, pk["ff1"])
-        x = mhsa_forward(x, pk["mhsa"], B, T, H)
+        x = mhsa_forward(x, pk["mhsa"], B, T, H, index=pk.get("index"))
         x = convmod_forward(x, pk["conv"], B, T)
         x = ffn_forward(x, pk["ff2"])
     out = torch.empty_like(x)
@@ -255,20 +271,24 @@ def block_forward(x32, pk, B, T, H, want16=False):
 
 def pack_complex_conformer(sd, num_blocks, num_heads=4):
     nf2 = sd["input_proj.weight"].shape[1]
-    return {"in": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"],
-                                  k_pad_to=ops.round_up(nf2, 64)),
-            "out": ops.pack_linear(sd["output_proj.weight"], sd["output_proj.bias"]),
-            "blocks": [pack_block(sub(sd, "blocks.%d" % i), num_heads) for i in range(num_blocks)], "nf2": nf2}
+    with ops.stage("front"):
+        win = ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(nf2, 64))
+    with ops.stage("tail"):
+        wout = ops.pack_linear(sd["output_proj.weight"], sd["output_proj.bias"])
+    return {"in": win, "out": wout,
+            "blocks": [pack_block(sub(sd, "blocks.%d" % i), num_heads, i) for i in range(num_blocks)], "nf2": nf2}
 
 
-def complex_conformer_core(x16, pk, B, T, H, out_dtype=torch.float32):
+def complex_conformer_core(x16, pk, B, T, H, out_dtype=None):
     """x16: [M, ld>=round32(2*n_freq)] 16-bit operand of input_proj -> output_proj result [M, 2*n_freq]."""
-    x = ops.linear16(x16, pk["in"], out_dtype=torch.float32)
+    with ops.stage("front"):
+        x = ops.linear16(x16, pk["in"], out_dtype=torch.float32)
     skip = x
     for bp in pk["blocks"]:
         x = block_forward(x, bp, B, T, H)
-    y16 = add_to16(x, skip, x.shape[1])
-    return ops.linear16(y16, pk["out"], out_dtype=out_dtype)
+    with ops.stage("tail"):
+        y16 = add_to16(x, skip, x.shape[1])
+        return ops.linear16(y16, pk["out"], out_dtype=out_dtype or ops.compute_dtype())
 
 
 def complex_conformer_forward(stft_real, stft_imag, pk, H):
@@ -277,10 +297,11 @@ def complex_conformer_forward(stft_real, stft_imag, pk, H):
     M = B * T
     sr, si = stft_real.contiguous(), stft_imag.contiguous()
     ld = pk["in"].Kpad
-    x16 = torch.empty(M, ld, device=sr.device, dtype=ops.compute_dtype())
-    ops.convert_rows(sr, x16, M, nf, nf, nf, ld)
-    ops.convert_rows(si, x16[:, nf:], M, nf, ld - nf, nf, ld)
-    y = complex_conformer_core(x16, pk, B, T, H).reshape(B, T, 2 * nf)
+    with ops.stage("front"):
+        x16 = torch.empty(M, ld, device=sr.device, dtype=ops.compute_dtype())
+        ops.convert_rows(sr, x16, M, nf, nf, nf, ld)
+        ops.convert_rows(si, x16[:, nf:], M, nf, ld - nf, nf, ld)
+    y = complex_conformer_core(x16, pk, B, T, H, out_dtype=torch.float32).reshape(B, T, 2 * nf)
     return y[..., :nf], y[..., nf:]
 
 
@@ -288,6 +309,11 @@ def complex_conformer_forward(stft_real, stft_imag, pk, H):
 # PerceptionAgent (agents/perception.py:216-251)
 # ---------------------------------------------------------------------------
 def pack_perception(sd, sample_rate):
+    with ops.stage("pa"):
+        return _pack_perception(sd, sample_rate)
+
+
+def _pack_perception(sd, sample_rate):
     pk = {"fs": float(sample_rate)}
     for k in ("low_hz_", "band_hz_", "window", "n_"):
         pk[k] = _f32(sd["sinc_conv." + k]).reshape(-1)
@@ -332,6 +358,11 @@ def _conv_gn(x16, pw, B, Lin, stride, pad, groups, raw_dtype):
 
 def perception_forward(wave, pk, keep_sinc=False, latents=True):
     """wave [B, L] fp32 -> zcat [B, T_pa, 2D] fp32 (z_real | z_imag, channels-last), sigma [B, T_pa] fp32."""
+    with ops.stage("pa"):
+        return _perception_forward(wave, pk, keep_sinc, latents)
+
+
+def _perception_forward(wave, pk, keep_sinc, latents):
     dt = ops.compute_dtype()
     wave = wave.contiguous()
     B, L = wave.shape
@@ -394,6 +425,11 @@ def perception_forward(wave, pk, keep_sinc=False, latents=True):
 # CPEA (agents/cpea.py:79-112)
 # ---------------------------------------------------------------------------
 def pack_cpea(sd, num_layers=2):
+    with ops.stage("front"):
+        return _pack_cpea(sd, num_layers)
+
+
+def _pack_cpea(sd, num_layers):
     pk = {"layers": [], "H": sd["lstm.weight_hh_l0"].shape[1]}
     for l in range(num_layers):
         wih = torch.cat([sd["lstm.weight_ih_l%d" % l], sd["lstm.weight_ih_l%d_reverse" % l]], dim=0)
@@ -412,6 +448,11 @@ def pack_cpea(sd, num_layers=2):
 def cpea_forward(z16, pk, B, T, out=None):
     """z16: [B*T, ld] 16-bit rows whose first input_dim columns are the latent ->
     [B*T, 4*oc] (rho_s | rho_n | phi1 | phi2); `out` may be a strided 16-bit/fp32 view."""
+    with ops.stage("front"):
+        return _cpea_forward(z16, pk, B, T, out)
+
+
+def _cpea_forward(z16, pk, B, T, out):
     H = pk["H"]
     M = B * T
     dt = ops.compute_dtype()
@@ -442,37 +483,47 @@ def pack_memory_params(sd):
 # MaskSynthesisAgent (agents/msa.py:106-174)
 # ---------------------------------------------------------------------------
 def pack_msa(sd, num_blocks, num_heads=4):
-    return {"f0": ops.pack_linear(sd["fusion.0.weight"], sd["fusion.0.bias"], k_pad_to=FUSE_LD),
-            "f1w": _f32(sd["fusion.1.weight"]), "f1b": _f32(sd["fusion.1.bias"]),
-            "f3": ops.pack_linear(sd["fusion.3.weight"], sd["fusion.3.bias"]),
-            "f4w": _f32(sd["fusion.4.weight"]), "f4b": _f32(sd["fusion.4.bias"]),
-            "conf": pack_complex_conformer(sub(sd, "conformer"), num_blocks, num_heads),
-            "r0": ops.pack_linear(sd["mask_proj_real.0.weight"], sd["mask_proj_real.0.bias"]),
-            "r2": ops.pack_linear(sd["mask_proj_real.2.weight"], sd["mask_proj_real.2.bias"]),
-            "i0": ops.pack_linear(sd["mask_proj_imag.0.weight"], sd["mask_proj_imag.0.bias"]),
-            "i2": ops.pack_linear(sd["mask_proj_imag.2.weight"], sd["mask_proj_imag.2.bias"]),
-            "d_model": sd["fusion.3.weight"].shape[0]}
+    with ops.stage("front"):
+        pk = {"f0": ops.pack_linear(sd["fusion.0.weight"], sd["fusion.0.bias"], k_pad_to=FUSE_LD),
+              "f1w": _f32(sd["fusion.1.weight"]), "f1b": _f32(sd["fusion.1.bias"]),
+              "f3": ops.pack_linear(sd["fusion.3.weight"], sd["fusion.3.bias"]),
+              "f4w": _f32(sd["fusion.4.weight"]), "f4b": _f32(sd["fusion.4.bias"])}
+    pk["conf"] = pack_complex_conformer(sub(sd, "conformer"), num_blocks, num_heads)
+    with ops.stage("tail"):
+        pk.update({"r0": ops.pack_linear(sd["mask_proj_real.0.weight"], sd["mask_proj_real.0.bias"]),
+                   "r2": ops.pack_linear(sd["mask_proj_real.2.weight"], sd["mask_proj_real.2.bias"]),
+                   "i0": ops.pack_linear(sd["mask_proj_imag.0.weight"], sd["mask_proj_imag.0.bias"]),
+                   "i2": ops.pack_linear(sd["mask_proj_imag.2.weight"], sd["mask_proj_imag.2.bias"])})
+    pk["d_model"] = sd["fusion.3.weight"].shape[0]
+    return pk
 
 
 def msa_logits(fused16, pk, B, T, H):
     """fused16 [M, FUSE_LD] 16-bit (the 8-way concat of agents/msa.py:140, zero padded)
     -> magnitude / phase logits [M, 129] fp32 each."""
     D = pk["d_model"]
-    h = ops.linear16(fused16, pk["f0"], out_dtype=torch.float32)
-    h16 = _ln16(h, pk["f1w"], pk["f1b"], act=1)
-    h = ops.linear16(h16, pk["f3"], out_dtype=torch.float32)
-    hf16 = _ln16(h, pk["f4w"], pk["f4b"])
-    y16 = complex_conformer_core(hf16, pk["conf"], B, T, H, out_dtype=ops.compute_dtype())   # [M, D]: mask_r | mask_i
+    with ops.stage("front"):
+        h = ops.linear16(fused16, pk["f0"], out_dtype=torch.float32)
+        h16 = _ln16(h, pk["f1w"], pk["f1b"], act=1)
+        h = ops.linear16(h16, pk["f3"], out_dtype=torch.float32)
+        hf16 = _ln16(h, pk["f4w"], pk["f4b"])
+    y16 = complex_conformer_core(hf16, pk["conf"], B, T, H)   # [M, D]: mask_r | mask_i, 16-bit in the tail's format
     half = D // 2
-    gr = ops.linear16(y16[:, :half], pk["r0"], epi=ops.EPI_GELU)
-    lm = ops.linear16(gr, pk["r2"], out_dtype=torch.float32)
-    gi = ops.linear16(y16[:, half:], pk["i0"], epi=ops.EPI_GELU)
-    lp = ops.linear16(gi, pk["i2"], out_dtype=torch.float32)
+    with ops.stage("tail"):
+        gr = ops.linear16(y16[:, :half], pk["r0"], epi=ops.EPI_GELU)
+        lm = ops.linear16(gr, pk["r2"], out_dtype=torch.float32)
+        gi = ops.linear16(y16[:, half:], pk["i0"], epi=ops.EPI_GELU)
+        lp = ops.linear16(gi, pk["i2"], out_dtype=torch.float32)
     return lm, lp
 
 
 def msa_pack_inputs(z_real, z_imag, cpea, noisy_real, noisy_imag):
     """Module-API inputs (reference layouts) -> fused 16-bit operand [B*T, FUSE_LD]."""
+    with ops.stage("front"):
+        return _msa_pack_inputs(z_real, z_imag, cpea, noisy_real, noisy_imag)
+
+
+def _msa_pack_inputs(z_real, z_imag, cpea, noisy_real, noisy_imag):
     B, D, T = z_real.shape
     M = B * T
     dev = z_real.device
@@ -512,7 +563,7 @@ def msa_forward(z_real, z_imag, cpea, noisy_real, noisy_imag, pk, H, mag_bias=No
 def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     """wave [B, L] fp32 -> dict(mask_real, mask_imag [B,T,129], enhanced [B,L], ...).
     packs: dict(pa=, cpea=, msa=[, memory=(params, kd, vd, slots, temp)])."""
-    dt = ops.compute_dtype()
+    dt = ops.stage_dtype("front")
     wave = wave.contiguous()
     B, L = wave.shape
     dev = wave.device
@@ -525,12 +576,14 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     zsrc, zsc, zsh = (zcat, None, None) if want_lat else zcat
     Tpa = zsrc.shape[1]
     fused = torch.empty(M, FUSE_LD, device=dev, dtype=dt)
-    ops.pool_time(zsrc, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD, scale=zsc, shift=zsh)   # G1 -> fused[:, :2D]
+    with ops.stage("front"):
+        ops.pool_time(zsrc, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD, scale=zsc, shift=zsh)   # G1 -> fused[:, :2D]
     oc4 = 4 * packs["cpea"]["oc"]
     cpea_forward(fused, packs["cpea"], B, T, out=fused[:, 2 * D:2 * D + oc4])   # CPEA(z_real pooled) -> fused cols
     nr, ni = stft(wave)
     col = 2 * D + oc4
-    ops.stft_lognorm_pack(nr, ni, fused[:, col:], M, N_FREQ, FUSE_LD - col - 2 * N_FREQ, FUSE_LD)
+    with ops.stage("front"):
+        ops.stft_lognorm_pack(nr, ni, fused[:, col:], M, N_FREQ, FUSE_LD - col - 2 * N_FREQ, FUSE_LD)
     bias = None
     out = {}
     if use_memory:

@@ -34,6 +34,7 @@ SIGNATURES = {
     "sfm_framed_gemm_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i,
                             c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_vp],
     "sfm_attention_fwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_vp],
+    "sfm_attention_fwd_ex": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_i, c_vp],
     "sfm_layernorm": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_vp],
     "sfm_gn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_f, c_vp],
     "sfm_gn_apply": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp],

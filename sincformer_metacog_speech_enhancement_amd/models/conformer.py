@@ -9,7 +9,7 @@ reference lines they replace.
 import torch
 from torch import nn
 
-from .. import config, functional as Fn
+from .. import config, functional as Fn, ops
 from .._hostmod import HipModule
 
 
@@ -42,9 +42,10 @@ class FeedForwardModule(HipModule):
         self._require_device(x)
         if self.training or self._wants_autograd(x):
             return _submodule_autograd(self, "ffn", x, 1, self.dropout.p, None)
-        pk = self._packed(Fn.pack_ffn)
-        shp = x.shape
-        y = Fn.ffn_forward(x.float().reshape(-1, shp[-1]).contiguous(), pk)
+        with ops.stage("block"):
+            pk = self._packed(Fn.pack_ffn)
+            shp = x.shape
+            y = Fn.ffn_forward(x.float().reshape(-1, shp[-1]).contiguous(), pk)
         return y.reshape(shp)
 
 
@@ -62,9 +63,10 @@ class MultiHeadSelfAttention(HipModule):
         self._require_device(x)
         if self.training or self._wants_autograd(x):
             return _submodule_autograd(self, "mhsa", x, self.num_heads, self.dropout.p, None)
-        pk = self._packed(lambda sd: Fn.pack_mhsa(sd, self.num_heads))
-        B, T, D = x.shape
-        y = Fn.mhsa_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T, self.num_heads)
+        with ops.stage("block"):
+            pk = self._packed(lambda sd: Fn.pack_mhsa(sd, self.num_heads))
+            B, T, D = x.shape
+            y = Fn.mhsa_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T, self.num_heads)
         return y.reshape(B, T, D)
 
 
@@ -84,9 +86,10 @@ class ConvolutionModule(HipModule):
         self._require_device(x)
         if self.training or self._wants_autograd(x):
             return _submodule_autograd(self, "conv", x, 1, self.dropout.p, self.batch_norm)
-        pk = self._packed(Fn.pack_convmod)
-        B, T, D = x.shape
-        y = Fn.convmod_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T)
+        with ops.stage("block"):
+            pk = self._packed(Fn.pack_convmod)
+            B, T, D = x.shape
+            y = Fn.convmod_forward(x.float().reshape(B * T, D).contiguous(), pk, B, T)
         return y.reshape(B, T, D)
 
 

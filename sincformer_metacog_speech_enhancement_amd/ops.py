@@ -21,14 +21,105 @@ def set_gemm_variant(v):
 
 
 
-def set_compute_dtype(dt):
-    """16-bit MFMA operand/activation format: torch.bfloat16 (default) or torch.float16."""
+_DT_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16,
+             "float16": torch.float16}
+# Inference stages of the path whose 16-bit operand format can be chosen separately (the boundaries between them are
+# fp32 tensors, so no stage reads another stage's 16-bit data in the wrong format):
+#   pa    PerceptionAgent convs (inputs are GroupNorm + GELU outputs, the sinc FIR output is bounded by the waveform)
+#   front CPEA, the fused 1026-column operand, fusion MLP, input projections
+#   block the Linear / Conv1d GEMMs of the Conformer blocks (operands are LayerNorm outputs or bounded activations)
+#   attn  the Q | K | V buffer and the attention core (QK^T, softmax, PV), head_dim 64 kernels
+#   tail  output projection and the mask heads
+STAGES = ("pa", "front", "block", "attn", "tail")
+POLICIES = {
+    "bf16": {s: torch.bfloat16 for s in STAGES},
+    "fp16": {s: torch.float16 for s in STAGES},
+    # default of inference: measured per-stage error budget in profiles/r02/precision_probe.json
+    # (bf16 everywhere misses the 1e-3 mask bound: 1.3-1.6e-3; a bf16 PerceptionAgent alone costs 6.5e-4 of it; with the
+    # attention core in bf16 and fp16 elsewhere the whole path is at 3e-4)
+    "mixed": {"pa": torch.float16, "front": torch.float16, "block": torch.float16, "attn": torch.bfloat16,
+              "tail": torch.float16},
+}
+_state["policy"] = dict(POLICIES["mixed"])          # inference default; training uses the base dtype (bf16)
+_state["policy_name"] = "mixed"
+
+
+def reset_precision():
+    """the defaults: base (training) format bf16, inference stages per POLICIES["mixed"]"""
+    _state["dtype"] = torch.bfloat16
+    _state["policy"] = dict(POLICIES["mixed"])
+    _state["policy_name"] = "mixed"
+
+
+def _as_dtype(dt):
     if isinstance(dt, str):
-        dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16,
-              "float16": torch.float16}[dt]
+        dt = _DT_NAMES[dt]
     if dt not in _DT_ID:
         raise ValueError("compute dtype must be bfloat16 or float16")
+    return dt
+
+
+def set_compute_dtype(dt):
+    """16-bit MFMA operand/activation format for EVERYTHING (training and every inference stage):
+    torch.bfloat16 or torch.float16.  See set_precision_policy for the per-stage recipe of inference."""
+    dt = _as_dtype(dt)
     _state["dtype"] = dt
+    _state["policy"] = {s: dt for s in STAGES}
+    _state["policy_name"] = "bf16" if dt is torch.bfloat16 else "fp16"
+
+
+def set_precision_policy(policy):
+    """Operand format per inference stage: a name of POLICIES ("bf16", "fp16", "mixed") or a dict stage -> dtype
+    (keys of STAGES; "block3" / "attn3" override one Conformer block).  Training keeps the base dtype."""
+    if isinstance(policy, str):
+        name, pol = policy, dict(POLICIES[policy])
+    else:
+        pol = dict(POLICIES["bf16"])
+        pol.update({k: _as_dtype(v) for k, v in policy.items()})
+        name = "custom:" + ",".join("%s=%s" % (k, "bf16" if v is torch.bfloat16 else "fp16") for k, v in sorted(pol.items()))
+    _state["policy"] = pol
+    _state["policy_name"] = name
+
+
+def policy_name():
+    return _state["policy_name"]
+
+
+_state["weights_gen"] = 0
+
+
+def bump_weights_generation():
+    """Called by optimisers that update parameters through storage the parameter's own version counter does not see
+    (optim.FlatAdamW steps a flat buffer the parameters are views of): invalidates every packed-weight cache."""
+    _state["weights_gen"] += 1
+
+
+def policy_key():
+    """hashable signature of (base dtype, per-stage formats, weights generation): part of every packed-weight cache key"""
+    return (_state["dtype"], _state["weights_gen"]) + tuple(sorted((k, str(v)) for k, v in _state["policy"].items()))
+
+
+def stage_dtype(name, index=None):
+    pol = _state["policy"]
+    if index is not None and (name + str(index)) in pol:
+        return pol[name + str(index)]
+    return pol[name]
+
+
+class stage:
+    """with ops.stage("block", 3): ... — kernels and packs inside use that stage's operand format"""
+
+    def __init__(self, name, index=None):
+        self.dt = stage_dtype(name, index)
+
+    def __enter__(self):
+        self.prev = _state["dtype"]
+        _state["dtype"] = self.dt
+        return self
+
+    def __exit__(self, *exc):
+        _state["dtype"] = self.prev
+        return False
 
 
 def compute_dtype():
@@ -241,7 +332,12 @@ def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda
     L = _lib.load()
     cin = pw.cin
     lda = cin if lda is None else lda
-    out_f32 = 1 if out.dtype == torch.float32 else 0
+    # out_f32: 0 = 16-bit in the operands' format, 1 = fp32, 2 = the OTHER 16-bit format (a stage boundary of the precision
+    # policy, e.g. the Q | K | V buffer of a bf16 attention core behind fp16 projections): one rounding of the fp32 accumulators
+    out_f32 = 1 if out.dtype == torch.float32 else (0 if out.dtype == _state["dtype"] else 2)
+    if A.dtype != _state["dtype"] or pw.w.dtype != _state["dtype"]:
+        raise RuntimeError("gemm16: operand formats %s / %s do not match the stage's %s (precision policy)" %
+                           (A.dtype, pw.w.dtype, _state["dtype"]))
     if p_drop > 0.0:                                   # training forward: residual-branch dropout in the epilogue
         _call("gemm16", L.sfm_gemm16_train, (_p(A), _p(pw.w), _p(pw.bias), _p(out), _p(resid), _p(gn_partial), B, Lout, Lin, cin,
                                              lda, pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo,
@@ -337,17 +433,20 @@ def set_attention_variant(v):
     _lib.check(_lib.load().sfm_attention_set_variant(int(v)), "attention_set_variant")
 
 
-def attention(qkv16, B, T, H, hd, out=None, prescaled=False):
+def attention(qkv16, B, T, H, hd, out=None, prescaled=False, out_dtype=None):
     """qkv16 [B*T, 3*H*hd] (q | k | v) -> [B*T, H*hd].  prescaled: q already multiplied by
     log2(e)/sqrt(hd) (functional.pack_mhsa folds it into W_q, b_q before the 16-bit rounding)."""
     _need_dev(qkv16)
     L = _lib.load()
     D = H * hd
     ld = qkv16.stride(0)
+    if qkv16.dtype != _state["dtype"]:
+        raise RuntimeError("attention: Q | K | V are %s, the stage's format is %s" % (qkv16.dtype, _state["dtype"]))
     if out is None:
-        out = torch.empty(B * T, D, device=qkv16.device, dtype=qkv16.dtype)
-    _call("attention_fwd", L.sfm_attention_fwd, (_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld, T * out.stride(0),
-                             (-1.0 if prescaled else 1.0 / math.sqrt(hd)), _dt(), _stream()),
+        out = torch.empty(B * T, D, device=qkv16.device, dtype=out_dtype or qkv16.dtype)
+    _call("attention_fwd", L.sfm_attention_fwd_ex, (_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld,
+                                                    T * out.stride(0), (-1.0 if prescaled else 1.0 / math.sqrt(hd)), _dt(),
+                                                    _DT_ID[out.dtype], _stream()),
           *_cost_of("attention_fwd", locals()))
     return out
 

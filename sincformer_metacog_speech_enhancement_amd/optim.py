@@ -48,8 +48,11 @@ class FlatAdamW:
         self._bump_versions()                         # packed-weight caches key on the parameters' version counter
 
     def _bump_versions(self):
-        # an in-place no-op on the flat buffer bumps the version of every parameter view (they share its counter)
+        # The parameters were rebound to views of flat_p (`p.data = ...`), which gives each of them its OWN version
+        # counter: an in-place op on flat_p does not bump it.  The packed-weight caches therefore also key on a global
+        # weights generation (ops.policy_key), advanced here; the in-place no-op keeps flat_p's own counter honest.
         self.flat_p.add_(0.0)
+        ops.bump_weights_generation()
 
     def stats(self):
         """host sync: {'step', 'grad_norm', 'skipped'} of the last step."""

@@ -54,11 +54,15 @@ class SpeechEnhancer(HipModule):
         F2 = 2 * self.n_freq
         heads_w = torch.cat([sd["mag_head.weight"], sd["phase_head.weight"]], dim=0)
         heads_b = torch.cat([sd["mag_head.bias"], sd["phase_head.bias"]], dim=0)
+        with ops.stage("front"):
+            proj = ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(F2, 64))
+        with ops.stage("tail"):
+            heads = ops.pack_linear(heads_w, heads_b)
         return {"in_w": sd["input_norm.weight"].float().contiguous(), "in_b": sd["input_norm.bias"].float().contiguous(),
-                "proj": ops.pack_linear(sd["input_proj.weight"], sd["input_proj.bias"], k_pad_to=ops.round_up(F2, 64)),
-                "blocks": [Fn.pack_block(Fn.sub(sd, "blocks.%d" % i), self.num_heads) for i in range(self.num_blocks)],
+                "proj": proj,
+                "blocks": [Fn.pack_block(Fn.sub(sd, "blocks.%d" % i), self.num_heads, i) for i in range(self.num_blocks)],
                 "on_w": sd["output_norm.weight"].float().contiguous(), "on_b": sd["output_norm.bias"].float().contiguous(),
-                "heads": ops.pack_linear(heads_w, heads_b)}
+                "heads": heads}
 
     def _train_forward(self, noisy_real, noisy_imag):
         """train() mode: same graph built from autograd nodes whose forward AND backward are HIP kernels
@@ -94,13 +98,15 @@ class SpeechEnhancer(HipModule):
         cat = torch.empty(M, ldc, device=dev, dtype=torch.float32)
         ops.pack_spec(nr, ni, cat, M, F, ldc, F)
         ld16 = pk["proj"].Kpad
-        x16 = torch.zeros(M, ld16, device=dev, dtype=ops.compute_dtype())
-        ops.layernorm(cat, pk["in_w"], pk["in_b"], out16=x16)            # D = 2F columns, pad stays zero
-        x = ops.linear16(x16, pk["proj"], out_dtype=torch.float32)
+        with ops.stage("front"):
+            x16 = torch.zeros(M, ld16, device=dev, dtype=ops.compute_dtype())
+            ops.layernorm(cat, pk["in_w"], pk["in_b"], out16=x16)            # D = 2F columns, pad stays zero
+            x = ops.linear16(x16, pk["proj"], out_dtype=torch.float32)
         for bp in pk["blocks"]:
             x = Fn.block_forward(x, bp, B, T, self.num_heads)
-        h16 = Fn._ln16(x, pk["on_w"], pk["on_b"])
-        logits = ops.linear16(h16, pk["heads"], out_dtype=torch.float32)   # [M, 2F] = mag | phase
+        with ops.stage("tail"):
+            h16 = Fn._ln16(x, pk["on_w"], pk["on_b"])
+            logits = ops.linear16(h16, pk["heads"], out_dtype=torch.float32)   # [M, 2F] = mag | phase
         er = torch.empty(B, T, F, device=dev, dtype=torch.float32)
         ei = torch.empty(B, T, F, device=dev, dtype=torch.float32)
         mm = torch.empty(B, T, F, device=dev, dtype=torch.float32)
@@ -163,7 +169,7 @@ class EnhancementPath(HipModule):
         return packs
 
     def _pack_key(self):
-        return tuple([ops.compute_dtype()] + [(p.data_ptr(), p._version) for p in self.parameters()] +
+        return tuple([ops.policy_key()] + [(p.data_ptr(), p._version) for p in self.parameters()] +
                      [(b.data_ptr(), b._version) for n, b in self.named_buffers() if "usage" not in n and "num_queries" not in n])
 
     def freeze_perception(self, flag=True):

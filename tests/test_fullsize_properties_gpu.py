@@ -19,7 +19,7 @@ B, L = 64, 64000
 def path_and_out():
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
-    ops.set_compute_dtype(torch.float16)
+    ops.reset_precision()                 # the bench's operand formats (default policy "mixed": ops.POLICIES)
     sds = {"pa": synth_sd("PerceptionAgent", 291, sinc_scale=2000.0), "cpea": synth_sd("CorrelationPhaseEstimationAgent", 292),
            "msa": synth_sd("MaskSynthesisAgent", 293)}
     path = EnhancementPath(sample_rate=16000)
@@ -116,7 +116,7 @@ def test_training_backward_directional_derivative_at_full_size():
     backward is checked on identical inputs in tests/test_train_gpu.py."""
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft
-    ops.set_compute_dtype(torch.float16)
+    ops.reset_precision()                 # training runs in the base format (bf16), as bench.py --workload c3se does
     Bt, Lt = 256, 64000
     model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.0)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -142,7 +142,7 @@ def test_path_backward_directional_derivative_at_full_size():
     the enhanced spectrum"""
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
-    ops.set_compute_dtype(torch.float16)
+    ops.reset_precision()                 # the bench's operand formats (default policy "mixed": ops.POLICIES)
     path = EnhancementPath(sample_rate=16000)
     path.perception.load_state_dict(synth_sd("PerceptionAgent", 291, sinc_scale=2000.0))
     path.cpea.load_state_dict(synth_sd("CorrelationPhaseEstimationAgent", 292))
@@ -177,7 +177,7 @@ def test_long_utterances_with_memory_vs_oracle_and_batch_independence():
     full 6001 x 6001 score matrix on the CPU), bounds, and independence of the other utterances of the batch."""
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
-    ops.set_compute_dtype(torch.float16)
+    ops.reset_precision()                 # the bench's operand formats (default policy "mixed": ops.POLICIES)
     Bl, Ll = 3, 480000
     sds = {"pa": synth_sd("PerceptionAgent", 391, sinc_scale=2000.0), "cpea": synth_sd("CorrelationPhaseEstimationAgent", 392),
            "msa": synth_sd("MaskSynthesisAgent", 393), "memory": synth_sd("EpisodicMemory", 394)}

@@ -12,7 +12,8 @@ ap.add_argument("--frames", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--variant", type=int, default=0, help="0: auto by T, 1: 32 q rows/wave, 2: 64 q rows/wave (pipelined)")
+ap.add_argument("--variant", type=int, default=0, help="0: auto by T, 1: 32 q rows/wave, 2: 64 q rows/wave (pipelined), 3: persistent ring kernel")
+ap.add_argument("--check", action="store_true", help="compare with the 32-rows-per-wave kernel (variant 1) and fp32 torch on one (b, h)")
 a = ap.parse_args()
 ops.set_compute_dtype(a.dtype)
 ops.set_attention_variant(a.variant)
@@ -23,6 +24,18 @@ out = torch.empty(B * T, H * hd, device="cuda", dtype=ops.compute_dtype())
 for _ in range(3):
     ops.attention(qkv, B, T, H, hd, out=out)
 torch.cuda.synchronize()
+if a.check:
+    ops.set_attention_variant(1)
+    ref = ops.attention(qkv, B, T, H, hd)
+    ops.set_attention_variant(a.variant)
+    torch.cuda.synchronize()
+    d = (out.float() - ref.float()).abs()
+    q, k, v = [t.float().reshape(B, T, H, hd) for t in qkv.split(H * hd, dim=1)]
+    bi, hi = B - 1, H - 1
+    p = torch.softmax(q[bi, :, hi] @ k[bi, :, hi].t() / hd ** 0.5, dim=-1) @ v[bi, :, hi]
+    e = (out.float().reshape(B, T, H, hd)[bi, :, hi] - p).abs().max()
+    print("check: max |variant %d - variant 1| = %.3e (mean %.3e); max |out - fp32 softmax| on (b=%d, h=%d) = %.3e, finite %s" %
+          (a.variant, float(d.max()), float(d.mean()), bi, hi, float(e), bool(torch.isfinite(out.float()).all())), file=sys.stderr)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.iters):
@@ -31,5 +44,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 fl = 4.0 * B * H * T * T * hd
-print(json.dumps({"kernel": "attn_fwd_hd64x2" if (a.variant == 2 or (a.variant == 0 and a.frames >= 1024)) else "attn_fwd_hd64", "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
+print(json.dumps({"kernel": "attn_fwd_hd64r" if (a.variant == 3 or (a.variant == 0 and 256 < a.frames <= 512 and B * H >= 256)) else "attn_fwd_hd64x2" if (a.variant == 2 or (a.variant == 0 and a.frames >= 1024)) else "attn_fwd_hd64", "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
                   "tflops": fl / ms / 1e9, "frac_of_2.5PF": fl / ms / 1e9 / 2500.0}))
