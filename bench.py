@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path on MI355X (contract: see the round prompt / DESIGN.md §Measurement).
+"""Benchmark of the hot path on MI355X (contract: see the round prompt / DESIGN.md section 7).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3p|c1|c5|c3se|c2t] [--dtype bf16|f16] [--streams S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3p|c1|c5|c3se|c2t|c3t] [--dtype mixed|bf16|f16]
+                    [--streams S]
 
-A step = one forward pass of the north-star path (PerceptionAgent -> pool -> CPEA -> STFT ->
-MaskSynthesisAgent -> apply_mask -> iSTFT) over one batch of synthetic 16 kHz utterances that is
-already resident in HBM.  Default workload = BASELINE.json configs[1]: batch 64 x 4 s (L = 64 000,
-T = 801 STFT frames/utterance), forward only, bf16 MFMA operands with fp32 accumulation.
+A step = one forward pass of the north-star path (PerceptionAgent -> pool -> CPEA -> STFT -> MaskSynthesisAgent ->
+apply_mask -> iSTFT) over one batch of synthetic 16 kHz utterances that is already resident in HBM.  Default workload =
+BASELINE.json configs[1]: batch 64 x 4 s (L = 64 000, T = 801 STFT frames / utterance), forward only, 16-bit MFMA operands
+(default policy "mixed": fp16 GEMM operands, bf16 attention core) with fp32 accumulation.
 value = STFT frames/s over all ranks (utterances shard over ranks: no data-path collective).
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+
+Launching: `python bench.py --gpus N` with no torchrun environment starts the N ranks itself (child processes, before this
+process touches the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the
+launcher's.  A --gpus that disagrees with WORLD_SIZE is an error.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel family, HIP-event timed inside the timed region, plus the same
+launches in strictly sequential passes), `mask_rmse` (one utterance against the CPU oracle, outside the timed region),
+`headline` (BASELINE's metric shape: batch 256 x 512-frame utterances, and the attention kernel alone at that shape) and
+`cpu_baseline` (the oracle on the host cores, bounded sample, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,18 +40,36 @@ WORKLOADS = {
     "c2t": (64, 64000, "B64 x 4 s (L64000, T801) SincNet+Conformer path (PerceptionAgent, CPEA, MaskSynthesisAgent) training "
                        "step: forward, SI-SNR + L1 + multi-res STFT objective, backward through every module, all-reduce, "
                        "clip, AdamW"),
+    "c3t": (256, 64000, "B256 x 4 s (L64000, T801) SincNet+Conformer path (PerceptionAgent, CPEA, MaskSynthesisAgent) training "
+                        "step: forward, SI-SNR + L1 + multi-res STFT objective, backward through every module, all-reduce, "
+                        "clip, AdamW (BASELINE configs[2]/[3] on the north-star composition)"),
     "c5": (32, 480000, "B32 x 30 s (L480000, T6001) forward with episodic memory (BASELINE configs[4], fwd)"),
 }
+TRAIN_WORKLOADS = ("c3se", "c2t", "c3t")
 PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "hbm": 8000.0}      # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
 FAMILY_BOUND = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32", "gemm16_tn": "mfma16",
-                "attention_bwd": "mfma16"}
+                "attention_bwd": "mfma16", "conv16": "mfma16", "ffn_fused": "mfma16"}
+METRIC = "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref"
+DTYPE_DESC = {
+    "mixed": "fp16 MFMA operands (PerceptionAgent, fusion, Conformer GEMMs, heads) + bf16 attention core, fp32 accumulate "
+             "(ops.POLICIES['mixed'])",
+    "bf16": "bf16", "f16": "fp16",
+}
+
+
+def set_precision(dtype):
+    from sincformer_metacog_speech_enhancement_amd import ops
+    if dtype == "mixed":
+        ops.reset_precision()
+    else:
+        ops.set_compute_dtype(dtype)
 
 
 def build_path(dtype, seed=1234, use_memory=False):
     import torch
-    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    from sincformer_metacog_speech_enhancement_amd import synthetic as syn
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
-    ops.set_compute_dtype(dtype)
+    set_precision(dtype)
     path = EnhancementPath(sample_rate=16000, use_memory=use_memory)
     sd = path.state_dict()
     shapes = {k: tuple(v.shape) for k, v in sd.items()}
@@ -68,12 +96,13 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(weights, L, batch=None, iters=4):
-    """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample (about 10 s of CPU work)."""
+def cpu_baseline(weights, L, wave_np, gpu_masks=None, batch=None, iters=4, use_memory=False):
+    """Oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample (about 10-25 s of CPU work):
+    the first `batch` utterances of the bench batch `wave_np` (numpy [B, L]).  gpu_masks: (mask_real, mask_imag) the HIP path produced for utterance 0 of the same synthetic batch -> the oracle's
+    output for that utterance doubles as the parity check of the line (`mask_rmse`)."""
     batch = batch or max(1, min(8, 512000 // L))
     import torch
     from oracle import sfm_oracle as orc
-    from sincformer_metacog_speech_enhancement_amd import synthetic as syn
     cores = host_cores()
     torch.set_num_threads(cores)
 
@@ -81,16 +110,25 @@ def cpu_baseline(weights, L, batch=None, iters=4):
         p = prefix + "."
         return {k[len(p):]: torch.from_numpy(v) for k, v in weights.items() if k.startswith(p)}
     sds = {"pa": subd("perception"), "cpea": subd("cpea"), "msa": subd("msa")}
-    noisy, _ = syn.synth_wave(batch, L, 1234)
-    orc.enhance_path(sds, noisy, 16000)           # warm-up
+    if use_memory:
+        sds["memory"] = subd("memory")
+    batch = min(batch, wave_np.shape[0])
+    noisy = wave_np[:batch]
+    ref = orc.enhance_path(sds, noisy, 16000, use_memory=use_memory)           # warm-up (and the parity reference)
+    rm = None
+    if gpu_masks is not None:
+        got = torch.cat([gpu_masks[0], gpu_masks[1]], -1).double()
+        want = torch.cat([ref["mask_real"][:1], ref["mask_imag"][:1]], -1).double()
+        rm = float(((got - want) ** 2).mean().sqrt())
     t0 = time.perf_counter()
     for _ in range(iters):
-        orc.enhance_path(sds, noisy, 16000)
+        orc.enhance_path(sds, noisy, 16000, use_memory=use_memory)
     dt = (time.perf_counter() - t0) / iters
     T = 1 + L // 80
-    return {"value": batch * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    base = {"value": batch * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "oracle enhance_path, batch %d x L%d, %d iterations after 1 warm-up, fp32, torch %d threads"
                       % (batch, L, iters, cores)}
+    return base, rm
 
 
 def cpu_baseline_train(sd, L, iters=8, batch=8):
@@ -148,37 +186,104 @@ def cpu_baseline_path_train(weights, L, iters=3, batch=4):
                       "iterations, %.1f s each; no optimiser step" % (batch, L, iters, dt)}
 
 
-def main_train(args):
-    """--workload c3se / c2t: one training step of training/conformer_pipeline.py per bench step (c3se: the reference's
-    SpeechEnhancer; c2t: the north-star SincNet + Conformer composition)."""
+# ---------------------------------------------------------------------------------------------------------------
+# launching
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as child processes (this process has not touched the
+    GPU and never will), pass rank 0's line through, exit with the worst return code."""
+    n = args.gpus
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SFM_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
+
+
+def init_ranks(args):
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     torch.cuda.set_device(0 if os.environ.get("SFM_SINGLE_DEVICE") else local_rank)   # rehearsal of N ranks on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("SFM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    return rank, world
+
+
+def roofline_of(dominant, dom, traffic_src=None):
+    kind = FAMILY_BOUND.get(dominant, "hbm")
+    secs = dom["ms_avg"] * 1e-3
+    if kind == "hbm":
+        ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
+    else:
+        ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
+    r = {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+         "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
+         "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]}
+    if traffic_src and os.path.exists(os.path.join(ROOT, traffic_src)):
+        t = json.load(open(os.path.join(ROOT, traffic_src))).get(dominant, {}).get("hbm_bytes_per_launch")
+        if t is not None:
+            r.update({"traffic": t, "traffic_unit": "HBM bytes/launch",
+                      "traffic_source": "NOT measured in this run: read from %s = committed rocprofv3 --pmc FETCH_SIZE / "
+                                        "WRITE_SIZE passes of this command (FETCH_SIZE doubled per the gfx950 note)" % traffic_src})
+    return r
+
+
+def traffic_file(workload):
+    for d in ("profiles/r02", "profiles"):
+        p = "%s/pmc_traffic_%s.json" % (d, workload)
+        if os.path.exists(os.path.join(ROOT, p)):
+            return p
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training workloads
+# ---------------------------------------------------------------------------------------------------------------
+def main_train(args):
+    """--workload c3se / c2t / c3t: one training step of training/conformer_pipeline.py per bench step (c3se: the reference's
+    SpeechEnhancer; c2t / c3t: the north-star SincNet + Conformer composition at B 64 / B 256)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = init_ranks(args)
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
     from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
-    ops.set_compute_dtype(args.dtype)
+    dtype = "bf16" if args.dtype == "mixed" else args.dtype          # training runs in ONE base format
+    ops.set_compute_dtype(dtype)
     B, L, desc = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
     T = 1 + L // 80
-    whole_path = args.workload == "c2t"
+    whole_path = args.workload in ("c2t", "c3t")
     if whole_path:
         from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import compute_path_loss
-        model, sd = build_path(args.dtype, seed=4321)
+        model, sd = build_path(dtype, seed=4321)
     else:
         model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, 4321).items()}
         model.load_state_dict(sd)                                   # same weights on every rank
     model.cuda().train()
-    opt = FlatAdamW(model.parameters(), lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0)
+    # the objective's graph does not reach the uncertainty head (sigma feeds no loss on the path): like torch.optim.AdamW,
+    # which skips parameters whose grad is None, the flat optimiser is built from the parameters that are trained
+    params = [p_ for n_, p_ in model.named_parameters() if "uncertainty_head" not in n_]
+    opt = FlatAdamW(params, lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0)
     noisy, clean = syn.synth_wave(B, L, 1234 + rank)                # each rank trains on its own utterance shard
     noisy, clean = torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda()
     torch.manual_seed(1000 + rank)                                  # dropout seeds
@@ -203,9 +308,10 @@ def main_train(args):
         torch.cuda.synchronize()
 
     if rank == 0:
-        print("[bench] %s, dtype %s, world %d, batch/GPU %d" % (desc, args.dtype, world, B), file=sys.stderr, flush=True)
+        print("[bench] %s, dtype %s, world %d, batch/GPU %d" % (desc, dtype, world, B), file=sys.stderr, flush=True)
     for i in range(max(args.warmup, 1)):
         if i == max(args.warmup, 1) - 1:
+            torch.cuda.synchronize()                                # the instrumented step runs alone on the device
             ops.profiler.enable(None)
         loss = step()
     breakdown = ops.profiler.summary()
@@ -226,30 +332,17 @@ def main_train(args):
     elapsed = float(tmax.item())
     frames = world * B * T * args.steps
     if rank == 0:
-        kind = FAMILY_BOUND.get(dominant, "hbm")
-        secs = dom["ms_avg"] * 1e-3
-        if kind == "hbm":
-            ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
-        else:
-            ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
         st = opt.stats()
-        traffic = None                                  # HBM bytes per launch of the dominant family from the committed PMC passes
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
-        if os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
         line = {
-            "metric": "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref",
+            "metric": METRIC,
             "value": frames / elapsed, "unit": "STFT frames/s trained (whole job)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_DESC[dtype], "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
                        "sharding": "utterances over ranks; one bucketed all-reduce (RCCL) of the flat fp32 gradient per step, "
                                    "overlapped with backward", "optimizer": "AdamW lr 5e-4 betas (0.9, 0.98) wd 0.01, clip 5.0",
                        "dropout": "module defaults (0.1 / 0.15)" if whole_path else 0.15},
-            "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)",
-                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
-                         "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]},
+            "roofline": roofline_of(dominant, dom, traffic_file(args.workload)),
             "frames_per_s_per_gpu": frames / elapsed / world,
             "final_loss": float(loss.detach()), "optimizer_state": st,
             "breakdown_ms_per_step": {k: round(v["ms_total"], 4) for k, v in
@@ -262,19 +355,72 @@ def main_train(args):
         if args.breakdown:
             with open(args.breakdown, "w") as fh:
                 json.dump(breakdown, fh, indent=1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the headline shape of BASELINE's metric, measured after the timed region (rank 0)
+# ---------------------------------------------------------------------------------------------------------------
+def headline_shape(path, passes=4):
+    """B 256 x 512-frame utterances through the same path (frames/s), and the attention kernel ALONE at that shape
+    (batch 256 x 512 frames x 4 heads x 64, bf16 operands: the north-star's >= 30 % of bf16 MFMA peak target), each launch
+    timed by HIP events with nothing else on the device."""
+    import torch
+    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    B, L, desc = WORKLOADS["c3p"]
+    T = 1 + L // 80
+    noisy, _ = syn.synth_wave(B, L, 4242)
+    wave = torch.from_numpy(noisy).cuda()
+    out = {"workload": desc}
+    with torch.no_grad():
+        path(wave)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            path(wave)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / passes
+    out.update({"frames_per_s": B * T / dt, "ms_per_step": dt * 1e3, "passes_in_flight": 1})
+    del wave
+    H, hd = 4, 64
+    with ops.stage("attn"):
+        adt = ops.compute_dtype()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        qkv = torch.randn(B * T, 3 * H * hd, device="cuda", generator=g).to(adt)
+        o = torch.empty(B * T, H * hd, device="cuda", dtype=adt)
+        for _ in range(3):
+            ops.attention(qkv, B, T, H, hd, out=o)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        ev[0].record()
+        for i in range(20):
+            ops.attention(qkv, B, T, H, hd, out=o)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))
+    avg = sum(ms) / len(ms)
+    fl = 4.0 * B * H * T * T * hd
+    out["attention"] = {"shape": "B256 x T512 x 4 heads x 64", "operands": "bf16" if adt is torch.bfloat16 else "fp16",
+                        "avg_ms": avg, "min_ms": ms[0], "tflops": fl / avg / 1e9, "frac_bf16_mfma_peak": fl / avg / 1e9 / PEAKS["mfma16"],
+                        "launches": 20, "note": "kernel alone on the device, random (gaussian) Q K V, HIP events per launch"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# forward workloads
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="mixed", choices=["mixed", "bf16", "f16"],
+                    help="16-bit operand formats: mixed = the default per-stage policy (ops.POLICIES['mixed']; training: bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-headline", action="store_true", help="skip the B256 x 512-frame extra measurements")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel-family breakdown JSON here")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound small batches)")
@@ -282,23 +428,24 @@ def main():
                     "HIP streams (each step is still one whole pass over its own buffers; 1 = strictly one pass at a time; "
                     "0 = auto: a short calibration during warm-up picks the fastest of 1, 2 and 3 on this machine)")
     args = ap.parse_args()
-    if args.workload in ("c3se", "c2t"):
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                          # before anything in this process touches the GPU
+    if args.workload in TRAIN_WORKLOADS:
         return main_train(args)
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(0 if os.environ.get("SFM_SINGLE_DEVICE") else local_rank)   # rehearsal of N ranks on a 1-GPU box
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("SFM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    rank, world = init_ranks(args)
 
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
     B, L, desc = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
     T = 1 + L // 80
-    path, weights = build_path(args.dtype, use_memory=(args.workload == "c5"))
+    use_memory = args.workload == "c5"
+    path, weights = build_path(args.dtype, use_memory=use_memory)
     path = path.cuda().eval()
     noisy, _ = syn.synth_wave(B, L, 1234 + rank)          # each rank enhances its own utterance shard
     wave = torch.from_numpy(noisy).cuda()
@@ -335,6 +482,7 @@ def main():
     if rank == 0:
         print("[bench] %s, dtype %s, world %d" % (desc, args.dtype, world), file=sys.stderr, flush=True)
     with torch.no_grad():
+        calib = None
         if auto_streams and not args.graph:
             # calibration (untimed, part of the warm-up): 6 passes each with 1, 2 and 3 passes in flight; the fastest wins
             # (more streams than the process has hardware queues run SLOWER than one: never assume, measure)
@@ -355,18 +503,21 @@ def main():
             best = min(res, key=lambda c: res[c] * (1.0 + 0.01 * c))          # prefer fewer passes in flight on a tie
             args.streams = best
             streams = pool[:best] if best > 1 else None
+            calib = {str(c): res[c] * 1e3 for c in (1, 2, 3)}
             if rank == 0:
                 print("[bench] calibration (ms/pass): %s -> --streams %d" %
                       (", ".join("%d in flight %.2f" % (c, res[c] * 1e3) for c in (1, 2, 3)), best), file=sys.stderr, flush=True)
-        # warm-up; the last warm-up step is instrumented per kernel family to find the dominant one
+        # warm-up; then ONE instrumented pass, alone on the device (everything enqueued before it has finished), to find the
+        # dominant kernel family and the exclusive per-family times
         for i in range(max(args.warmup, 1)):
-            if i == max(args.warmup, 1) - 1:
-                ops.profiler.enable(None, tags=bool(args.breakdown))
-                path(wave)                                # eager, so the per-launch events exist even with --graph
-            else:
-                step()
+            step()
+        torch.cuda.synchronize()
+        ops.profiler.enable(None, tags=bool(args.breakdown))
+        out_one = path(wave)                              # eager, so the per-launch events exist even with --graph
         breakdown = ops.profiler.summary()
         ops.profiler.disable()
+        gpu_masks = (out_one["mask_real"][:1].cpu(), out_one["mask_imag"][:1].cpu()) if rank == 0 else None
+        del out_one
         dominant = max((k for k in breakdown if "[" not in k), key=lambda k: breakdown[k]["ms_total"])
         if not args.graph:
             ops.profiler.enable({dominant})
@@ -379,15 +530,22 @@ def main():
         dom = breakdown[dominant] if args.graph else ops.profiler.summary()[dominant]
         ops.profiler.disable()
         # with several passes in flight the live per-launch durations include the time a kernel shares the chip with the
-        # other stream's kernels; a few strictly sequential passes AFTER the timed region give the exclusive durations
-        dom_excl = None
-        if streams is not None and not args.graph:
+        # other stream's kernels; strictly sequential passes AFTER the timed region give the exclusive durations and the
+        # single-pass step time
+        dom_excl, single_ms = None, None
+        if not args.graph:
             torch.cuda.synchronize()
             ops.profiler.enable({dominant})
+            t1 = time.perf_counter()
             for _ in range(3):
                 path(wave)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t1) / 3 * 1e3
             dom_excl = ops.profiler.summary()[dominant]
             ops.profiler.disable()
+        headline = None
+        if rank == 0 and not args.no_headline and args.workload == "c2":
+            headline = headline_shape(path)
 
     tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     if world > 1:
@@ -395,56 +553,52 @@ def main():
     elapsed = float(tmax.item())
     frames = world * B * T * args.steps
     if rank == 0:
+        roof = roofline_of(dominant, dom, traffic_file(args.workload))
+        peak = roof["peak"]
         kind = FAMILY_BOUND.get(dominant, "hbm")
-        secs = dom["ms_avg"] * 1e-3
-        if kind == "hbm":
-            ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
-        else:
-            ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # tools/pmc_summary.py) for this workload, when present; None otherwise
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
-        if os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
-        att = breakdown.get("attention_fwd")
         line = {
-            "metric": "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref",
+            "metric": METRIC,
             "value": frames / elapsed, "unit": "STFT frames/s (whole job)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_DESC[args.dtype], "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
                        "sharding": "utterances over ranks, no data-path collective",
                        "launch": "one hipGraph replay per step" if args.graph else "eager launches",
-                       "streams": args.streams},
-            "roofline": {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)",
-                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
-                         "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"],
-                         "avg_ms": dom["ms_avg"]},
+                       "streams": args.streams, "precision_policy": ops.policy_name()},
+            "roofline": roof,
             "frames_per_s_per_gpu": frames / elapsed / world,
         }
+        if calib:
+            line["config"]["calibration_ms_per_pass"] = calib
         if dom_excl is not None:
             ex = (dom_excl["bytes"] if kind == "hbm" else dom_excl["flops"]) / dom_excl["n"] / (dom_excl["ms_avg"] * 1e-3) / \
                 (1e9 if kind == "hbm" else 1e12)
             line["roofline"].update({"passes_in_flight": args.streams, "exclusive_achieved": ex, "exclusive_frac": ex / peak,
                                      "exclusive_avg_ms": dom_excl["ms_avg"],
-                                     "note": "achieved / avg_ms are live in the timed region, where %d passes share the chip; "
+                                     "note": "achieved / avg_ms are live in the timed region, where %d pass(es) share the chip; "
                                              "exclusive_* are the same launches in 3 strictly sequential passes right after "
-                                             "it (= what --streams 1 measures)" % args.streams})
+                                             "it" % args.streams})
+            line["single_pass_ms_per_step"] = single_ms
+        att = breakdown.get("attention_fwd")
         if att:
             tf = att["flops"] / att["n"] / (att["ms_avg"] * 1e-3) / 1e12
-            line["attention"] = {"tflops": tf, "frac_bf16_mfma_peak": tf / PEAKS["mfma16"], "avg_ms": att["ms_avg"]}
+            line["attention"] = {"tflops": tf, "frac_bf16_mfma_peak": tf / PEAKS["mfma16"], "avg_ms": att["ms_avg"],
+                                 "shape": "B%d x T%d x 4 heads x 64 (this workload), instrumented pass alone on the device" % (B, T)}
         line["breakdown_ms_per_step"] = {k: round(v["ms_total"], 4) for k, v in
                                          sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]) if "[" not in k}
+        line["breakdown_note"] = "one instrumented pass alone on the device (HIP events per launch); sums to the single-pass step"
+        if headline:
+            line["headline"] = headline
         print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
               (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(weights, L)
+            line["cpu_baseline"], rm = cpu_baseline(weights, L, noisy, gpu_masks=gpu_masks, use_memory=use_memory)
+            line["mask_rmse"] = {"value": rm, "bound": 1e-3, "what": "RMSE of (mask_real | mask_imag) of utterance 0 of the bench "
+                                 "batch, HIP path (this dtype) vs the CPU oracle (fp32), outside the timed region"}
         if args.breakdown:
             with open(args.breakdown, "w") as fh:
                 json.dump(breakdown, fh, indent=1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -105,8 +105,9 @@ int sfm_framed_gemm_f32(const float* sig, const float* Wt, const float* bias, vo
  * nn.MultiheadAttention (models/conformer.py:69).  qkv [B,T,ldqkv] 16-bit with
  * q at column h*hd, k at koff+h*hd, v at voff+h*hd; out [B,T,ldo] 16-bit at h*hd.
  * scale <= 0 means Q is pre-multiplied by softmax_scale*log2(e) (folded into W_q/b_q). */
-/* head_dim-64 kernel selection (diagnostics / A-B measurements): 0 = by sequence length (default: 64 query rows per
- * wave from T >= 1024, 32 below), 1 = always 32 query rows per wave, 2 = always 64 (software-pipelined kernel). */
+/* head_dim-64 kernel selection (diagnostics / A-B measurements): 0 = by shape (default: the persistent ring kernel
+ * attn_fwd_hd64r for 256 < T <= 512 and T >= 1024, 32 query rows per wave otherwise), 1 = always 32 query rows per wave,
+ * 3 (or 2) = always the persistent ring kernel. */
 int sfm_attention_set_variant(int v);
 int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                       int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,

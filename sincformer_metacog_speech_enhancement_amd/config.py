@@ -1,6 +1,11 @@
 """Constants of the reference's config.py that the hot path reads
 (config.py:17-21 audio framing, :93-98 Conformer, :105-107 agents, :25 channels).
 Only values are mirrored; nothing else of the reference configuration exists here."""
+import os as _os
+
+# checkpoints (config.py:13 of the reference: <repo>/saved_models); override with SFM_MODEL_DIR
+MODEL_DIR = _os.environ.get("SFM_MODEL_DIR") or _os.path.join(_os.getcwd(), "saved_models")
+
 SAMPLE_RATE = 8000
 FRAME_SIZE_MS = 20
 FRAME_SIZE = int(SAMPLE_RATE * FRAME_SIZE_MS / 1000)   # 160

@@ -40,6 +40,13 @@ __device__ __forceinline__ float attn_keep_rk(uint32_t rowh, int key, uint32_t t
   return ((x >> 8) >= thr24) ? inv_keep : 0.f;
 }
 
+// Row maxima: this file is compiled with -fno-honor-nans (build.py), so fmaxf() on MFMA results is a plain v_max_f32 /
+// v_max3_f32; with NaNs honoured hipcc canonicalises every operand first (one extra v_max_f32 x, x per score pair, +3 %
+// kernel time).  The scores cannot be NaN here (finite operands, -BIG instead of -inf).  (An inline-asm v_max3 would also
+// avoid the canonicalisation but hides the MFMA-result hazard from the compiler's nop insertion: wrong values now and then.)
+__device__ __forceinline__ float sfm_max2_raw(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float sfm_max3_raw(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 // O is written in the operands' format T, or (out_other) in the other 16-bit format: the attention core may run in bf16 behind
 // fp16 projections (precision policy, ops.STAGES)
 template <class T>
@@ -181,9 +188,9 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
     // DEFER_THR (log2 units) - a rare, wave-uniform branch that rescales O, l and this tile's scores;
     // otherwise P = exp2(s) directly (values up to 2^DEFER_THR).
     const int kbase = kt * 64;
-    float mx = fmaxf(s[0][0], s[1][0]);
+    float mx = sfm_max2_raw(s[0][0], s[1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+    for (int r = 1; r < 16; ++r) mx = sfm_max3_raw(mx, s[0][r], s[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (kt == 0 || __any(mx > DEFER_THR)) {
       // new subtracted value = m_run + mx, split in two 16-bit terms so the MFMA subtracts it to ~2^-17
@@ -290,13 +297,6 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64_kernel(const u16* __restric
 }
 
 // ---------------------------------------------------------------------------
-// attn_fwd_hd64x2: the inference / no-dropout kernel.  Same math and operand layouts as attn_fwd_hd64 above, but a
-// wave owns 64 query rows = two independent 32-row sub-blocks that share every K fragment (ds_read_b128) and every
-// V^T fragment (ds_read_b64_tr_b16): LDS and L2 traffic per FLOP halve, there is one barrier per 2x the work, and
-// the two sub-blocks give the in-order wave independent MFMA / VALU streams to interleave (the softmax of one
-// sub-block issues in the gaps of the other's MFMAs).  Block = 4 waves = 256 query rows; the online softmax runs
-// per 32-key step (two steps per staged 64-key tile).  Row maxima cross the lane halves with v_permlane32_swap.
-// ---------------------------------------------------------------------------
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of the second: fed two copies of x it
 // leaves [x.lo, x.lo] and [x.hi, x.hi].  The s_nop covers the 2 wait states a VALU write of an operand needs before
 // the swap reads it.  (Scalars in and out: this compiler reads element 0 for __builtin_bit_cast(float, vec[i]).)
@@ -317,293 +317,50 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return lo + hi;
 }
 
-template <class T>
-__global__ __launch_bounds__(256, 1) void attn_fwd_hd64x2_kernel(const u16* __restrict__ qkv, u16* __restrict__ out,
-                                                                 int Tlen, int ldqkv, int ldo, int koff, int voff,
-                                                                 long long qkv_batch_stride, long long o_batch_stride,
-                                                                 float scale_log2e, int nqt, int nheads,
-                                                                 float* __restrict__ lse_out, int out_other) {
-  constexpr int KV_BUF = 64 * KS_ROW + 64 * VS_ROW;
-  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV_BUF];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int id = blockIdx.x;
-  {
-    const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+// ---- ablation hooks of the ring kernel (diagnostic builds only: -DSFM_ABL=n; results are then WRONG on purpose) ----
+#ifndef SFM_ABL
+#define SFM_ABL 0
+#endif
+#if SFM_ABL == 1
+#define SFM_ABL_EXP(x) (x)
+#else
+#define SFM_ABL_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
+#if SFM_ABL == 13
+#define SFM_ABL_ROWMAX(sn) ([&]() { float m_ = fmaxf(sn[0], sn[1]); _Pragma("unroll") for (int r = 2; r < 16; ++r) m_ = fmaxf(m_, sn[r]); return m_; }())
+#else
+#define SFM_ABL_ROWMAX(sn) ([&]() { float m_ = sfm_max2_raw(sn[0], sn[1]); _Pragma("unroll") for (int r = 2; r < 16; r += 2) m_ = sfm_max3_raw(m_, sn[r], sn[r + 1]); return m_; }())
+#endif
+#if SFM_ABL == 5
+#define SFM_ABL_LACC(x)
+#else
+#define SFM_ABL_LACC(x) x
+#endif
+#if SFM_ABL == 4
+#define SFM_ABL_SCHED
+#else
+#define SFM_ABL_SCHED                                                                                                  \
+  _Pragma("unroll") for (int g_ = 0; g_ < 11; ++g_) {                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                                 \
   }
-  const int qt = id % nqt;
-  const int h = (id / nqt) % nheads, b = id / (nqt * nheads);
-  const int q0 = qt * 256 + wave * 64;
-  const int hl = lane >> 5, l31 = lane & 31;
-  const u16* base = qkv + (long long)b * qkv_batch_stride + h * 64;
+#endif
+#if SFM_ABL == 10
+#define SFM_ABL_STORE_AUX 17
+#else
+#define SFM_ABL_STORE_AUX 0
+#endif
+#if SFM_ABL == 11
+#define SFM_ABL_STAGGER() do { if (wave >= 4) __builtin_amdgcn_s_sleep(6); } while (0)
+#else
+#define SFM_ABL_STAGGER() do { } while (0)
+#endif
+#if SFM_ABL == 3
+#define SFM_ABL_SYNC()
+#else
+#define SFM_ABL_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#endif
 
-  u32x4 qf[2][4];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int q = q0 + 32 * u + l31;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (q < Tlen) v = *reinterpret_cast<const u32x4*>(base + (long long)q * ldqkv + ks * 16 + hl * 8);
-      if (scale_log2e != 1.0f) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = pack2<T>(T::to_f32((u16)(v[e] & 0xffffu)) * scale_log2e, T::to_f32((u16)(v[e] >> 16)) * scale_log2e);
-      }
-      qf[u][ks] = v;
-    }
-  }
-  // augmented k-step: K side (1, 1, pad, 0...) x Q side (-m_hi, -m_lo, -BIG, 0...) -> the matrix core subtracts the
-  // running max AND pushes the scores of padding keys (>= Tlen, only in the last tile) to -BIG: no masking on the VALU
-  const uint32_t one16 = T::from_f32(1.0f);
-  const uint32_t ones2 = one16 | (one16 << 16);
-  const uint32_t negbig = (uint32_t)T::from_f32(T::id == SFM_DT_F16 ? -60000.0f : -3.0e38f);
-  const u32x4 vones = {ones2, ones2, ones2, ones2};
-  uint32_t qaug[2] = {0u, 0u};
-  float m_run[2] = {0.f, 0.f};
-
-  f32x16 o[2][2], lacc[2], s[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o[u][0][r] = 0.f;
-      o[u][1][r] = 0.f;
-      lacc[u][r] = 0.f;
-      s[u][r] = 0.f;
-    }
-  }
-
-  int srow[2], scol[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i;
-    srow[i] = c >> 3;
-    scol[i] = (c & 7) * 8;
-  }
-  u32x4 rk[2], rv[2];
-  const int ntiles = (Tlen + 63) / 64;
-
-  auto load_kv = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = kt * 64 + srow[i];
-      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
-      if (key < Tlen) {
-        const u16* rowp = base + (long long)key * ldqkv + scol[i];
-        a = *reinterpret_cast<const u32x4*>(rowp + koff);
-        c = *reinterpret_cast<const u32x4*>(rowp + voff);
-      }
-      rk[i] = a;
-      rv[i] = c;
-    }
-  };
-  auto store_kv = [&](int buf) {
-    u16* Kd = smem + buf * KV_BUF;
-    u16* Vd = Kd + 64 * KS_ROW;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(&Kd[srow[i] * KS_ROW + scol[i]]) = rk[i];
-      *reinterpret_cast<u32x4*>(&Vd[srow[i] * VS_ROW + scol[i]]) = rv[i];
-    }
-  };
-
-  // transposed V reads: 16-lane group g -> d block (g&1)*16, lane half = g>>1; lane 4q+p addresses row q, cols 4p..4p+3
-  const int g16 = lane >> 4, i16 = lane & 15;
-  const int vrow0 = 4 * (g16 >> 1) + (i16 >> 2);
-  const int vcol0 = (g16 & 1) * 16 + 4 * (i16 & 3);
-
-  u32x4 kf[4], vf[2][2];
-  auto load_kf = [&](int step) {                                   // K rows of 32-key step `step`
-    const u16* Ks = smem + ((step >> 1) & 1) * KV_BUF;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      kf[ks] = *reinterpret_cast<const u32x4*>(&Ks[((step & 1) * 32 + l31) * KS_ROW + ks * 16 + hl * 8]);
-  };
-  auto load_vf = [&](int step) {                                   // V^T fragments of step `step`
-    const u16* Vs = smem + ((step >> 1) & 1) * KV_BUF + 64 * KS_ROW;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int dj = 0; dj < 2; ++dj) {
-        const u16* vp = &Vs[((step & 1) * 32 + s2 * 16 + vrow0) * VS_ROW + dj * 32 + vcol0];
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * VS_ROW));
-        const u32x2 a0 = __builtin_bit_cast(u32x2, v0), a1 = __builtin_bit_cast(u32x2, v1);
-        vf[s2][dj] = u32x4{a0[0], a0[1], a1[0], a1[1]};
-      }
-  };
-
-  // Software pipeline over "items" (sub-block u of 32-key step i), order A(0) B(0) A(1) B(1) ...
-  //   item<u>(i):  S_u(i) MFMAs  ||  exp2 / pack of the PREVIOUS item's scores   (VALU in the MFMA gaps)
-  //                P.V MFMAs of the previous item  ||  row max of S_u(i)
-  //                rare wave-uniform branch: raise m_run[u] (rescales o[u], l[u], S_u(i))
-  // so every basic block carries 11 MFMAs and ~45 independent VALU instructions (sched_group_barrier spreads them).
-#define SFM_ATTN_ITEM(U, STEP, HAS_PREV, FIRST)                                                                       \
-  {                                                                                                                   \
-    constexpr int V_ = 1 - (U);                                                                                       \
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
-    const bool pad_ = (STEP) * 32 + l31 >= Tlen;                                                                      \
-    const u32x4 ka = {hl == 0 ? ones2 : 0u, (hl == 0 && pad_) ? one16 : 0u, 0u, 0u};                                  \
-    const u32x4 qa = {qaug[U], hl == 0 ? negbig : 0u, 0u, 0u};                                                        \
-    f32x16 sn = T::mfma(ka, qa, zero);                                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) sn = T::mfma(kf[ks], qf[U][ks], sn);                             \
-    if (HAS_PREV) {                                                                                                   \
-      u32x4 pf[2];                                                                                                    \
-      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
-        float e_[8];                                                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[V_][8 * s2 + r]);              \
-        pf[s2][0] = pack2<T>(e_[0], e_[1]);                                                                           \
-        pf[s2][1] = pack2<T>(e_[2], e_[3]);                                                                           \
-        pf[s2][2] = pack2<T>(e_[4], e_[5]);                                                                           \
-        pf[s2][3] = pack2<T>(e_[6], e_[7]);                                                                           \
-      }                                                                                                               \
-      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
-        lacc[V_] = T::mfma(vones, pf[s2], lacc[V_]);                                                                  \
-        o[V_][0] = T::mfma(vf[s2][0], pf[s2], o[V_][0]);                                                              \
-        o[V_][1] = T::mfma(vf[s2][1], pf[s2], o[V_][1]);                                                              \
-      }                                                                                                               \
-    }                                                                                                                 \
-    float mx = fmaxf(sn[0], sn[1]);                                                                                   \
-    _Pragma("unroll") for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sn[r]);                                             \
-    mx = xhalf_max(mx);                                                                                               \
-    _Pragma("unroll") for (int g_ = 0; g_ < 11; ++g_) {                                                               \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                              \
-    }                                                                                                                 \
-    if ((FIRST) || __any(mx > DEFER_THR)) {                                                                           \
-      const float want = m_run[U] + mx;                                                                               \
-      const float hi = T::to_f32(T::from_f32(want));                                                                  \
-      const float lo = T::to_f32(T::from_f32(want - hi));                                                             \
-      const float m_new = hi + lo;                                                                                    \
-      const float delta = m_new - m_run[U];                                                                           \
-      if (!(FIRST)) {                                                                                                 \
-        const float alpha = __builtin_amdgcn_exp2f(-delta);                                                           \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
-          o[U][0][r] *= alpha;                                                                                        \
-          o[U][1][r] *= alpha;                                                                                        \
-          lacc[U][r] *= alpha;                                                                                        \
-        }                                                                                                             \
-      }                                                                                                               \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) sn[r] -= delta;                                                  \
-      m_run[U] = m_new;                                                                                               \
-      qaug[U] = (hl == 0) ? pack2<T>(-hi, -lo) : 0u;                                                                  \
-    }                                                                                                                 \
-    s[U] = sn;                                                                                                        \
-  }
-
-  load_kv(0);
-  store_kv(0);
-  __syncthreads();
-  load_kf(0);
-  // ---- first tile, peeled: the running maxima are initialised here and A(0) has no predecessor ----
-  {
-    const bool more = 1 < ntiles;
-    SFM_ATTN_ITEM(0, 0, false, true)
-    if (more) load_kv(1);
-    load_vf(0);
-    SFM_ATTN_ITEM(1, 0, true, true)
-    load_kf(1);
-    SFM_ATTN_ITEM(0, 1, true, false)
-    load_vf(1);
-    if (more) store_kv(1);
-    SFM_ATTN_ITEM(1, 1, true, false)
-    __syncthreads();
-    if (more) load_kf(2);
-  }
-  for (int kt = 1; kt < ntiles; ++kt) {
-    const int e = 2 * kt, od = 2 * kt + 1;
-    const bool more = kt + 1 < ntiles;
-    SFM_ATTN_ITEM(0, e, true, false)
-    if (more) load_kv(kt + 1);                                     // global -> registers, lands during this tile
-    load_vf(e);
-    SFM_ATTN_ITEM(1, e, true, false)
-    load_kf(od);
-    SFM_ATTN_ITEM(0, od, true, false)
-    load_vf(od);
-    if (more) store_kv((kt + 1) & 1);                              // readers of that buffer passed the previous barrier
-    SFM_ATTN_ITEM(1, od, true, false)
-    __syncthreads();                                               // tile kt fully consumed, tile kt+1 fully staged
-    if (more) load_kf(od + 1);
-  }
-  // drain: the last item B(last step) still has to be exponentiated and multiplied into O
-  {
-    u32x4 pf[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float e_[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[1][8 * s2 + r]);
-      pf[s2][0] = pack2<T>(e_[0], e_[1]);
-      pf[s2][1] = pack2<T>(e_[2], e_[3]);
-      pf[s2][2] = pack2<T>(e_[4], e_[5]);
-      pf[s2][3] = pack2<T>(e_[6], e_[7]);
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      lacc[1] = T::mfma(vones, pf[s2], lacc[1]);
-      o[1][0] = T::mfma(vf[s2][0], pf[s2], o[1][0]);
-      o[1][1] = T::mfma(vf[s2][1], pf[s2], o[1][1]);
-    }
-  }
-#undef SFM_ATTN_ITEM
-
-  // ---- epilogue: normalise, transpose through LDS (64 rows per wave), coalesced 16-byte stores ----
-  u16* Os = smem + wave * (64 * OS_ROW);
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const float l = lacc[u][0];
-    const float inv = 1.0f / l;
-    const int q = q0 + 32 * u + l31;
-    if (lse_out && hl == 0 && q < Tlen)
-      lse_out[((long long)b * nheads + h) * Tlen + q] = m_run[u] + __builtin_amdgcn_logf(l);
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = dj * 32 + 8 * rq + 4 * hl;
-        u32x2 w;
-        w[0] = pack2_o<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv, out_other != 0);
-        w[1] = pack2_o<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv, out_other != 0);
-        *reinterpret_cast<u32x2*>(&Os[(32 * u + l31) * OS_ROW + d0]) = w;
-      }
-  }
-  __syncthreads();
-  u16* ob = out + (long long)b * o_batch_stride + h * 64;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    const int row = c >> 3, ch = (c & 7) * 8;
-    const int q = q0 + row;
-    if (q < Tlen) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(&Os[row * OS_ROW + ch]);
-      *reinterpret_cast<u32x4*>(ob + (long long)q * ldo + ch) = v;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// attn_fwd_hd64r: persistent form for the headline shape (batch 256 x 512-frame utterances: 8 key tiles per row, where the
-// per-workgroup costs of the kernels above - Q fetch, first K/V tile, one barrier per key tile, O transpose and store tail -
-// are 15-20 % of the launch).  Same arithmetic and fragment layouts as attn_fwd_hd64x2 (64 query rows per wave, software
-// pipeline over (sub-block, 32-key step) items, augmented k-step, ones-row sums, deferred running-max raise); what differs:
-//   * one workgroup per CU: 8 waves = 512 query rows of one (batch, head), 2 waves per SIMD; the grid is persistent, each
-//     workgroup walks its list of (batch, head, 512-row query tile) items;
-//   * K and V go HBM -> LDS by LDS-DMA (`buffer_load ... lds`: no staging registers, no ds_write) into a ring of 6 key-tile
-//     slots (96 KB) = two groups of 3 tiles.  ONE workgroup barrier per 3 key tiles: at the start of group g every wave has
-//     finished group g-1, so the half it occupied is refilled with group g+1 - of this item or of the workgroup's NEXT item, so
-//     the K/V stream never stops at an item boundary;
-//   * the NEXT item's Q rows (64 KB) are prefetched by LDS-DMA into the rest of the LDS (each wave its own 64 rows: no
-//     cross-wave ordering needed), so an item starts with LDS reads instead of a global round trip;
-//   * the descriptor's range check zero-fills keys >= T (their scores are pushed to -BIG by the augmented k-step) and drops
-//     the stores of query rows >= T: no predicates in the loop;
-//   * 128-byte LDS rows; 16-byte chunk c of K row r sits at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments), of V row
-//     r at c ^ (((r >> 1) & 1) << 2) (the four rows x 64 B of a transposed read tile the 256-byte bank row); the swizzle is
-//     applied to the SOURCE address, since LDS-DMA writes lane-linear;
-//   * O leaves the registers directly: v_permlane32_swap pairs the 8-byte fragments of the lane halves into 16-byte row
-//     segments (no LDS transpose), issued after the next item's first barrier so the stores drain under its math.
-// ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 
 template <class T>
@@ -727,25 +484,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64r_kernel(const u16* __res
       u32x4 pf[2];                                                                                                    \
       _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
         float e_[8];                                                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[V_][8 * s2 + r]);              \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) e_[r] = SFM_ABL_EXP(s[V_][8 * s2 + r]);                         \
         pf[s2][0] = pack2<T>(e_[0], e_[1]);                                                                           \
         pf[s2][1] = pack2<T>(e_[2], e_[3]);                                                                           \
         pf[s2][2] = pack2<T>(e_[4], e_[5]);                                                                           \
         pf[s2][3] = pack2<T>(e_[6], e_[7]);                                                                           \
       }                                                                                                               \
       _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
-        lacc[V_] = T::mfma(vones, pf[s2], lacc[V_]);                                                                  \
+        SFM_ABL_LACC(lacc[V_] = T::mfma(vones, pf[s2], lacc[V_]);)                                                    \
         o[V_][0] = T::mfma(SFM_VF(s2, 0), pf[s2], o[V_][0]);                                                              \
         o[V_][1] = T::mfma(SFM_VF(s2, 1), pf[s2], o[V_][1]);                                                              \
       }                                                                                                               \
     }                                                                                                                 \
-    float mx = fmaxf(sn[0], sn[1]);                                                                                   \
-    _Pragma("unroll") for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sn[r]);                                             \
+    float mx = SFM_ABL_ROWMAX(sn);                                                                                    \
     mx = xhalf_max(mx);                                                                                               \
-    _Pragma("unroll") for (int g_ = 0; g_ < 11; ++g_) {                                                               \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                              \
-    }                                                                                                                 \
+    SFM_ABL_SCHED                                                                                                     \
     if ((FIRST) || __any(mx > DEFER_THR)) {                                                                           \
       const float want = m_run[U] + mx;                                                                               \
       const float hi = T::to_f32(T::from_f32(want));                                                                  \
@@ -767,7 +520,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64r_kernel(const u16* __res
     s[U] = sn;                                                                                                        \
   }
 
-  // ---- O of the finished item, held until the next item's first barrier has been passed ----
+  // ---- O of the finished item, held in registers until the next item's first barrier has been passed; then transposed
+  //      through the wave's own 8 KB of the Q region (free between the Q fragment reads and the next Q prefetch) so that
+  //      every store instruction writes 8 whole 128-byte rows (per-lane row-strided stores cost ~600 cycles of issue each) ----
   uint32_t ow[2][2][4][2];                                          // [sub-block][dj][rq][2 dwords] = 4 consecutive d, 16-bit
   int st_item = -1;
   auto store_o = [&]() {
@@ -775,25 +530,48 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64r_kernel(const u16* __res
     const int qt = st_item % nqt, bh = st_item / nqt;
     const int h = bh % nheads, b = bh / nheads;
     auto ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * o_batch_stride), 0, orec_bytes, 0x00020000);
+    unsigned char* ob = rsm + QBASE + wave * 8192;
+    // the lane id is made opaque here so that the two dozen per-lane addresses below are computed HERE, once per item:
+    // hoisted to kernel entry they live across the whole tile loop, get spilled, and every reload (scratch = vector memory)
+    // brings a vmcnt wait into the store sequence
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int l31o = ln & 31, hlo = ln >> 5;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int q = qt * 512 + wave * 64 + 32 * u + l31;
-      const int rowoff = q * ldo * 2 + h * 128 + hl * 16;
+      const int row = 32 * u + l31o;
 #pragma unroll
       for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // lanes 0-31 keep fragment 2j and receive the upper half's fragment 2j (d + 4): 16 contiguous bytes; lanes 32-63
-          // likewise for fragment 2j+1
-          const auto x = __builtin_amdgcn_permlane32_swap(ow[u][dj][2 * j][0], ow[u][dj][2 * j + 1][0], false, false);
-          const auto y = __builtin_amdgcn_permlane32_swap(ow[u][dj][2 * j][1], ow[u][dj][2 * j + 1][1], false, false);
-          const u32x4 v = {x[0], y[0], x[1], y[1]};
-          __builtin_amdgcn_raw_buffer_store_b128(v, ors, rowoff + dj * 64 + j * 32, 0, 0);
-        }
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<u32x2*>(ob + row * 128 + (((dj * 4 + rq) ^ ((row >> 1) & 7)) << 4) + 8 * hlo) =
+              u32x2{ow[u][dj][rq][0], ow[u][dj][rq][1]};
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): the wave's own image is complete
+    __builtin_amdgcn_wave_barrier();
+    const int qbase = qt * 512 + wave * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ln + 64 * i;
+      const int row = c >> 3, ch = c & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, (qbase + row) * ldo * 2 + h * 128 + ch * 16, 0, SFM_ABL_STORE_AUX);
     }
     st_item = -1;
   };
 
+#if SFM_ABL == 9
+  // diagnostic build: lse_out is a stamp buffer, 8 x uint64 per workgroup: start, end, end of items 0..5 (100 MHz ticks)
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lse_out) + (size_t)blockIdx.x * 8;
+  if (tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+  int dbg_k = 0;
+  lse_out = nullptr;
+#endif
+#if SFM_ABL != 12
+  // the second-dispatched half of the workgroup loses the VALU arbitration against its SIMD partner on every segment
+  // (priority, then age): one static s_setprio for that half (+1.5 %; `wave` is wave-uniform by readfirstlane)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   int gcount = 0;                                                   // groups consumed so far by this workgroup (ring parity)
   if ((int)blockIdx.x < n_items) {
     issue_q(blockIdx.x);
@@ -803,50 +581,54 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64r_kernel(const u16* __res
     const int qt = item % nqt, bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
     const int q0 = qt * 512 + wave * 64;
-    // ---- Q fragments (B operand: col = query, k = d) from the prefetched LDS rows; rows >= Tlen were zero-filled ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's own Q pieces (issued an item ago)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        qf[u][ks] = *reinterpret_cast<const u32x4*>(rsm + QBASE + wave * 8192 + u * 4096 + klane[ks]);
-    if (scale_log2e != 1.0f) {                                     // callers normally fold the scale into W_q (scale_log2e == 1)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t w = qf[u][ks][e];
-            qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
-          }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      qaug[u] = 0u;
-      m_run[u] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o[u][0][r] = 0.f;
-        o[u][1][r] = 0.f;
-        lacc[u][r] = 0.f;
-        s[u][r] = 0.f;
-      }
-    }
-
     for (int g = 0; g < ngrp; ++g) {
       // ---- group boundary: this wave's pieces of group g have landed (vmcnt), everyone's have and everyone is done with
       //      group g-1 (barrier): refill that half with the next group of this item or group 0 of the next item ----
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      SFM_ABL_SYNC();
+      SFM_ABL_STAGGER();
       const int half = gcount & 1;
       if (g + 1 < ngrp) issue_group(item, g + 1, half ^ 1);
       else if (item + (int)gridDim.x < n_items) issue_group(item + gridDim.x, 0, half ^ 1);
       ++gcount;
-      if (g == 0) store_o();                                        // the previous item's O: drains under this item's math
-      // the next item's Q rows: this wave's own region, free since its Q fragments are in registers (the barrier above
-      // also waited for those LDS reads)
-      if (g == (ngrp > 1 ? 1 : 0) && item + (int)gridDim.x < n_items) issue_q(item + gridDim.x);
+      if (g == 0) {
+        // ---- Q fragments (B operand: col = query, k = d) from the prefetched LDS rows (rows >= Tlen were zero-filled; the
+        //      vmcnt wait above covered this wave's own Q pieces, issued an item ago) ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            qf[u][ks] = *reinterpret_cast<const u32x4*>(rsm + QBASE + wave * 8192 + u * 4096 + klane[ks]);
+        if (scale_log2e != 1.0f) {                                 // callers normally fold the scale into W_q (scale_log2e == 1)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t w = qf[u][ks][e];
+                qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
+              }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // Q fragments are in registers: the region may be reused
+        store_o();                                                  // the previous item's O: drains under this item's math
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                              // (after the stores: their registers are free again)
+          qaug[u] = 0u;
+          m_run[u] = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            o[u][0][r] = 0.f;
+            o[u][1][r] = 0.f;
+            lacc[u][r] = 0.f;
+            s[u][r] = 0.f;
+          }
+        }
+      }
+      // the next item's Q rows -> this wave's own region (its last LDS accesses, the O read-back, have completed)
+      if (g == (ngrp > 1 ? 1 : 0) && item + (int)gridDim.x < n_items) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_q(item + gridDim.x);
+      }
       const int step_end = min(nsteps, (g + 1) * 2 * GT);
       int step = g * 2 * GT;
       if (g == 0) {
@@ -903,10 +685,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64r_kernel(const u16* __res
         }
     }
     st_item = item;
+#if SFM_ABL == 9
+    if (tid == 0 && dbg_k < 6) dbg[2 + dbg_k] = __builtin_amdgcn_s_memrealtime();
+    ++dbg_k;
+#endif
   }
 #undef SFM_ATTN_RITEM
 #undef SFM_VF
   store_o();
+#if SFM_ABL == 9
+  if (tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -966,13 +755,13 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
   }
 }
 
-// kernel selection for the head_dim 64 no-dropout path: 0 = by sequence length (64 query rows per wave from T >= 1024,
-// where the software-pipelined kernel wins; 32 rows per wave below, where its shorter prologue does), 1 = always 32 rows
-// per wave, 2 = always 64 rows per wave, 3 = always the persistent ring kernel (attn_fwd_hd64r)
+// kernel selection for the head_dim 64 no-dropout path: 0 = by shape (persistent ring kernel for 256 < T <= 512 and
+// T >= 1024, 32 query rows per wave otherwise), 1 = always 32 rows per wave (attn_fwd_hd64), 3 = always the persistent ring
+// kernel (attn_fwd_hd64r); 2 (the former 64-rows-per-wave kernel, superseded by the ring kernel) is accepted as 3
 static int sfm_attn_variant = 0;
 extern "C" int sfm_attention_set_variant(int v) {
   if (v < 0 || v > 3) return SFM_ERR_ARG;
-  sfm_attn_variant = v;
+  sfm_attn_variant = (v == 2) ? 3 : v;
   return SFM_OK;
 }
 
@@ -991,12 +780,13 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
       (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
     // scale <= 0: Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
     float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
-    // persistent ring kernel: one 512-row query tile per item; auto for 256 < T <= 512 with at least one item per CU
-    // (the headline shape, batch 256 x 512 frames x 4 heads = 1024 items), variant 3 forces it for any T
+    // persistent ring kernel (512-row query tiles): auto for 256 < T <= 512 and for T >= 1024 when there is at least half an
+    // item per CU (in between, the second query tile of a (batch, head) would be mostly padding); variant 3 forces it
     const long long bytes_q = (long long)T * ldqkv * 2, bytes_o = (long long)T * ldo * 2;
+    const int nqt5 = (T + 511) / 512;
+    const bool ring_auto = ((T > 256 && T <= 512) || T >= 1024) && (long long)B * H * nqt5 >= 128;
     if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) &&
-        (sfm_attn_variant == 3 || (sfm_attn_variant == 0 && T > 256 && T <= 512 && (long long)B * H >= 256))) {
-      const int nqt5 = (T + 511) / 512;
+        (sfm_attn_variant == 3 || (sfm_attn_variant == 0 && ring_auto))) {
       const int n_items = nqt5 * H * B;
       static int ncu = 0;
       if (ncu == 0) {
@@ -1020,17 +810,6 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
       else
         SFM_LAUNCH((attn_fwd_hd64r_kernel<BF16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
                    qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
-      return SFM_OK;
-    }
-    if (p_drop == 0.f && (sfm_attn_variant == 2 || (sfm_attn_variant == 0 && T >= 1024))) {   // 64 query rows per wave
-      const int nqt2 = (T + 255) / 256;
-      dim3 grid2(nqt2 * H * B), block2(256);
-      if (dtype == SFM_DT_F16)
-        SFM_LAUNCH((attn_fwd_hd64x2_kernel<F16>), grid2, block2, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
-                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse, out_other);
-      else
-        SFM_LAUNCH((attn_fwd_hd64x2_kernel<BF16>), grid2, block2, 0, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
-                   qkv_batch_stride, o_batch_stride, sl2, nqt2, H, lse, out_other);
       return SFM_OK;
     }
     const int nqt = (T + 127) / 128;

@@ -4,7 +4,8 @@ At small batch the path is launch-bound (about 130 kernel launches per utterance
 B = 1), so the launch sequence is captured once per input shape into a hipGraph (torch.cuda.CUDAGraph is hipGraph on
 ROCm; our kernels are enqueued through the C ABI on torch's current stream, which is the capture stream) and replayed
 with one call.  Inputs are copied into static buffers, outputs are the graph's static tensors (clone them to keep them
-across replays).  Inference only; shapes are the cache key."""
+across replays).  Inference only; the cache key is (input shapes, operand formats, weights generation).  Parameters updated IN PLACE by
+anything but optim.FlatAdamW (which advances the weights generation) are not seen: drop the GraphedForward then."""
 import torch
 
 
@@ -15,7 +16,10 @@ class GraphedForward:
         self._cache = {}
 
     def _key(self, args):
-        return tuple((tuple(a.shape), a.dtype, a.device.index) for a in args)
+        # shapes + the operand formats / weights generation in force (ops.policy_key): a graph captured before an optimiser
+        # step or a precision change would replay stale packed weights
+        from . import ops
+        return (ops.policy_key(),) + tuple((tuple(a.shape), a.dtype, a.device.index) for a in args)
 
     def __call__(self, *args):
         key = self._key(args)

@@ -429,7 +429,7 @@ ATTN_QSCALE_LOG2E = 1.4426950408889634
 
 
 def set_attention_variant(v):
-    """0: chosen by sequence length (default), 1: 32 query rows per wave, 2: 64 query rows per wave (A/B measurements)."""
+    """0: chosen by shape (default), 1: 32 query rows per wave, 3: persistent ring kernel (A/B measurements)."""
     _lib.check(_lib.load().sfm_attention_set_variant(int(v)), "attention_set_variant")
 
 
@@ -650,11 +650,12 @@ def spec_sums(pr, pi, tr, ti, out=None):
     return S
 
 
-def enhancer_loss_finalize(Sw, Sm, Sr, nr, B, Ln, n_mag):
+def enhancer_loss_finalize(Sw, Sm, Sr, nr, B, Ln, n_mag, R=None):
+    """-> [total, neg SI-SNR, L1 magnitude, MR-STFT]; R: resolutions in Sr / nr (default: all rows; 0 = none)"""
     L = _lib.load()
     out = torch.empty(4, device=Sw.device, dtype=torch.float32)
-    _call("loss_reduce", L.sfm_enhancer_loss_finalize, (_p(Sw), _p(Sm), _p(Sr), _p(nr), B, Ln, n_mag, Sr.shape[0], _p(out),
-                                                        _stream()))
+    _call("loss_reduce", L.sfm_enhancer_loss_finalize, (_p(Sw), _p(Sm), _p(Sr), _p(nr), B, Ln, n_mag,
+                                                        Sr.shape[0] if R is None else int(R), _p(out), _stream()))
     return out
 
 

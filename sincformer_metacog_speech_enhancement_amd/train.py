@@ -486,6 +486,117 @@ class EnhancerLossFunction(torch.autograd.Function):
         return (d_er * s).to(ctx.dtypes[0]), (d_ei * s).to(ctx.dtypes[1]), None, None, None, None, None, None
 
 
+# ---- the objective's three terms as stand-alone nodes (the reference's si_snr_loss / MultiResolutionSTFTLoss /
+#      F.l1_loss on magnitudes can be called on their own; EnhancerLossFunction above is their fused form) ----
+def _dummy_moments(dev):
+    """wave moments of a (1 x 1-sample) pair with a finite SI-SNR: placeholder for terms a call does not use"""
+    return torch.tensor([[0.0, 0.0, 1.0, 1.0, 0.0]], device=dev, dtype=torch.float64)
+
+
+class SiSnrFunction(torch.autograd.Function):
+    """si_snr_loss (training/conformer_pipeline.py:52-71): negative mean SI-SNR of estimated [.., L] against target."""
+
+    @staticmethod
+    def forward(ctx, estimated, target):
+        L = estimated.shape[-1]
+        e = estimated.detach().float().reshape(-1, L).contiguous()
+        t = target.detach().float().reshape(-1, L).contiguous()
+        B = e.shape[0]
+        Sw = ops.wave_moments(e, t)
+        z4 = torch.zeros(1, 4, device=e.device, dtype=torch.float64)
+        nr = torch.ones(1, device=e.device, dtype=torch.int64)
+        losses = ops.enhancer_loss_finalize(Sw, z4[0], z4, nr, B, L, 1, R=0)
+        ctx.grad = None
+        if estimated.requires_grad:
+            dw = torch.empty(B, L, device=e.device, dtype=torch.float32)
+            ops.sisnr_bwd(e, t, Sw, dw)
+            ctx.grad = dw.reshape(estimated.shape)
+        ctx.dtype = estimated.dtype
+        return losses[1].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        d, ctx.grad = ctx.grad, None
+        return (None if d is None else (d * g.float()).to(ctx.dtype)), None
+
+
+class MrStftFunction(torch.autograd.Function):
+    """MultiResolutionSTFTLoss.forward (training/conformer_pipeline.py:94-108): mean over the resolutions of spectral
+    convergence + L1 log-magnitude, predicted [B, L] against target; sizes = ((n_fft, hop, win), ...)."""
+
+    @staticmethod
+    def forward(ctx, predicted, target, sizes):
+        from . import functional as Fn
+        L = predicted.shape[-1]
+        pw = predicted.detach().float().reshape(-1, L).contiguous()
+        tw = target.detach().float().reshape(-1, L).contiguous()
+        B, dev, R = pw.shape[0], pw.device, len(sizes)
+        need_grad = predicted.requires_grad
+        Sr = torch.zeros(R, 4, device=dev, dtype=torch.float64)
+        dwave = torch.zeros(B, L, device=dev, dtype=torch.float32) if need_grad else None
+        counts = []
+        for i, (nf, hp, wn) in enumerate(sizes):
+            split = LOSS_STFT_SPLIT16 and nf == wn and nf % 256 == 0
+            stft_ = Fn.stft_split16 if split else Fn.stft
+            pr, pi = stft_(pw, nf, hp, wn)
+            tr, ti = stft_(tw, nf, hp, wn)
+            ops.spec_sums(pr, pi, tr, ti, out=Sr[i])
+            counts.append(pr.numel())
+            if need_grad:
+                Tr, Fr = pr.shape[1], pr.shape[2]
+                Mr = B * Tr
+                ld = ops.round_up(2 * Fr, 8)
+                g = torch.zeros(Mr, ld, device=dev, dtype=torch.float32)
+                ops.spec_loss_bwd(pr, pi, tr, ti, Sr[i], g, g[:, Fr:], Fr, ld, 0, scale=1.0 / R)
+                frames = torch.empty(Mr, wn, device=dev, dtype=torch.float32)
+                if split:
+                    ops.framed_gemm_split16(g, _adjoint_consts(nf, wn, dev)["fwdT16"], frames, B=1, M=Mr, Ls=Mr * ld,
+                                            sig_batch_stride=0, hop=ld, padl=0, o_batch_stride=0, ldm=wn, mode=0)
+                else:
+                    ops.framed_gemm(g, _adjoint_consts(nf, wn, dev)["fwdT"], frames, B=1, M=Mr, Ls=Mr * ld, sig_batch_stride=0,
+                                    hop=ld, padl=0, K=2 * Fr, N=wn, o_batch_stride=0, ldm=wn, ldn=1, mode=0)
+                ops.stft_adjoint_ola(frames, dwave, B, Tr, L, nf, hp, wn, accumulate=True)
+        nr = Fn.counts_tensor(tuple(counts), dev)
+        losses = ops.enhancer_loss_finalize(_dummy_moments(dev), Sr[0], Sr, nr, 1, 1, 1)
+        ctx.grad = dwave.reshape(predicted.shape) if need_grad else None
+        ctx.dtype = predicted.dtype
+        return losses[3].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        d, ctx.grad = ctx.grad, None
+        return (None if d is None else (d * g.float()).to(ctx.dtype)), None, None
+
+
+class L1MagnitudeFunction(torch.autograd.Function):
+    """F.l1_loss(sqrt(er^2 + ei^2 + 1e-8), sqrt(cr^2 + ci^2 + 1e-8)) of training/conformer_pipeline.py:562-564."""
+
+    @staticmethod
+    def forward(ctx, er, ei, cr, ci):
+        a = [t.detach().float().contiguous() for t in (er, ei, cr, ci)]
+        dev = a[0].device
+        Sm = ops.spec_sums(*a)
+        nr = torch.ones(1, device=dev, dtype=torch.int64)
+        losses = ops.enhancer_loss_finalize(_dummy_moments(dev), Sm, torch.zeros(1, 4, device=dev, dtype=torch.float64), nr, 1, 1,
+                                            a[0].numel(), R=0)
+        ctx.grads = None
+        if er.requires_grad or ei.requires_grad:
+            F = a[0].shape[-1]
+            d_er, d_ei = torch.empty_like(a[0]), torch.empty_like(a[0])
+            ops.spec_loss_bwd(a[0], a[1], a[2], a[3], Sm, d_er, d_ei, F, F, 1, accumulate=False, scale=1.0)
+            ctx.grads = (d_er, d_ei)
+        ctx.dtypes = (er.dtype, ei.dtype)
+        return losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grads is None:
+            return None, None, None, None
+        d_er, d_ei = ctx.grads
+        ctx.grads = None
+        return (d_er * g.float()).to(ctx.dtypes[0]), (d_ei * g.float()).to(ctx.dtypes[1]), None, None
+
+
 class ComplexMulFunction(torch.autograd.Function):
     """ComplexConformer.apply_mask (models/conformer.py:230-245) with its backward: the gradient of a complex product
     is the incoming gradient times the conjugate of the other factor — the same HIP kernel."""

@@ -1,7 +1,7 @@
-"""Host-side mirror of the model/STFT part of training/conformer_pipeline.py
-(batch_stft :196, batch_istft :205, SpeechEnhancer :218-301) plus the
-inference half of ConformerPipeline (:611-685) and the north-star agent
-composition (EnhancementPath; SURVEY.md §3.3 with the glue of DESIGN.md).
+"""Host-side mirror of the model / STFT / objective part of training/conformer_pipeline.py
+(si_snr_loss :52, MultiResolutionSTFTLoss :74, batch_stft :196, batch_istft :205, SpeechEnhancer :218-301,
+ConformerPipeline._compute_loss :539, _save_best :611, save_model :618, load_model :628, enhance_signal :653) and the
+north-star agent composition (EnhancementPath; SURVEY.md §3.3 with the glue of DESIGN.md).
 The data loaders / optimiser loop of the reference are out of scope.
 """
 import math
@@ -32,6 +32,43 @@ def batch_istft(stft_real, stft_imag, fft_size, hop_size, frame_size, length):
     if not stft_real.is_cuda:
         raise RuntimeError("batch_istft: HIP path needs a device tensor (no CPU fallback)")
     return Fn.istft(stft_real.float(), stft_imag.float(), length, fft_size, hop_size, frame_size)
+
+
+def si_snr_loss(estimated, target):
+    """training/conformer_pipeline.py:52-71 - negative mean scale-invariant SNR of `estimated` [..., L] against `target`
+    (to minimise).  Differentiable w.r.t. `estimated` (HIP backward kernel)."""
+    if not estimated.is_cuda:
+        raise RuntimeError("si_snr_loss: HIP path needs device tensors (no CPU fallback)")
+    from .. import train
+    return train.SiSnrFunction.apply(estimated, target)
+
+
+class MultiResolutionSTFTLoss(nn.Module):
+    """training/conformer_pipeline.py:74-108 - spectral convergence + L1 log-magnitude at three STFT resolutions (Hann
+    windows, centre reflect padding), averaged over the resolutions.  Same constructor and method names as the reference;
+    the STFTs, the reductions and the backward run on the HIP kernels."""
+
+    def __init__(self, fft_sizes=None, hop_sizes=None, win_sizes=None):
+        super().__init__()
+        self.fft_sizes = fft_sizes or [256, 512, 1024]
+        self.hop_sizes = hop_sizes or [64, 128, 256]
+        self.win_sizes = win_sizes or [256, 512, 1024]
+
+    def _sizes(self):
+        return tuple(zip(self.fft_sizes, self.hop_sizes, self.win_sizes))
+
+    def _stft_mag(self, x, fft_size, hop_size, win_size):
+        """|STFT| laid out [B, F, T] like torch.stft (monitoring / tests; forward() does not materialise it)."""
+        if not x.is_cuda:
+            raise RuntimeError("MultiResolutionSTFTLoss: HIP path needs device tensors (no CPU fallback)")
+        r, i = Fn.stft(x.float(), fft_size, hop_size, win_size)
+        return torch.sqrt(r * r + i * i).transpose(1, 2)
+
+    def forward(self, predicted, target):
+        if not predicted.is_cuda:
+            raise RuntimeError("MultiResolutionSTFTLoss: HIP path needs device tensors (no CPU fallback)")
+        from .. import train
+        return train.MrStftFunction.apply(predicted, target, self._sizes())
 
 
 class SpeechEnhancer(HipModule):
@@ -236,12 +273,54 @@ class ConformerPipeline:
         self.use_graph = False        # True: enhance_signal replays one hipGraph per signal length (graph.GraphedForward)
         self._graphed = None
 
-    def load_model(self, path):
+    def _compute_loss(self, noisy_real, noisy_imag, clean_wav, clean_real, clean_imag, mr_stft_fn):
+        """training/conformer_pipeline.py:539-572: model forward -> iSTFT -> SI-SNR + 0.5 * L1 magnitude +
+        multi-resolution STFT; returns (total, neg_sisnr).  With the reference's default resolutions the whole objective is
+        one fused autograd node (compute_loss); any other `mr_stft_fn` is composed from the stand-alone nodes."""
+        default = isinstance(mr_stft_fn, MultiResolutionSTFTLoss) and mr_stft_fn._sizes() == tuple(Fn.MR_STFT)
+        if default:
+            return compute_loss(self.model, noisy_real, noisy_imag, clean_wav, clean_real, clean_imag, self.fft_size,
+                                self.hop_size, self.frame_size)
+        from .. import train
+        enh_real, enh_imag, _ = self.model(noisy_real, noisy_imag)
+        T = min(enh_real.shape[1], clean_real.shape[1])
+        enh_real, enh_imag = enh_real[:, :T], enh_imag[:, :T]
+        enh_wav = train.IstftFunction.apply(enh_real, enh_imag, clean_wav.shape[-1], self.fft_size, self.hop_size, self.frame_size)
+        loss_sisnr = si_snr_loss(enh_wav, clean_wav)
+        loss_mag = train.L1MagnitudeFunction.apply(enh_real, enh_imag, clean_real[:, :T], clean_imag[:, :T])
+        loss_stft = mr_stft_fn(enh_wav, clean_wav)
+        return loss_sisnr + 0.5 * loss_mag + loss_stft, loss_sisnr
+
+    # -- model I/O (training/conformer_pipeline.py:611-649): {'model_state', 'model_class'} checkpoints ----------------
+    def _checkpoint(self):
+        return {"model_state": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}, "model_class": "SpeechEnhancer"}
+
+    def _save_best(self):
+        os.makedirs(config.MODEL_DIR, exist_ok=True)
+        torch.save(self._checkpoint(), os.path.join(config.MODEL_DIR, "best_conformer.pt"))
+
+    def save_model(self, filename="conformer_final.pt"):
+        if self.model is None:
+            return
+        os.makedirs(config.MODEL_DIR, exist_ok=True)
+        path = os.path.join(config.MODEL_DIR, filename)
+        torch.save(self._checkpoint(), path)
+        print(f"  + Model saved: {path}")
+
+    def load_model(self, path=None):
+        if path is None:
+            path = os.path.join(config.MODEL_DIR, "conformer_final.pt")
+            if not os.path.exists(path):
+                path = os.path.join(config.MODEL_DIR, "best_conformer.pt")
+        # tensors only: a checkpoint is {'model_state': state_dict, 'model_class': str} (the reference unpickles with
+        # weights_only=False; nothing in its checkpoints needs that)
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
         self.model = SpeechEnhancer(n_freq=self.fft_size // 2 + 1, d_model=256, num_blocks=4, num_heads=4, d_ff=1024,
                                     kernel_size=31, dropout=0.15)
         self.model.load_state_dict(ckpt["model_state"])
         self.model.to(self.device).eval()
+        self._graphed = None          # a captured hipGraph replays the OLD model's packed weights
+        print(f"  + Conformer loaded: {path}")
 
     @torch.no_grad()
     def enhance_signal(self, noisy_signal):

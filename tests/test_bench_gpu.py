@@ -37,6 +37,42 @@ def test_bench_single_gpu_line():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1 and r["achieved"] > 0 and r["peak"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    # the line carries the parity check its metric string promises, at the north-star bound, for the dtype it names
+    assert d["mask_rmse"]["bound"] == 1e-3 and 0 < d["mask_rmse"]["value"] <= 1e-3
+    assert "fp16" in d["dtype"] and "bf16 attention" in d["dtype"] and d["config"]["precision_policy"] == "mixed"
+    # the per-family breakdown comes from ONE pass alone on the device: it cannot exceed the single-pass step
+    assert sum(d["breakdown_ms_per_step"].values()) <= 1.1 * d["single_pass_ms_per_step"]
+
+
+def test_bench_default_workload_carries_the_headline_shape():
+    """configs[1] line + the extra keys for BASELINE's metric shape (B 256 x 512-frame utterances) and the attention kernel
+    alone at that shape"""
+    d = _json_line(_run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]))
+    assert "B64 x 4 s" in d["config"]["workload"] and d["roofline"]["traffic"] is None or "NOT measured" in d["roofline"]["traffic_source"]
+    assert sum(d["breakdown_ms_per_step"].values()) <= 1.1 * d["single_pass_ms_per_step"]
+    h = d["headline"]
+    assert "B256 x 512-frame" in h["workload"] and h["frames_per_s"] > 1e6
+    a = h["attention"]
+    assert a["operands"] == "bf16" and a["tflops"] > 300 and abs(a["frac_bf16_mfma_peak"] - a["tflops"] / 2500.0) < 1e-9
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """plain `python bench.py --gpus 2` (no launcher): the parent spawns both ranks before touching the GPU; rehearsed on the
+    single card (both ranks on device 0, collectives over gloo)"""
+    env = {"SFM_SINGLE_DEVICE": "1", "SFM_DIST_BACKEND": "gloo"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    d = _json_line(_run([sys.executable, "bench.py", "--gpus", "2", "--workload", "c1", "--steps", "3", "--warmup", "1"], env))
+    assert d["n_gpus"] == 2 and abs(d["value"] - 2 * 201 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert "cpu_baseline" not in d
+
+
+def test_bench_rejects_a_gpus_flag_that_disagrees_with_the_launcher():
+    e = dict(os.environ)
+    e.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "c1", "--steps", "1", "--warmup", "1"], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
 @pytest.mark.parametrize("workload,extra", [("c1", []), ("c3se", ["--batch", "4"])])

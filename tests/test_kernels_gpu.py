@@ -78,6 +78,22 @@ def test_gemm16_plain(ops, dt, M, K, N, variant):
     report("gemm16 %s %dx%dx%d" % (dt, M, K, N), out.cpu(), ref, 2e-4)
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 256, 768), (129, 1024, 256), (77, 64, 129), (2100, 256, 768)])
+def test_gemm16_result_in_the_other_16bit_format(ops, M, K, N):
+    """stage boundary of the precision policy: fp16 operands, result rounded once to bf16 (and the reverse), on the default,
+    the wide (N % 256 == 0, many tiles) and the ragged-N tile paths"""
+    x = arr("gx", (M, K), 1)
+    w = arr("gw", (N, K), 2) / math.sqrt(K)
+    b = arr("gb", (N,), 3)
+    for dt, odt in ((torch.float16, torch.bfloat16), (torch.bfloat16, torch.float16)):
+        ops.set_compute_dtype(dt)
+        pw = ops.pack_linear(dev(w), dev(b))
+        out = ops.linear16(dev(x).to(dt).contiguous(), pw, out_dtype=odt)
+        assert out.dtype == odt
+        ref = (q16(x, dt) @ q16(w, dt).t() + b).to(odt).float()
+        report("gemm16 %s -> %s %dx%dx%d" % (dt, odt, M, K, N), out.float().cpu(), ref, 4 * EPS[odt] * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_gemm16_strided_operand_views(ops, variant):
     """A is a column slice of a wider buffer (lda > K), output goes into a column slice (ldo > N)"""
@@ -230,7 +246,7 @@ def _attn_ref(qkv, B, T, H, hd):
     return (p @ v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("variant", [1, 2])          # both head_dim-64 kernels: 32 / 64 query rows per wave
+@pytest.mark.parametrize("variant", [1, 3])          # both head_dim-64 kernels: 32 query rows per wave / persistent ring
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,T,H,hd", [(2, 200, 4, 64), (1, 64, 4, 64), (3, 1, 2, 64), (1, 801, 4, 64), (2, 129, 1, 64),
                                       (1, 1100, 2, 64), (2, 20, 4, 16), (1, 37, 2, 32)])
@@ -246,7 +262,40 @@ def test_attention(ops, dt, B, T, H, hd, variant):
     report("attention v%d %s B%d T%d H%d hd%d" % (variant, dt, B, T, H, hd), out.float().cpu(), ref, 6 * EPS[dt])
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_persistent_kernel_walks_several_items_per_workgroup(ops):
+    """more (batch, head, query tile) items than CUs: every workgroup of the ring kernel handles two items, the second one's
+    Q / first K,V group prefetched under the first; ragged T (keys and query rows beyond T are zero-filled / dropped by the
+    buffer descriptors), two query tiles per (batch, head)"""
+    ops.set_compute_dtype(torch.bfloat16)
+    B, T, H, hd = 40, 700, 4, 64                      # 2 query tiles x 4 heads x 40 = 320 items > 256 CUs
+    qkv = arr("aq3", (B * T, 3 * H * hd), 91, 1.0)
+    ops.set_attention_variant(3)
+    try:
+        out = ops.attention(dev(qkv).to(torch.bfloat16).contiguous(), B, T, H, hd)
+    finally:
+        ops.set_attention_variant(0)
+    ref = _attn_ref(q16(qkv, torch.bfloat16), B, T, H, hd)
+    report("attention ring, 320 items", out.float().cpu(), ref, 6 * EPS[torch.bfloat16])
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_attention_result_in_the_other_16bit_format(ops, variant):
+    """precision policy: bf16 attention core, O written as fp16 (and the reverse)"""
+    B, T, H, hd = 2, 300, 4, 64
+    qkv = arr("aq4", (B * T, 3 * H * hd), 92, 1.0)
+    for dt, odt in ((torch.bfloat16, torch.float16), (torch.float16, torch.bfloat16)):
+        ops.set_compute_dtype(dt)
+        ops.set_attention_variant(variant)
+        try:
+            out = ops.attention(dev(qkv).to(dt).contiguous(), B, T, H, hd, out_dtype=odt)
+        finally:
+            ops.set_attention_variant(0)
+        assert out.dtype == odt
+        ref = _attn_ref(q16(qkv, dt), B, T, H, hd)
+        report("attention v%d %s -> %s" % (variant, dt, odt), out.float().cpu(), ref, 6 * max(EPS[dt], EPS[odt]))
+
+
+@pytest.mark.parametrize("variant", [1, 3])
 def test_attention_online_softmax_rescale(ops, variant):
     """a spiked key late in the sequence forces the running-max rescale branch"""
     ops.set_compute_dtype(torch.float16)

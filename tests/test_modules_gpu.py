@@ -287,10 +287,87 @@ def test_mrstft_sizes_vs_golden(pkg):
     g = gold("g3_mrstft")
     noisy, clean = syn.synth_wave(2, 2048, 32)
     w = torch.from_numpy(noisy).cuda()
+    mr = pkg.cp.MultiResolutionSTFTLoss()
     for nf, hp in ((256, 64), (512, 128), (1024, 256)):
-        r, i = pkg.Fn.stft(w, nf, hp, nf)
-        mag = torch.sqrt(r ** 2 + i ** 2).transpose(1, 2)
-        assert maxerr(mag.cpu(), g["mag%d" % nf]) < 2e-4
+        mag = mr._stft_mag(w, nf, hp, nf)                                     # the reference's method name and [B, F, T] layout
+        assert mag.shape == g["mag%d" % nf].shape and maxerr(mag.cpu(), g["mag%d" % nf]) < 2e-4
+
+
+def test_loss_mirrors_by_their_reference_names_vs_golden(pkg):
+    """si_snr_loss / MultiResolutionSTFTLoss (training/conformer_pipeline.py:52, :74) called exactly as the reference's
+    training loop calls them: values against the reference's own outputs (g3), gradients against torch autograd of the
+    oracle's restatement on the same inputs"""
+    g = gold("g3_mrstft")
+    noisy, clean = syn.synth_wave(2, 2048, 32)
+    est = torch.from_numpy(noisy).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(clean).cuda()
+    l_si = pkg.cp.si_snr_loss(est, tgt)
+    mr = pkg.cp.MultiResolutionSTFTLoss()
+    l_mr = mr(est, tgt)
+    print("si_snr_loss %.6f (ref %.6f)   MultiResolutionSTFTLoss %.6f (ref %.6f)" %
+          (float(l_si), float(g["sisnr"]), float(l_mr), float(g["loss"])))
+    assert abs(float(l_si) - float(g["sisnr"])) < 2e-4 and abs(float(l_mr) - float(g["loss"])) < 2e-4
+    g_si, = torch.autograd.grad(l_si, est, retain_graph=True)
+    g_mr, = torch.autograd.grad(l_mr, est)
+    e2 = torch.from_numpy(noisy).requires_grad_(True)
+    r_si, = torch.autograd.grad(orc.si_snr_loss(e2, torch.from_numpy(clean)), e2)
+    r_mr, = torch.autograd.grad(orc.mr_stft_loss(e2, torch.from_numpy(clean)), e2)
+    assert rel(g_si.cpu(), r_si.numpy()) < 1e-4, rel(g_si.cpu(), r_si.numpy())
+    assert rel(g_mr.cpu(), r_mr.numpy()) < 2e-3, rel(g_mr.cpu(), r_mr.numpy())
+    # a non-default resolution list runs the exact-fp32 STFT path
+    mr2 = pkg.cp.MultiResolutionSTFTLoss([128, 320], [32, 80], [128, 320])
+    l2 = mr2(est, tgt)
+    r2 = orc.mr_stft_loss(e2, torch.from_numpy(clean), (128, 320), (32, 80), (128, 320))
+    assert abs(float(l2) - float(r2)) < 2e-4
+    g2, = torch.autograd.grad(l2, est)
+    rr2, = torch.autograd.grad(r2, e2)
+    assert rel(g2.cpu(), rr2.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("custom", [False, True])
+def test_pipeline_compute_loss_by_its_reference_signature(pkg, custom, tmp_path, monkeypatch):
+    """ConformerPipeline._compute_loss(noisy_real, noisy_imag, clean_wav, clean_real, clean_imag, mr_stft_fn) (:539), with
+    the reference's default MultiResolutionSTFTLoss (fused objective node) and with a custom resolution list (composed from
+    si_snr_loss / L1 magnitude / mr_stft_fn); save_model -> load_model(path=None) round trip of the checkpoint format"""
+    pkg.ops.set_compute_dtype(torch.float16)
+    g = gold("g8_enhancer")
+    from sincformer_metacog_speech_enhancement_amd import config
+    monkeypatch.setattr(config, "MODEL_DIR", str(tmp_path))
+    pipe = pkg.cp.ConformerPipeline()
+    pipe.model = load(pkg.cp.SpeechEnhancer(n_freq=129), "SpeechEnhancer", 81)
+    noisy, clean = syn.synth_wave(2, 2000, 82)
+    nw, cw = torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda()
+    nr, ni = pkg.cp.batch_stft(nw, 256, 80, 160)
+    cr, ci = pkg.cp.batch_stft(cw, 256, 80, 160)
+    sizes = ([128, 320], [32, 80], [128, 320]) if custom else (None, None, None)
+    mr = pkg.cp.MultiResolutionSTFTLoss(*sizes)
+    with torch.no_grad():
+        total, neg = pipe._compute_loss(nr, ni, cw, cr, ci, mr)
+    if custom:
+        sd = synth_sd("SpeechEnhancer", 81)
+        onr, oni = orc.stft(torch.from_numpy(noisy))
+        ocr, oci = orc.stft(torch.from_numpy(clean))
+        er, ei, _ = orc.speech_enhancer_forward(sd, onr, oni, 4)
+        wav = orc.istft(er, ei, 2000)
+        mag = (torch.sqrt(er ** 2 + ei ** 2 + 1e-8) - torch.sqrt(ocr ** 2 + oci ** 2 + 1e-8)).abs().mean()
+        want_neg = orc.si_snr_loss(wav, torch.from_numpy(clean))
+        want = want_neg + 0.5 * mag + orc.mr_stft_loss(wav, torch.from_numpy(clean), (128, 320), (32, 80), (128, 320))
+        want, want_neg = float(want), float(want_neg)
+    else:
+        want, want_neg = float(g["loss"]), float(g["neg_sisnr"])
+    print("_compute_loss custom=%s: %.5f (ref %.5f), neg_sisnr %.5f (ref %.5f)" % (custom, float(total), want, float(neg), want_neg))
+    assert abs(float(total) - want) < 1e-2 and abs(float(neg) - want_neg) < 1e-2
+    # checkpoint round trip through the reference's file names and dict layout
+    pipe.save_model()
+    pipe._save_best()
+    ck = torch.load(str(tmp_path / "conformer_final.pt"), map_location="cpu", weights_only=True)
+    assert ck["model_class"] == "SpeechEnhancer" and set(ck["model_state"]) == set(pipe.model.state_dict())
+    assert (tmp_path / "best_conformer.pt").exists()
+    pipe2 = pkg.cp.ConformerPipeline()
+    pipe2.load_model()                                                       # path=None -> MODEL_DIR/conformer_final.pt
+    y1 = pipe.enhance_signal(noisy[0])
+    y2 = pipe2.enhance_signal(noisy[0])
+    assert np.array_equal(y1, y2)
 
 
 # ---------------------------------------------------------------------------

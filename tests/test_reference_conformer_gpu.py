@@ -1,8 +1,10 @@
-"""The reference's own tests/test_conformer.py (TestComplexConformer, 4 tests), run against the HIP mirror of
-models.conformer.ComplexConformer with device tensors.  Like the reference's tests the module stays in its default
-train() mode, so this is the training-mode forward (dropout — `dropout=0.0` silently becomes 0.1 through the `x or
-config.X` defaulting of models/conformer.py:179 —, BatchNorm batch statistics) and, in test_gradient_flow, the whole
-HIP backward down to the inputs.  The numeric check at the end adds what the reference's tests do not have."""
+"""ComplexConformer at the configuration the reference's own plumbing test uses (n_freq 32, d_model 64, 2 blocks,
+4 heads -> head_dim 16, d_ff 128, depthwise kernel 7: the small-shape attention / depthwise kernels), in the module's
+default train() mode: dropout is active (`dropout=0.0` silently becomes 0.1 through the `x or config.X` defaulting of
+models/conformer.py:179) and BatchNorm uses batch statistics.  The reference checks plumbing only; the
+checks below are this build's own: plumbing properties of the HIP training-mode forward / backward, then a numeric
+comparison against torch autograd of the oracle.  The eval-mode outputs of this configuration are pinned by the reference's
+golden vector g4_cconf_small (tests/test_modules_gpu.py)."""
 import numpy as np
 import pytest
 import torch
@@ -11,52 +13,59 @@ from helpers import arr, maxerr, rmse, synth_sd
 from oracle import sfm_oracle as orc
 
 pytestmark = pytest.mark.gpu
+SMALL = dict(n_freq=32, d_model=64, num_blocks=2, num_heads=4, d_ff=128, kernel_size=7, dropout=0.0)
 
 
-class TestComplexConformer:
-    @pytest.fixture
-    def conformer(self):
-        from sincformer_metacog_speech_enhancement_amd.models.conformer import ComplexConformer
-        torch.manual_seed(0)
-        return ComplexConformer(n_freq=32, d_model=64, num_blocks=2, num_heads=4, d_ff=128, kernel_size=7,
-                                dropout=0.0).cuda()
+def _small_conformer(seed=0):
+    from sincformer_metacog_speech_enhancement_amd.models.conformer import ComplexConformer
+    torch.manual_seed(seed)
+    return ComplexConformer(**SMALL).cuda()
 
-    def test_forward_shape(self, conformer):
-        batch, time, n_freq = 2, 20, 32
-        stft_real = torch.randn(batch, time, n_freq).cuda()
-        stft_imag = torch.randn(batch, time, n_freq).cuda()
 
-        mask_real, mask_imag = conformer(stft_real, stft_imag)
-        assert mask_real.shape == (batch, time, n_freq)
-        assert mask_imag.shape == (batch, time, n_freq)
-        assert torch.isfinite(mask_real).all() and torch.isfinite(mask_imag).all()
+def _spectrum(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).cuda(), torch.randn(*shape, generator=g).cuda()
 
-    def test_complex_mask_application(self, conformer):
-        batch, time, n_freq = 2, 10, 32
-        stft_r = torch.randn(batch, time, n_freq).cuda()
-        stft_i = torch.randn(batch, time, n_freq).cuda()
 
-        mask_r, mask_i = conformer(stft_r, stft_i)
-        enh_r, enh_i = conformer.apply_mask(stft_r, stft_i, mask_r, mask_i)
+@pytest.mark.parametrize("shape", [(2, 20, 32), (1, 10, 32), (3, 7, 32)])
+def test_train_mode_masks_keep_the_spectrum_shape_and_stay_finite(shape):
+    net = _small_conformer()
+    assert net.training                                        # constructed modules are in train() mode, like the reference's
+    re, im = _spectrum(shape, 1)
+    m_re, m_im = net(re, im)
+    for m in (m_re, m_im):
+        assert tuple(m.shape) == shape and m.dtype == torch.float32 and bool(torch.isfinite(m).all())
+    # dropout is live in this mode (the 0.0 -> 0.1 quirk): two passes over the same input differ
+    m_re2, _ = net(re, im)
+    assert not torch.equal(m_re, m_re2)
 
-        assert enh_r.shape == stft_r.shape
-        assert enh_i.shape == stft_i.shape
 
-    def test_gradient_flow(self, conformer):
-        stft_r = torch.randn(1, 10, 32).cuda().requires_grad_(True)
-        stft_i = torch.randn(1, 10, 32).cuda().requires_grad_(True)
+def test_apply_mask_is_the_complex_product_of_spectrum_and_mask():
+    net = _small_conformer()
+    re, im = _spectrum((2, 10, 32), 2)
+    m_re, m_im = net(re, im)
+    e_re, e_im = net.apply_mask(re, im, m_re, m_im)
+    assert e_re.shape == re.shape and e_im.shape == im.shape
+    want = torch.complex(re, im) * torch.complex(m_re.detach(), m_im.detach())
+    assert maxerr(e_re.detach().cpu(), want.real.cpu()) < 1e-5 and maxerr(e_im.detach().cpu(), want.imag.cpu()) < 1e-5
 
-        mask_r, mask_i = conformer(stft_r, stft_i)
-        loss = mask_r.sum() + mask_i.sum()
-        loss.backward()
 
-        assert stft_r.grad is not None
-        assert torch.isfinite(stft_r.grad).all() and float(stft_r.grad.abs().max()) > 0
-        assert all(p.grad is not None for p in conformer.parameters())
+def test_backward_reaches_the_inputs_and_every_parameter():
+    net = _small_conformer()
+    re, im = _spectrum((1, 10, 32), 3)
+    re.requires_grad_(True)
+    im.requires_grad_(True)
+    m_re, m_im = net(re, im)
+    (m_re.sum() + m_im.sum()).backward()
+    for t in (re, im):
+        assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+    missing = [n for n, p in net.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+    assert not missing, missing
 
-    def test_parameter_count(self, conformer):
-        count = conformer.count_parameters()
-        assert count > 0
+
+def test_count_parameters_equals_the_sum_over_the_state():
+    net = _small_conformer()
+    assert net.count_parameters() == sum(p.numel() for p in net.parameters()) == 135424
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
