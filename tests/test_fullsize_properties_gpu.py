@@ -189,9 +189,18 @@ def test_long_utterances_with_memory_vs_oracle_and_batch_independence():
     path = path.cuda().eval()
     noisy, _ = syn.synth_wave(Bl, Ll, 396)
     wave = torch.from_numpy(noisy).cuda()
+    # the attention kernel is chosen by shape (the persistent ring kernel needs enough (batch, head, query tile) items to
+    # fill the chip): pin it, so that "one utterance alone" and "the same utterance in a batch" run the same arithmetic
+    # and the independence check below can be held to fp32 rounding
+    ops.set_attention_variant(3)
+    try:
+        with torch.no_grad():
+            out = path(wave)
+            one = path(wave[1:2].contiguous())
+    finally:
+        ops.set_attention_variant(0)
     with torch.no_grad():
-        out = path(wave)
-        one = path(wave[1:2].contiguous())
+        auto_one = path(wave[1:2].contiguous())               # default selection at batch 1: the 32-rows-per-wave kernel
     T = 1 + Ll // 80
     assert tuple(out["mask_real"].shape) == (Bl, T, 129) and tuple(out["enhanced"].shape) == (Bl, Ll)
     assert all(bool(torch.isfinite(v).all()) for v in out.values() if isinstance(v, torch.Tensor) and v.dtype.is_floating_point)
@@ -199,6 +208,7 @@ def test_long_utterances_with_memory_vs_oracle_and_batch_independence():
     assert float(mag.max()) <= 1.0 + 1e-5
     for k in ("mask_real", "mask_imag", "enhanced"):
         assert rmse(one[k].cpu(), out[k][1:2].cpu()) < 2e-5, k
+        assert rmse(auto_one[k].cpu(), out[k][1:2].cpu()) < 3e-4, k      # other kernel: same result up to 16-bit rounding of P
     ref = orc.enhance_path(sds, noisy[1:2], 16000, use_memory=True)
     got = torch.cat([out["mask_real"][1:2], out["mask_imag"][1:2]], -1).cpu()
     want = torch.cat([ref["mask_real"], ref["mask_imag"]], -1)
