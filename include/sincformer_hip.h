@@ -47,7 +47,7 @@ int sfm_abi_version(void);
  * :175,179 (real/imag proj), :185,187 (uncertainty head); agents/cpea.py:56-76.
  *   A   [B, Lin, Cin] 16-bit (position stride lda >= Cin, batch stride a_batch_stride; elements)
  *   W   [Npad, Kpad] 16-bit, row n = output channel, K order = (tap, cin);
- *       zero padded; Kpad % 64 == 0 (32 for variant 1), Npad % 64 == 0
+ *       zero padded; Kpad % 64 == 0, Npad % 64 == 0
  *   out row (b, l) = epi( sum_{tap,ci} A[b, l*stride-pad+tap, ci] W[n,(tap,ci)] + bias[n] )
  *   gn_partial (optional): per (batch, row-half-tile, group) {sum, sumsq} of the
  *       pre-activation outputs, [B][2*ceil(Lout/128)][N/gn_group][2] floats.
@@ -60,8 +60,8 @@ int sfm_gemm16(const void* A, const void* W, const float* bias, void* out, const
                int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
                int nsplit, int dtype, void* stream);
 
-/* Same contract with an explicit kernel variant: 0 auto, 1 register-staged (gemm16.hip),
- * 2 / 3 LDS-DMA ring with 2 / 3 stages (gemm16v2.hip).  sfm_gemm16 == variant 0. */
+/* Same contract with an explicit kernel variant (A/B measurements): 0 auto, 2 = 128-row tiles with a 2-stage LDS-DMA ring,
+ * 6 = persistent form, 9 = 256-row wide tiles, 10 = 512 x 128 tiles (gemm16v2.hip).  sfm_gemm16 == variant 0. */
 int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,
                   float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
                   long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
@@ -83,11 +83,21 @@ int sfm_gemm16_train(const void* A, const void* W, const float* bias, void* out,
 int sfm_gemm16_swish(const void* A, const void* W, const float* bias, void* out, const void* aux, void* out2, int M, int Cin,
                      int lda, int Kpad, int N, int Npad, int ldo, int backward, float p_drop, unsigned int seed, int dtype,
                      void* stream);
-int sfm_gemm16_v1(const void* A, const void* W, const float* bias, void* out, const float* resid,
-                  float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
-                  long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
-                  int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
-                  int nsplit, int dtype, void* stream);
+/* Conv1d (channels-last) whose INPUT is normalised while the operand is staged: replaces the
+ * GroupNorm -> GELU -> Conv1d chains of the PerceptionAgent (agents/perception.py:192-206 `_make_block`, :121-129
+ * `_ResidualBlock.forward`, :167-171 `downsample`) without materialising the normalised activation:
+ *     x = GELU(sc1[b,c] * x1 + sh1[b,c]  [+ sc2[b,c] * x2 + sh2[b,c]]),   out = Conv1d(x; W, bias, ksize, stride, pad)
+ *   x1, x2 [B, Lin, Cin] 16-bit raw outputs of the producing conv(s); sc / sh [B, Cin] fp32 from sfm_gn_finalize
+ *   W [N][ksize * Cin] 16-bit tap-major (sfm_gemm16's layout), bias [N]; out [B, Lout, N] (out_f32 as sfm_gemm16)
+ *   gn_partial: as sfm_gemm16 ([B][2 ceil(Lout/128)][N/gn_group][2]) or NULL
+ *   Ws, bias_s, out_s, gn_partial_s: optional Conv1d(Cin -> N, 1, stride 2) of a residual block's skip branch on the same
+ *   x, computed from the same staged input (N = 128, ksize 7 only)
+ * Shapes: Cin % 64 == 0; (ksize, stride, pad, N, #inputs) in {(7,2,3,128 + skip,1|2), (7,2,3,256,2), (3,1,1,128|256,1),
+ * (5,2,2,256,2), (1,2,0,256,2)}; anything else returns SFM_ERR_SHAPE (-2). */
+int sfm_conv16p(const void* x1, const float* sc1, const float* sh1, const void* x2, const float* sc2, const float* sh2,
+                const void* W, const float* bias, void* out, float* gn_partial, const void* Ws, const float* bias_s,
+                void* out_s, float* gn_partial_s, int B, int Lin, int Cin, int N, int ksize, int stride, int pad,
+                int out_f32, int gn_group, int dtype, void* stream);
 
 /* out[b,m,n] = bias[n] + sum_k sig[b, m*hop + k - padl] * Wt[k][n], exact fp32 on
  * v_mfma_f32_32x32x2_f32.  Replaces F.conv1d of SincConv1d (agents/perception.py:117),

@@ -1,0 +1,380 @@
+#include "gemm16_epi.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv16p: the PerceptionAgent's Conv1d layers (agents/perception.py:192-206, 167-171) with the GroupNorm + GELU of their
+// INPUT applied while the operand is staged, so the normalised activation never exists in HBM:
+//     y[b, l, n] = bias[n] + sum_{t, c} x[b, l s - p + t, c] W[n, (t, c)],   x = GELU( sc1[b,c] r1 + sh1[b,c]  [+ sc2[b,c] r2 + sh2[b,c]] )
+// r1 (r2) = the RAW output of the producing conv(s), sc / sh = the finalised GroupNorm scale / shift of that output
+// (sfm_gn_finalize); the two-input form is the residual block's  GELU(GN(main) + GN(skip))  (agents/perception.py:129).
+// What changes against sfm_gemm16's implicit GEMM:
+//   * the input rows of a 128-row output tile ("patch": 127 s + k rows x 64 channels) are fetched ONCE, transformed in
+//     registers (unpack, scale / shift, exact-erf GELU by Abramowitz-Stegun 7.1.26, |err| < 1.5e-7, pack) and written to LDS;
+//     the k taps then read the same patch at shifted rows (stride 2: even / odd input rows live in two planes, so that the
+//     rows of consecutive outputs stay consecutive in LDS and the usual chunk swizzle keeps ds_read_b128 conflict-free).
+//     The implicit im2col of sfm_gemm16 re-reads every input row k / s times from L2 and cannot transform in flight
+//     (LDS-DMA), which is why a separate gn_apply pass (read + write of every activation) used to sit between two convs;
+//   * more than 64 input channels: 64-channel slabs, one patch at a time, accumulators kept across slabs;
+//   * the 1x1 stride-2 skip conv of a residual block reads the centre tap of the same patch: SKIP adds its k-tiles and a
+//     second accumulator / output (N = 128 layers); N = 256 runs as two 128-column passes over the same patch (NPASS);
+//   * weights stream L2 -> LDS by LDS-DMA in 128 x 64 tiles through a 2-stage ring, one barrier per k-tile, as in gemm16w.
+// LDS: patch 16.6-33.8 KB + ring 32 KB: two workgroups per CU, so one's staging (VALU) overlaps the other's MFMA loop.
+// Epilogue = gemm16_epilogue_strips (bias, GroupNorm partials of the raw output, 16-byte row stores).
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvPParams {
+  Gemm2Params g;                                       // main conv: W [N][KS * Cin] tap-major, bias, out, gn_partial, ...
+  Gemm2Params gs;                                      // skip conv (SKIP): W [N][Cin], bias, out, gn_partial
+  const u16* x1; const float* sc1; const float* sh1;
+  const u16* x2; const float* sc2; const float* sh2;
+  int Lin, Cin, pad, nMt;
+  long long x_batch_stride;
+};
+
+__device__ __forceinline__ float gelu_as(float z) {    // z Phi(z), erf by A&S 7.1.26 (the backward in gn_bwd.hip uses the same)
+  const float ax = fabsf(z) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);     // 1 ulp: the result is rounded to 16 bits afterwards
+  const float ex = __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * ex;
+  return z * (0.5f + 0.5f * copysignf(erfa, z));
+}
+
+// Epilogue of one 64 x 64 wave tile: bias, GroupNorm partial sums of the raw output, 16-byte row stores.  (The general
+// gemm16_epilogue_strips carries every activation / residual / dropout mode of sfm_gemm16 inline in each of its 8 unrolled
+// passes - 28 k instructions per instance; this kernel needs none of them, and two instances of that per kernel made the
+// instruction fetch, not the arithmetic, the bound.)
+template <class T>
+__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], float* img, int lane, int b, int colb,
+                                               int row_base) {
+  constexpr int IMG_LD = 64 + 4;
+  const int l31 = lane & 31, hl = lane >> 5;
+  const int c8 = (lane & 7) * 8, rsub = lane >> 3;     // 8 column chunks x 8 rows per pass
+  const int ncol0 = colb + c8;
+  float bia[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bia[e] = g.bias ? g.bias[ncol0 + e] : 0.f;
+  const long long obase = (long long)b * g.o_batch_stride;
+  float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      const int m = row_base + i * 32 + q * 8 + rsub;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[rsub * IMG_LD + c8]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[rsub * IMG_LD + c8 + 4]);
+      float v[8] = {x0[0] + bia[0], x0[1] + bia[1], x0[2] + bia[2], x0[3] + bia[3],
+                    x1[0] + bia[4], x1[1] + bia[5], x1[2] + bia[6], x1[3] + bia[7]};
+      if (m < g.Lout) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gsum += v[e]; gsq += v[e] * v[e]; }
+        const long long orow = obase + (long long)m * g.ldo + ncol0;
+        if (g.out_f32 == 1) {
+          float* op = reinterpret_cast<float*>(g.out) + orow;
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          u32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(v[2 * e], v[2 * e + 1], g.out_f32 == 2);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(g.out) + orow) = pk;
+        }
+      }
+    }
+  if (g.gn_partial) {
+    for (int o = 8; o < 64; o <<= 1) {                 // lanes with the same column chunk hold different rows
+      gsum += __shfl_xor(gsum, o, 64);
+      gsq += __shfl_xor(gsq, o, 64);
+    }
+    const int cpg = g.gn_group >> 3;                   // 8-column chunks per group (1, 2 or 4)
+    for (int o = 1; o < cpg; o <<= 1) {
+      gsum += __shfl_xor(gsum, o, 64);
+      gsq += __shfl_xor(gsq, o, 64);
+    }
+    if (lane < 8 && (lane % cpg) == 0 && (row_base >> 6) < g.gn_slots) {
+      const int ngroups = g.N / g.gn_group;
+      const long long sl = ((long long)b * g.gn_slots + (row_base >> 6)) * ngroups + ncol0 / g.gn_group;
+      g.gn_partial[sl * 2 + 0] = gsum;
+      g.gn_partial[sl * 2 + 1] = gsq;
+    }
+  }
+}
+
+template <class T, int KS, int STRIDE, int NPASS, bool SKIP, bool TWO_IN>
+__global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
+  constexpr int R = 127 * STRIDE + KS;                 // input rows of a 128-row output tile
+  constexpr int PLANES = (STRIDE == 2 && KS > 1) ? 2 : 1;
+  constexpr int PR = (STRIDE == 2) ? ((R + 1) / 2 + 1) / 2 * 2 : (R + 1) / 2 * 2;   // rows per plane (even)
+  constexpr int PATCH = PLANES * PR * 128;             // bytes
+  constexpr int WT = 128 * 128;                        // one weight tile: 128 output channels x 64 k
+  constexpr int TPS = NPASS * KS + (SKIP ? 1 : 0);     // weight tiles per 64-channel slab
+  constexpr int IMG_LD = 64 + 4;
+  static_assert(!SKIP || NPASS == 1, "the fused skip conv needs N = 128");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ring = smem + PATCH;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hl = lane >> 5;
+
+  int id = blockIdx.x;                                 // XCD-aware order: neighbouring tiles (shared halo rows) on one XCD
+  {
+    const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int mtile = id % p.nMt, b = id / p.nMt;
+  const int l0 = mtile * 128;
+  const int nslab = p.Cin >> 6;
+  const int Q = nslab * TPS;                           // weight tiles of this output tile
+
+  auto w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.g.W, 0, p.g.w_records, 0x00020000);
+  auto ws_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(SKIP ? p.gs.W : p.g.W), 0, SKIP ? p.gs.w_records : p.g.w_records, 0x00020000);
+  // LDS-DMA lane coordinates of a weight tile (8 rows x 128 B per instruction, 4 instructions per wave)
+  int b_row[4], b_swz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b_row[i] = (wave * 4 + i) * 8 + (lane >> 3);
+    b_swz[i] = ((lane & 7) ^ ((b_row[i] >> 1) & 7)) * 8;
+  }
+  // weight tile q of the sequence: slab = q / TPS; within the slab: (pass, tap) main tiles, then the skip tile
+  auto issue_w = [&](int q) {
+    const int slab = q / TPS, j = q - slab * TPS;
+    unsigned char* dst = ring + (q & 1) * WT;
+    if (SKIP && j == TPS - 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws_rs, (lds_ptr_t)(dst + (wave * 4 + i) * 1024), 16,
+                                                 (b_row[i] * p.gs.Kpad + slab * 64 + b_swz[i]) * 2, 0, 0, 0);
+    } else {
+      const int np = j / KS, t = j - np * KS;
+      const int koff = t * p.Cin + slab * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(dst + (wave * 4 + i) * 1024), 16,
+                                                 ((np * 128 + b_row[i]) * p.g.Kpad + koff + b_swz[i]) * 2, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[NPASS][2][2], accs[2][2];
+#pragma unroll
+  for (int n = 0; n < NPASS; ++n)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[i][j][r] = 0.f;
+
+  int fb_off[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wn * 64 + j * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb_off[j][s] = row * 128 + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
+  }
+
+  // ---- patch staging: thread = (16-byte chunk c of the 64-channel slab, row of a 32-row pass) ----
+  const int sc_ = tid & 7, srow = tid >> 3;
+  const u16* x1b = p.x1 + (long long)b * p.x_batch_stride;
+  const u16* x2b = TWO_IN ? p.x2 + (long long)b * p.x_batch_stride : nullptr;
+  auto stage_patch = [&](int slab) {
+    const int ch0 = slab * 64 + sc_ * 8;
+    float a1[8], d1[8], a2[8], d2[8];
+    {
+      const f32x4* ps = reinterpret_cast<const f32x4*>(p.sc1 + (long long)b * p.Cin + ch0);
+      const f32x4* ph = reinterpret_cast<const f32x4*>(p.sh1 + (long long)b * p.Cin + ch0);
+      const f32x4 s0 = ps[0], s1 = ps[1], h0 = ph[0], h1 = ph[1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a1[e] = s0[e]; a1[4 + e] = s1[e]; d1[e] = h0[e]; d1[4 + e] = h1[e]; }
+      if (TWO_IN) {
+        const f32x4* qs = reinterpret_cast<const f32x4*>(p.sc2 + (long long)b * p.Cin + ch0);
+        const f32x4* qh = reinterpret_cast<const f32x4*>(p.sh2 + (long long)b * p.Cin + ch0);
+        const f32x4 t0 = qs[0], t1 = qs[1], g0 = qh[0], g1 = qh[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a2[e] = t0[e]; a2[4 + e] = t1[e]; d1[e] += g0[e]; d1[4 + e] += g1[e]; }
+      }
+    }
+    constexpr int JSTEP = (PLANES == 1 && STRIDE == 2) ? 2 : 1;      // k = 1, stride 2: only the even input rows are read
+    constexpr int NROWS = (R + JSTEP - 1) / JSTEP;
+    constexpr int NP = (NROWS + 31) / 32;                            // 32-row passes
+    constexpr int UN = TWO_IN ? 2 : 3;                               // passes in flight (registers: 4 per input and pass)
+#pragma unroll 1
+    for (int p0 = 0; p0 < NP; p0 += UN) {
+      u32x4 v1[UN], v2[UN];
+      bool ok[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int jr = (p0 + u) * 32 + srow;
+        const int pos = l0 * STRIDE - p.pad + jr * JSTEP;
+        ok[u] = (p0 + u) < NP && jr < NROWS && pos >= 0 && pos < p.Lin;
+        v1[u] = u32x4{0u, 0u, 0u, 0u};
+        v2[u] = u32x4{0u, 0u, 0u, 0u};
+        if (ok[u]) {
+          v1[u] = *reinterpret_cast<const u32x4*>(x1b + (long long)pos * p.Cin + ch0);
+          if (TWO_IN) v2[u] = *reinterpret_cast<const u32x4*>(x2b + (long long)pos * p.Cin + ch0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int jr = (p0 + u) * 32 + srow;
+        if ((p0 + u) < NP && jr < NROWS) {
+          u32x4 o = {0u, 0u, 0u, 0u};                                // rows outside [0, Lin): the conv's zero padding of x
+          if (ok[u]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float z0 = T::to_f32((u16)(v1[u][e] & 0xffffu)) * a1[2 * e] + d1[2 * e];
+              float z1 = T::to_f32((u16)(v1[u][e] >> 16)) * a1[2 * e + 1] + d1[2 * e + 1];
+              if (TWO_IN) {
+                z0 += T::to_f32((u16)(v2[u][e] & 0xffffu)) * a2[2 * e];
+                z1 += T::to_f32((u16)(v2[u][e] >> 16)) * a2[2 * e + 1];
+              }
+              o[e] = pack2<T>(gelu_as(z0), gelu_as(z1));
+            }
+          }
+          const int j = jr * JSTEP;
+          const int lrow = (PLANES == 2) ? (j & 1) * PR + (j >> 1) : jr;
+          *reinterpret_cast<u32x4*>(smem + lrow * 128 + ((sc_ ^ ((lrow >> 1) & 7)) << 4)) = o;
+        }
+      }
+    }
+  };
+
+  // ---- one weight tile against the patch rows of tap `t` ----
+  auto mma_tile = [&](int q, int t, f32x16 (&a)[2][2]) {
+    const unsigned char* wb = ring + (q & 1) * WT;
+    int arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rw = wm * 64 + i * 32 + l31;
+      arow[i] = (PLANES == 2) ? (t & 1) * PR + rw + (t >> 1) : ((STRIDE == 2) ? rw : rw + t);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[i] = *reinterpret_cast<const u32x4*>(smem + arow[i] * 128 + (((2 * s + hl) ^ ((arow[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(wb + fb_off[j][s]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a[i][j] = T::mfma(fa[i], fb[j], a[i][j]);
+    }
+  };
+
+  issue_w(0);
+  for (int slab = 0; slab < nslab; ++slab) {
+    if (slab > 0) __syncthreads();                     // every wave is done reading the previous slab's patch
+    stage_patch(slab);
+    __syncthreads();                                   // patch complete
+    const int q0 = slab * TPS;
+#pragma unroll
+    for (int j = 0; j < TPS; ++j) {
+      const int q = q0 + j;
+      wait_vmcnt<0>();                                 // this wave's share of weight tile q has landed
+      __builtin_amdgcn_s_barrier();                    // ... everyone's has, and tile q-1 is no longer being read
+      if (q + 1 < Q) issue_w(q + 1);
+      if (SKIP && j == TPS - 1) {
+        mma_tile(q, p.pad, accs);                      // 1x1 stride-2 conv = the centre tap of the same patch
+      } else {
+        const int np = j / KS, t = j - np * KS;
+        if (np == 0) mma_tile(q, t, acc[0]);
+        else mma_tile(q, t, acc[NPASS - 1]);
+      }
+    }
+  }
+  __syncthreads();                                     // the ring becomes the epilogue strips
+  float* img = reinterpret_cast<float*>(ring) + wave * (8 * IMG_LD);
+#pragma unroll
+  for (int n = 0; n < NPASS; ++n) convp_epilogue<T>(p.g, acc[n], img, lane, b, n * 128 + wn * 64, l0 + wm * 64);
+  if (SKIP) convp_epilogue<T>(p.gs, accs, img, lane, b, wn * 64, l0 + wm * 64);
+}
+
+template <class T, int KS, int STRIDE, int NPASS, bool SKIP, bool TWO_IN>
+static int launch_convp(const ConvPParams& p, hipStream_t stream) {
+  constexpr int R = 127 * STRIDE + KS;
+  constexpr int PLANES = (STRIDE == 2 && KS > 1) ? 2 : 1;
+  constexpr int PR = (STRIDE == 2) ? ((R + 1) / 2 + 1) / 2 * 2 : (R + 1) / 2 * 2;
+  constexpr int lds = PLANES * PR * 128 + 2 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv16p_kernel<T, KS, STRIDE, NPASS, SKIP, TWO_IN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  SFM_LAUNCH((conv16p_kernel<T, KS, STRIDE, NPASS, SKIP, TWO_IN>), dim3(p.nMt * p.g.B), dim3(256), lds, stream, p);
+  return SFM_OK;
+}
+
+static void convp_fill(Gemm2Params& g, const void* W, const float* bias, void* out, float* gn_partial, int B, int Lout, int N,
+                       int Kpad, int out_f32, int gn_group) {
+  g = Gemm2Params{};
+  g.W = (const u16*)W; g.bias = bias; g.out = out; g.gn_partial = gn_partial;
+  g.B = B; g.Lout = Lout; g.N = N; g.Npad = N; g.K = Kpad; g.Kpad = Kpad; g.ldo = N; g.o_batch_stride = (long long)Lout * N;
+  g.alpha = 1.0f; g.epi = EPI_NONE; g.out_f32 = out_f32; g.gn_group = gn_group; g.nsplit = 0;
+  g.w_records = (int)((long long)N * Kpad * 2);
+  g.gn_slots = 2 * ((Lout + 127) / 128);
+  const int osz = out_f32 == 1 ? 4 : 2;
+  g.vec_ok = ((((uintptr_t)out) % 16) == 0 && ((N * osz) % 16) == 0) ? 1 : 0;
+  g.p_drop = 0.f; g.seed = 0u; g.aux = nullptr; g.out2 = nullptr; g.resid = nullptr;
+}
+
+// Conv1d(Cin -> N, ksize, stride, zero padding `pad`) on x = GELU(sc1 * x1 + sh1 [+ sc2 * x2 + sh2]) (see conv16p above).
+//   x1, x2 [B, Lin, Cin] 16-bit channels-last raw conv outputs; sc / sh [B, Cin] fp32 (sfm_gn_finalize)
+//   W [N][ksize * Cin] 16-bit tap-major (the layout sfm_gemm16 takes), bias [N] fp32; out [B, Lout, N] (out_f32 as sfm_gemm16);
+//   gn_partial [B][2 ceil(Lout / 128)][N / gn_group][2] or NULL
+//   Ws / bias_s / out_s / gn_partial_s: optional fused Conv1d(Cin -> N, 1, stride 2) on the same x (N = 128, ksize 7 only)
+// Supported (the PerceptionAgent's layers): Cin % 64 == 0 and (ksize, stride, pad, N, inputs) in {(7, 2, 3, 128 + fused skip, 1 | 2),
+// (7, 2, 3, 256, 2), (3, 1, 1, 128 | 256, 1), (5, 2, 2, 256, 2), (1, 2, 0, 256, 2)}; anything else returns SFM_ERR_SHAPE.
+extern "C" int sfm_conv16p(const void* x1, const float* sc1, const float* sh1, const void* x2, const float* sc2, const float* sh2,
+                           const void* W, const float* bias, void* out, float* gn_partial, const void* Ws, const float* bias_s,
+                           void* out_s, float* gn_partial_s, int B, int Lin, int Cin, int N, int ksize, int stride, int pad,
+                           int out_f32, int gn_group, int dtype, void* stream) {
+  if (!x1 || !sc1 || !sh1 || !W || !out) return SFM_ERR_ARG;
+  if ((x2 != nullptr) != (sc2 != nullptr) || (x2 != nullptr) != (sh2 != nullptr)) return SFM_ERR_ARG;
+  if (B <= 0 || Lin <= 0 || Cin <= 0 || (Cin % 64) != 0 || (N != 128 && N != 256)) return SFM_ERR_SHAPE;
+  if (out_f32 < 0 || out_f32 > 2) return SFM_ERR_SHAPE;
+  if (gn_partial && gn_group != 8 && gn_group != 16 && gn_group != 32) return SFM_ERR_SHAPE;
+  if ((long long)Lin * Cin * 2 >= (1LL << 31) || (long long)N * ksize * Cin * 2 >= (1LL << 31)) return SFM_ERR_SHAPE;
+  const int Lout = (Lin + 2 * pad - ksize) / stride + 1;
+  if (Lout <= 0) return SFM_ERR_SHAPE;
+  const bool skip = Ws != nullptr;
+  if (skip && (!out_s || N != 128 || ksize != 7 || stride != 2)) return SFM_ERR_SHAPE;
+  if ((((uintptr_t)out) % 16) != 0 || (out_s && (((uintptr_t)out_s) % 16) != 0)) return SFM_ERR_SHAPE;   // 16-byte row stores
+  ConvPParams p{};
+  convp_fill(p.g, W, bias, out, gn_partial, B, Lout, N, ksize * Cin, out_f32, gn_group);
+  if (skip) convp_fill(p.gs, Ws, bias_s, out_s, gn_partial_s, B, Lout, N, Cin, out_f32, gn_group);
+  p.x1 = (const u16*)x1; p.sc1 = sc1; p.sh1 = sh1; p.x2 = (const u16*)x2; p.sc2 = sc2; p.sh2 = sh2;
+  p.Lin = Lin; p.Cin = Cin; p.pad = pad; p.nMt = (Lout + 127) / 128; p.x_batch_stride = (long long)Lin * Cin;
+  hipStream_t st = (hipStream_t)stream;
+  const bool two = x2 != nullptr;
+  const int key = ksize * 100 + stride * 10 + pad;
+  // the layer shapes of the PerceptionAgent (agents/perception.py:160-171 with encoder_channels 256); anything else: SFM_ERR_SHAPE
+#define CONVP_GO(TT)                                                                                       \
+  if (key == 723 && N == 128 && skip) return two ? launch_convp<TT, 7, 2, 1, true, true>(p, st) : launch_convp<TT, 7, 2, 1, true, false>(p, st); \
+  if (key == 723 && N == 256 && !skip && two) return launch_convp<TT, 7, 2, 2, false, true>(p, st);        \
+  if (key == 311 && N == 128 && !two) return launch_convp<TT, 3, 1, 1, false, false>(p, st);                \
+  if (key == 311 && N == 256 && !two) return launch_convp<TT, 3, 1, 2, false, false>(p, st);                \
+  if (key == 522 && N == 256 && two) return launch_convp<TT, 5, 2, 2, false, true>(p, st);                  \
+  if (key == 120 && N == 256 && two) return launch_convp<TT, 1, 2, 2, false, true>(p, st);
+  if (dtype == SFM_DT_BF16) { CONVP_GO(BF16) }
+  if (dtype == SFM_DT_F16) { CONVP_GO(F16) }
+#undef CONVP_GO
+  return SFM_ERR_SHAPE;
+}
+

@@ -12,56 +12,7 @@
 //   * XCD-aware block order: the N-tiles of one M-tile (same A rows) run on one XCD (L2 reuse).
 #include "sfm_common.h"
 
-#define EPI_NONE 0
-#define EPI_SWISH 1
-#define EPI_GELU 2
-#define EPI_RESID 3
-#define EPI_GLU 4
-#define EPI_SIGMOID 5
-#define EPI_TANH_SCALE 6
-#define EPI_SIGMA 7
-#define EPI_CPEA 8
-#define EPI_SWISH_DUAL 9     // training forward of an FFN's first Linear: out = keep * swish(z), out2 = d = keep * swish'(z) (16-bit)
-#define EPI_SWISH_BWD 10     // training backward: out = v * aux, aux = the saved derivative factor d
-
-struct Gemm2Params {
-  const u16* A;
-  const u16* W;
-  const float* bias;
-  void* out;
-  const float* resid;
-  float* gn_partial;
-  long long a_batch_stride, o_batch_stride, r_batch_stride;
-  int B, Lout, Lin, Cin, lda, stride, pad, cin_shift;
-  int K, Kpad, N, Npad, ldo, ldr;
-  float alpha;
-  int epi, out_f32, gn_group, nsplit;
-  int nMt, nNt, a_records, w_records, vec_ok, gn_slots;
-  float p_drop;                                   // EPI_RESID: out = resid + alpha * keep(m*N + n) * v; EPI_SWISH_*: hidden dropout
-  unsigned int seed;
-  const u16* aux;                                 // EPI_SWISH_BWD: saved derivative factor keep * swish'(z), layout of `out`
-  u16* out2;                                      // EPI_SWISH_DUAL: second output (that derivative factor), layout of `out`
-};
-
-// 16-bit results are written in the operands' format T (out_f32 == 0) or in the OTHER 16-bit format (out_f32 == 2: a stage
-// boundary of the precision policy, e.g. fp16 projections feeding a bf16 attention core); out_f32 == 1 is fp32.
-template <class T>
-__device__ __forceinline__ uint32_t pack2_out(float lo, float hi, bool other) {
-  if (T::id == SFM_DT_BF16) return other ? F16::pack(lo, hi) : BF16::pack(lo, hi);
-  return other ? BF16::pack(lo, hi) : F16::pack(lo, hi);
-}
-template <class T>
-__device__ __forceinline__ u16 from_f32_out(float v, bool other) {
-  if (T::id == SFM_DT_BF16) return other ? F16::from_f32(v) : BF16::from_f32(v);
-  return other ? BF16::from_f32(v) : F16::from_f32(v);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#include "gemm16_epi.h"
 
 // BM = 128: wave tile 64 x WN, 2 workgroups/CU.  BM = 256: wave tile 128 x WN - every B fragment read from LDS feeds
 // 4 MFMAs instead of 2 (0.75 instead of 1 ds_read_b128 per MFMA: the 128-row kernel needs the full 128 B/clk of the LDS
@@ -357,197 +308,6 @@ float kp[8];
 // free), and there is one workgroup launch per CU slot instead of one per tile.
 // Tile order: XCD x owns the contiguous range [x Q, (x+1) Q) of the (batch, M-tile, N-tile) list and its resident
 // workgroups take neighbouring tiles, so the N-tiles of one M-tile share that XCD's L2.
-// Epilogue of one wave tile (64 rows x WN columns, accumulators acc[2][NJ]) in 8 passes of 8 rows through the wave's private
-// LDS strip `img` (8 x (WN + 4) floats): bias / activation / GLU / residual / dropout / GroupNorm partials, 16-byte row stores.
-// colb = first packed column of the wave tile, row_base = its first output row (within batch entry b).
-template <class T, int NJ>
-__device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32x16 (&acc)[2][NJ], float* img, int lane, int b,
-                                                       int colb, int row_base) {
-  constexpr int WN = NJ * 32, IMG_LD = WN + 4;
-  const int l31 = lane & 31, hl = lane >> 5;
-  // ------------------------------ epilogue: 8 passes of 8 rows through the wave's LDS strip ------------------------------
-    const bool glu = (p.epi == EPI_GLU);
-  const int ecols = glu ? 32 : WN;
-  const int cpr = ecols >> 3;
-  const int c8 = (lane % cpr) * 8, rsub = lane / cpr;
-  const bool lane_on = rsub < 8;
-  
-  const int ncol0 = glu ? ((colb >> 1) + c8) : (colb + c8);
-  float bia[8], big[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;
-    big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
-  }
-  const long long obase = (long long)b * p.o_batch_stride;
-  float gsum = 0.f, gsq = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_wave_barrier();
-      const int row = i * 32 + q * 8 + rsub;           // row inside the wave tile
-      const int m = row_base + row;
-      const bool mok = lane_on && m < p.Lout;
-      float v[8];
-      {
-        const int rs = lane_on ? rsub : 0;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8]);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + c8 + 4]);
-        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
-        v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bia[e];
-        if (glu) {
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8]);
-          const f32x4 g1 = *reinterpret_cast<const f32x4*>(&img[rs * IMG_LD + 32 + c8 + 4]);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= sigmoid_f(g[e] + big[e]);
-        }
-      }
-      if (p.gn_partial && mok) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
-      }
-      switch (p.epi) {
-        case EPI_SWISH:
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = swish_f(v[e]);
-          break;
-        case EPI_GELU:
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-          break;
-        case EPI_SIGMOID:
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
-          break;
-        case EPI_TANH_SCALE:
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = p.alpha * tanhf(v[e]);
-          break;
-        case EPI_SIGMA:
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = expf(0.5f * fminf(fmaxf(v[e], -10.f), 10.f));
-          break;
-        case EPI_CPEA:
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (ncol0 + e < p.nsplit) ? sigmoid_f(v[e]) : p.alpha * tanhf(v[e]);
-          break;
-        default: break;
-      }
-      if (mok && (p.epi == EPI_SWISH_DUAL || p.epi == EPI_SWISH_BWD)) {
-        // fused Swish of the FFN (training): vector path only (the launcher guarantees N % 8 == 0, aligned rows, 16-bit out)
-        const long long orow = obase + (long long)m * p.ldo + ncol0;
-        if (ncol0 + 8 <= p.N) {
-          if (p.epi == EPI_SWISH_DUAL) {
-            // forward: u = keep * swish(z) and, for the backward, the derivative factor d = keep * swish'(z) (NOT z itself:
-            // the backward's epilogue is then a single multiply instead of exp + rcp + the dropout hash per element)
-            const float ik = (p.p_drop > 0.f) ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-            const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
-            float kp[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-            if (p.p_drop > 0.f) sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
-            float dd[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float sg = sigmoid_f(v[e]);
-              dd[e] = kp[e] * sg * (1.0f + v[e] * (1.0f - sg));
-              v[e] = v[e] * sg * kp[e];
-            }
-            u32x4 pd;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pd[e] = pack2<T>(dd[2 * e], dd[2 * e + 1]);
-            *reinterpret_cast<u32x4*>(p.out2 + orow) = pd;
-          } else {
-            const u32x4 pd = *reinterpret_cast<const u32x4*>(p.aux + orow);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * e] *= T::to_f32((u16)(pd[e] & 0xffffu));
-              v[2 * e + 1] *= T::to_f32((u16)(pd[e] >> 16));
-            }
-          }
-          u32x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-          *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
-        }
-      } else if (mok) {
-        const long long orow = obase + (long long)m * p.ldo + ncol0;
-        if (p.vec_ok && ncol0 + 8 <= p.N) {
-          if (p.epi == EPI_RESID) {
-            if (p.p_drop > 0.f) {
-              const float ik = 1.0f / (1.0f - p.p_drop);
-              const unsigned long long e0 = ((unsigned long long)b * p.Lout + m) * p.N + ncol0;
-float kp[8];
-              sfm_keep_scale8(p.seed, e0, p.p_drop, ik, kp);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= kp[e];
-            }
-            const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0;
-            const f32x4 r0v = *reinterpret_cast<const f32x4*>(rp);
-            const f32x4 r1v = *reinterpret_cast<const f32x4*>(rp + 4);
-            v[0] = r0v[0] + p.alpha * v[0]; v[1] = r0v[1] + p.alpha * v[1];
-            v[2] = r0v[2] + p.alpha * v[2]; v[3] = r0v[3] + p.alpha * v[3];
-            v[4] = r1v[0] + p.alpha * v[4]; v[5] = r1v[1] + p.alpha * v[5];
-            v[6] = r1v[2] + p.alpha * v[6]; v[7] = r1v[3] + p.alpha * v[7];
-          }
-          if (p.out_f32 == 1) {
-            float* op = reinterpret_cast<float*>(p.out) + orow;
-            f32x4 a = {v[0], v[1], v[2], v[3]}, c = {v[4], v[5], v[6], v[7]};
-            *reinterpret_cast<f32x4*>(op) = a;
-            *reinterpret_cast<f32x4*>(op + 4) = c;
-          } else {
-            u32x4 pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(v[2 * e], v[2 * e + 1], p.out_f32 == 2);
-            *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (ncol0 + e < p.N) {
-              float y = v[e];
-              if (p.epi == EPI_RESID) {
-                if (p.p_drop > 0.f)
-                  y *= sfm_keep_scale(p.seed, ((unsigned long long)b * p.Lout + m) * p.N + ncol0 + e, p.p_drop, 1.0f / (1.0f - p.p_drop));
-                y = p.resid[(long long)b * p.r_batch_stride + (long long)m * p.ldr + ncol0 + e] + p.alpha * y;
-              }
-              if (p.out_f32 == 1) reinterpret_cast<float*>(p.out)[orow + e] = y;
-              else reinterpret_cast<u16*>(p.out)[orow + e] = from_f32_out<T>(y, p.out_f32 == 2);
-            }
-          }
-        }
-      }
-    }
-  if (p.gn_partial) {
-    for (int o = cpr; o < 64; o <<= 1) {               // lanes with the same column chunk hold different rows
-      gsum += __shfl_xor(gsum, o, 64);
-      gsq += __shfl_xor(gsq, o, 64);
-    }
-    const int cpg = p.gn_group >> 3;
-    for (int o = 1; o < cpg; o <<= 1) {
-      gsum += __shfl_xor(gsum, o, 64);
-      gsq += __shfl_xor(gsq, o, 64);
-    }
-    if (lane < cpr && (lane % cpg) == 0 && ncol0 < p.N && (row_base >> 6) < p.gn_slots) {
-      const int ngroups = p.N / p.gn_group;
-      const long long sl = ((long long)b * p.gn_slots + (row_base >> 6)) * ngroups + ncol0 / p.gn_group;
-      p.gn_partial[sl * 2 + 0] = gsum;
-      p.gn_partial[sl * 2 + 1] = gsq;
-    }
-  }
-
-}
-
 template <class T, int BN>
 __global__ __launch_bounds__(256) void gemm16p_kernel(Gemm2Params p, int total_tiles) {
   constexpr int BM = 128, BKB = 128;
@@ -838,15 +598,11 @@ static int launch_v2(const Gemm2Params& p, hipStream_t stream) {
   return SFM_OK;
 }
 
-extern "C" int sfm_gemm16_v1(const void* A, const void* W, const float* bias, void* out, const float* resid,
-                             float* gn_partial, int B, int Lout, int Lin, int Cin, int lda, int ksize, int stride, int pad,
-                             long long a_batch_stride, int Kpad, int N, int Npad, int ldo, long long o_batch_stride,
-                             int ldr, long long r_batch_stride, float alpha, int epi, int out_f32, int gn_group,
-                             int nsplit, int dtype, void* stream);
-
-// same contract as sfm_gemm16_v1 (include/sincformer_hip.h); `variant`: 0 = auto, 1 = v1 register-staged kernel,
-// 2 = LDS-DMA ring with 2 stages (2 workgroups/CU), 3 = 3 stages (1 workgroup/CU), 4 / 5 = 256-row tiles with 2 / 3 stages,
-// 6 = persistent 2-stage kernel (tile loop inside the workgroup, next tile prefetched under the epilogue)
+// contract: include/sincformer_hip.h (sfm_gemm16); `variant`: 0 = auto, 2 = 128 x 128(64) tiles, LDS-DMA ring with 2 stages
+// (2 workgroups/CU), 6 = persistent form of it (tile loop inside the workgroup, next tile prefetched under the epilogue),
+// 9 = 256 x 256 / 256 x 128 tiles on 16 / 8 waves, 10 = 512 x 128 tiles on 16 waves.  (The register-staged v1 kernel, the
+// 3-stage ring and the 256-row wave tiles of round 1 were measured slower on every shape of the path and are gone:
+// profiles/README.md.)  Operands of 2 GiB or more (buffer descriptors are 32-bit) are cut into row chunks here.
 // sfm_gemm16_train = sfm_gemm16_ex + residual-branch dropout in the EPI_RESID epilogue (training forward):
 // out = resid + alpha * keep(seed, m*N + n) / (1 - p_drop) * (A W^T + bias)
 static int gemm16_impl(const void* A, const void* W, const float* bias, void* out, const float* resid,
@@ -863,19 +619,28 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
     if (out_f32 != 0 || (N % 8) != 0 || (ldo % 8) != 0 || (o_batch_stride % 8) != 0 || gn_partial) return SFM_ERR_SHAPE;
     if ((((uintptr_t)out) % 16) != 0 || (out2 && (((uintptr_t)out2) % 16) != 0) || (aux && (((uintptr_t)aux) % 16) != 0))
       return SFM_ERR_SHAPE;
-    if (variant == 1 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 8) variant = 0;
+    if (variant != 6 && variant != 9 && variant != 10) variant = 0;
   }
   if (B <= 0 || Lout <= 0 || N <= 0 || out_f32 < 0 || out_f32 > 2) return SFM_ERR_SHAPE;
   const long long a_rec = ((long long)(Lin - 1) * lda + Cin) * 2;
   const long long w_rec = (long long)Npad * Kpad * 2;
-  const bool v2_ok = (Kpad % 64 == 0) && (Npad % 64 == 0) && a_rec < (1LL << 31) && w_rec < (1LL << 31) &&
-                     (!gn_partial || gn_group == 8 || gn_group == 16 || gn_group == 32) &&
-                     ((long long)Lout * stride * lda * 2 < (1LL << 31)) && (epi != EPI_GLU || Npad % 128 == 0);
-  if ((variant == 1 || !v2_ok) && (p_drop > 0.f || swish || out_f32 == 2)) return SFM_ERR_SHAPE;
-  if (variant == 1 || !v2_ok)
-    return sfm_gemm16_v1(A, W, bias, out, resid, gn_partial, B, Lout, Lin, Cin, lda, ksize, stride, pad, a_batch_stride,
-                         Kpad, N, Npad, ldo, o_batch_stride, ldr, r_batch_stride, alpha, epi, out_f32, gn_group, nsplit,
-                         dtype, stream);
+  if ((Kpad % 64) != 0 || (Npad % 64) != 0 || w_rec >= (1LL << 31) || (epi == EPI_GLU && Npad % 128 != 0) ||
+      (gn_partial && gn_group != 8 && gn_group != 16 && gn_group != 32))
+    return SFM_ERR_SHAPE;
+  if (a_rec >= (1LL << 31) || (long long)Lout * stride * lda * 2 >= (1LL << 31)) {
+    // the A operand does not fit one 32-bit buffer descriptor: plain GEMMs (one batch entry, 1 tap) are cut into row chunks
+    if (B != 1 || ksize != 1 || stride != 1 || pad != 0 || gn_partial || swish) return SFM_ERR_SHAPE;
+    const long long rows_max = ((1LL << 30) / ((long long)lda * 2)) & ~255LL;
+    const int osz_ = out_f32 == 1 ? 4 : 2;
+    for (long long r0 = 0; r0 < Lout; r0 += rows_max) {
+      const int rows = (int)((Lout - r0 < rows_max) ? (Lout - r0) : rows_max);
+      const int rc = gemm16_impl((const u16*)A + r0 * lda, W, bias, (char*)out + r0 * ldo * osz_, resid ? resid + r0 * ldr : nullptr,
+                                 nullptr, 1, rows, rows, Cin, lda, 1, 1, 0, 0, Kpad, N, Npad, ldo, 0, ldr, 0, alpha, epi, out_f32,
+                                 gn_group, nsplit, dtype, variant, p_drop, seed + (unsigned)(r0 * 0x9E3779B1ull), nullptr, nullptr, stream);
+      if (rc != SFM_OK) return rc;
+    }
+    return SFM_OK;
+  }
   if (Cin % 8 != 0 || lda % 8 != 0 || lda < Cin) return SFM_ERR_SHAPE;
   const int K = ksize * Cin;
   if (K > Kpad) return SFM_ERR_SHAPE;
@@ -900,10 +665,8 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   const bool o_al = (((uintptr_t)out) % 16 == 0) && ((ldo * osz) % 16 == 0) && ((o_batch_stride * osz) % 16 == 0);
   const bool r_al = (epi != EPI_RESID) || ((((uintptr_t)resid) % 16 == 0) && ((ldr * 4) % 16 == 0) && ((r_batch_stride * 4) % 16 == 0));
   p.vec_ok = (o_al && r_al) ? 1 : 0;
-  const bool bn128 = (Npad % 128 == 0) && variant != 7 && variant != 8;   // 7 / 8: 64-column tiles with a 3- / 2-stage ring
+  const bool bn128 = (Npad % 128 == 0);
   const int BNv = bn128 ? 128 : 64;
-  // variants 4 / 5: 256-row tiles (wave tile 128 x 64), 2 / 3 stages, 128-column tiles only
-  const bool big = (variant == 4 || variant == 5) && bn128;
   // 256-row tiles, 8 or 16 waves (variant 9); auto picks the 256 x 256 form when the columns allow it and there are at
   // least two tiles per CU: +15..37 % on those shapes, the 256 x 128 form (one 8-wave workgroup per CU) is slower than
   // the default (tools/gemm_bench.py)
@@ -918,12 +681,11 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   const bool tall = ((variant == 10) && bn128) || auto_tall;
   const bool wide = ((variant == 9) && bn128) || auto_wide;
   const bool wide256 = wide && (Npad % 256 == 0);
-  const int BMv = tall ? 512 : ((big || wide) ? 256 : 128);
+  const int BMv = tall ? 512 : (wide ? 256 : 128);
   p.nMt = (Lout + BMv - 1) / BMv;
   p.nNt = wide256 ? Npad / 256 : Npad / BNv;
   p.gn_slots = 2 * ((Lout + 127) / 128);               // partial slots per batch entry: one per 64 output rows (padded to 128)
   hipStream_t st = (hipStream_t)stream;
-  const bool s3 = (variant == 3 || variant == 5 || variant == 7);
   // the persistent kernel is 5-20 % faster than variant 2 on isolated launches of the path's skinny GEMMs
   // (tools/gemm_bench.py) but 2 % slower inside the forward pass (bench.py, same box, A/B/A/B): not the default
   const bool persistent = (variant == 6) || (swish && !wide && !tall);   // the fused-Swish modes live in the strip epilogue
@@ -931,9 +693,8 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   if (tall) return launch_w<TT, 512, 128, 16>(p, st);                                                   \
   if (wide) return wide256 ? launch_w<TT, 256, 256, 16>(p, st) : launch_w<TT, 256, 128, 8>(p, st);      \
   if (persistent) return bn128 ? launch_p<TT, 128>(p, st) : launch_p<TT, 64>(p, st);                    \
-  if (big) return s3 ? launch_v2<TT, 128, 3, 256>(p, st) : launch_v2<TT, 128, 2, 256>(p, st);           \
-  if (bn128) return s3 ? launch_v2<TT, 128, 3, 128>(p, st) : launch_v2<TT, 128, 2, 128>(p, st);          \
-  else return s3 ? launch_v2<TT, 64, 3, 128>(p, st) : launch_v2<TT, 64, 2, 128>(p, st);
+  if (bn128) return launch_v2<TT, 128, 2, 128>(p, st);                                                   \
+  else return launch_v2<TT, 64, 2, 128>(p, st);
   if (dtype == SFM_DT_BF16) { GO(BF16) }
   if (dtype == SFM_DT_F16) { GO(F16) }
 #undef GO

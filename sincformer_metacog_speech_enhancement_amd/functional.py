@@ -362,6 +362,44 @@ def perception_forward(wave, pk, keep_sinc=False, latents=True):
         return _perception_forward(wave, pk, keep_sinc, latents)
 
 
+PATCH_CONV = True     # False: one gn_apply pass + implicit-GEMM convs (sfm_gemm16) per layer, as in round 1
+
+
+def _convp(inp, pw, B, Lin, stride, pad, groups, dt, skip_pw=None):
+    """conv16p on inp = (raw1, sc1, sh1[, raw2, sc2, sh2]) -> raw output + GroupNorm partials (and the same for the skip conv)"""
+    dev = inp[0].device
+    k, N = pw.ksize, pw.N
+    Lout = (Lin + 2 * pad - k) // stride + 1
+    P = 2 * ((Lout + 127) // 128)
+    raw = torch.empty(B, Lout, N, device=dev, dtype=dt)
+    part = torch.empty(B, P, groups, 2, device=dev, dtype=torch.float32)
+    raw_s = part_s = None
+    if skip_pw is not None:
+        raw_s = torch.empty(B, Lout, N, device=dev, dtype=dt)
+        part_s = torch.empty(B, P, groups, 2, device=dev, dtype=torch.float32)
+    x2, sc2, sh2 = (inp[3], inp[4], inp[5]) if len(inp) == 6 else (None, None, None)
+    ops.conv16p(inp[0], inp[1], inp[2], pw, raw, B=B, Lin=Lin, stride=stride, pad=pad, x2=x2, sc2=sc2, sh2=sh2,
+                gn_partial=part, gn_group=N // groups, skip_pw=skip_pw, out_s=raw_s, gn_partial_s=part_s)
+    return raw, part, P, Lout, raw_s, part_s
+
+
+def _patch_conv_ok(pk):
+    if not PATCH_CONV or pk["C0"] != 64:
+        return False
+    cin = 64
+    for i, bp in enumerate(pk["blocks"]):
+        C = bp["cout"]
+        fused_skip = C == 128
+        if not ops.conv16p_supported(cin, C, 7, 2, 3, i > 0, fused_skip):
+            return False
+        if not fused_skip and not ops.conv16p_supported(cin, C, 1, 2, 0, i > 0, False):
+            return False
+        if not ops.conv16p_supported(C, C, 3, 1, 1, False, False):
+            return False
+        cin = C
+    return ops.conv16p_supported(cin, pk["D"], 5, 2, 2, True, False)
+
+
 def _perception_forward(wave, pk, keep_sinc, latents):
     dt = ops.compute_dtype()
     wave = wave.contiguous()
@@ -380,25 +418,44 @@ def _perception_forward(wave, pk, keep_sinc, latents):
         ops.framed_gemm(wave, Wt, raw, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=K // 2, K=K, N=C0,
                         o_batch_stride=L * C0, ldm=C0, ldn=1, mode=0, gn_partial=part, gn_group=C0 // 8)
     sc, sh = ops.gn_finalize(part, pk["sn_w"], pk["sn_b"], B, P0, 8, C0, L)
-    x = torch.empty(B, L, C0, device=dev, dtype=dt)
-    ops.gn_apply(raw, sc, sh, x, B, L, C0, act=1)
-    del raw
     Lc = L
-    for bp in pk["blocks"]:
-        G, C = bp["groups"], bp["cout"]
-        r1, p1, P1, L1 = _conv_gn(x, bp["c1"], B, Lc, 2, 3, G, dt)
-        s1, h1 = ops.gn_finalize(p1, bp["g1w"], bp["g1b"], B, P1, G, C, L1)
-        a1 = torch.empty(B, L1, C, device=dev, dtype=dt)
-        ops.gn_apply(r1, s1, h1, a1, B, L1, C, act=1)
-        r2, p2, P2, _ = _conv_gn(a1, bp["c2"], B, L1, 1, 1, G, dt)
-        rs, ps, Ps, _ = _conv_gn(x, bp["cs"], B, Lc, 2, 0, G, dt)
-        s2, h2 = ops.gn_finalize(p2, bp["g2w"], bp["g2b"], B, P2, G, C, L1)
-        ss, hs = ops.gn_finalize(ps, bp["gsw"], bp["gsb"], B, Ps, G, C, L1)
-        x = torch.empty(B, L1, C, device=dev, dtype=dt)
-        ops.gn_apply(r2, s2, h2, x, B, L1, C, act=1, x2=rs, sc2=ss, sh2=hs)
-        Lc = L1
     D = pk["D"]
-    rd, pd, Pd, Tpa = _conv_gn(x, pk["down"], B, Lc, 2, 2, 16, dt)
+    if _patch_conv_ok(pk):
+        # Every conv reads the RAW output of its producer(s) and applies their GroupNorm (+ the residual add) + GELU while it
+        # stages its operand (sfm_conv16p): the activations between the layers are never materialised.
+        inp = (raw, sc, sh)
+        for bp in pk["blocks"]:
+            G, C = bp["groups"], bp["cout"]
+            if C == 128:                                  # main k7 s2 conv and the 1x1 s2 skip conv from one staged input
+                r1, p1, P1, L1, rs, ps = _convp(inp, bp["c1"], B, Lc, 2, 3, G, dt, skip_pw=bp["cs"])
+            else:
+                r1, p1, P1, L1, _, _ = _convp(inp, bp["c1"], B, Lc, 2, 3, G, dt)
+                rs, ps, _, _, _, _ = _convp(inp, bp["cs"], B, Lc, 2, 0, G, dt)
+            s1, h1 = ops.gn_finalize(p1, bp["g1w"], bp["g1b"], B, P1, G, C, L1)
+            ss, hs = ops.gn_finalize(ps, bp["gsw"], bp["gsb"], B, P1, G, C, L1)
+            r2, p2, P2, _, _, _ = _convp((r1, s1, h1), bp["c2"], B, L1, 1, 1, G, dt)
+            s2, h2 = ops.gn_finalize(p2, bp["g2w"], bp["g2b"], B, P2, G, C, L1)
+            inp = (r2, s2, h2, rs, ss, hs)
+            Lc = L1
+        rd, pd, Pd, Tpa, _, _ = _convp(inp, pk["down"], B, Lc, 2, 2, 16, dt)
+    else:
+        x = torch.empty(B, L, C0, device=dev, dtype=dt)
+        ops.gn_apply(raw, sc, sh, x, B, L, C0, act=1)
+        del raw
+        for bp in pk["blocks"]:
+            G, C = bp["groups"], bp["cout"]
+            r1, p1, P1, L1 = _conv_gn(x, bp["c1"], B, Lc, 2, 3, G, dt)
+            s1, h1 = ops.gn_finalize(p1, bp["g1w"], bp["g1b"], B, P1, G, C, L1)
+            a1 = torch.empty(B, L1, C, device=dev, dtype=dt)
+            ops.gn_apply(r1, s1, h1, a1, B, L1, C, act=1)
+            r2, p2, P2, _ = _conv_gn(a1, bp["c2"], B, L1, 1, 1, G, dt)
+            rs, ps, Ps, _ = _conv_gn(x, bp["cs"], B, Lc, 2, 0, G, dt)
+            s2, h2 = ops.gn_finalize(p2, bp["g2w"], bp["g2b"], B, P2, G, C, L1)
+            ss, hs = ops.gn_finalize(ps, bp["gsw"], bp["gsb"], B, Ps, G, C, L1)
+            x = torch.empty(B, L1, C, device=dev, dtype=dt)
+            ops.gn_apply(r2, s2, h2, x, B, L1, C, act=1, x2=rs, sc2=ss, sh2=hs)
+            Lc = L1
+        rd, pd, Pd, Tpa = _conv_gn(x, pk["down"], B, Lc, 2, 2, 16, dt)
     sd_, hd_ = ops.gn_finalize(pd, pk["dn_w"], pk["dn_b"], B, Pd, 16, D, Tpa)
     xd = torch.empty(B, Tpa, D, device=dev, dtype=dt)
     ops.gn_apply(rd, sd_, hd_, xd, B, Tpa, D, act=1)

@@ -29,8 +29,8 @@ SIGNATURES = {
                    c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_gemm16_train": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i,
                    c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_vp],
-    "sfm_gemm16_v1": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i,
-                   c_i, c_ll, c_i, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_conv16p": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,
+                    c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_framed_gemm_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i,
                             c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_vp],
     "sfm_attention_fwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_vp],

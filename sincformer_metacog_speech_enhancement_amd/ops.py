@@ -16,7 +16,7 @@ _state = {"dtype": torch.bfloat16, "gemm_variant": int(_os.environ.get("SFM_GEMM
 
 
 def set_gemm_variant(v):
-    """0 auto, 1 register-staged kernel, 2/3 LDS-DMA ring with 2/3 stages (A/B testing)."""
+    """0 auto, 2 = 128-row tiles, 6 = persistent, 9 = 256-row wide tiles, 10 = 512 x 128 tiles (A/B testing)."""
     _state["gemm_variant"] = int(v)
 
 
@@ -349,6 +349,43 @@ def gemm16(A, pw, out, *, B, Lout, Lin, a_batch_stride, ldo, o_batch_stride, lda
                       pw.ksize, stride, pad, a_batch_stride, pw.Kpad, pw.N, pw.Npad, ldo, o_batch_stride, ldr, r_batch_stride,
                       float(alpha), epi, out_f32, gn_group, nsplit, _dt(), _state["gemm_variant"], _stream()),
           *_cost_of("gemm16", locals()))
+    return out
+
+
+def conv16p_supported(cin, n, ksize, stride, pad, two_inputs, skip):
+    """layer shapes sfm_conv16p is built for (the PerceptionAgent's: include/sincformer_hip.h)"""
+    if cin % 64:
+        return False
+    key = (ksize, stride, pad, n)
+    if skip:
+        return key == (7, 2, 3, 128)
+    return (key == (7, 2, 3, 256) and two_inputs) or (key in ((3, 1, 1, 128), (3, 1, 1, 256)) and not two_inputs) or \
+        (key in ((5, 2, 2, 256), (1, 2, 0, 256)) and two_inputs)
+
+
+def conv16p(x1, sc1, sh1, pw, out, *, B, Lin, stride, pad, x2=None, sc2=None, sh2=None, gn_partial=None, gn_group=0,
+            skip_pw=None, out_s=None, gn_partial_s=None):
+    """out = Conv1d(GELU(sc1 * x1 + sh1 [+ sc2 * x2 + sh2]); pw) on channels-last raw conv outputs x1 / x2 [B, Lin, Cin] with
+    per-(batch, channel) GroupNorm scale / shift [B, Cin]: the normalised activation is produced while the operand is staged
+    and never written to HBM.  skip_pw / out_s / gn_partial_s: the residual block's 1x1 stride-2 skip conv on the same input."""
+    _need_dev(x1, out)
+    L = _lib.load()
+    cin, N, ks = pw.cin, pw.N, pw.ksize
+    dt = _state["dtype"]
+    if x1.dtype != dt or pw.w.dtype != dt or (x2 is not None and x2.dtype != dt):
+        raise RuntimeError("conv16p: operand formats do not match the stage's %s (precision policy)" % dt)
+    if pw.Npad != N or pw.Kpad != ks * cin or (skip_pw is not None and (skip_pw.Npad != N or skip_pw.Kpad != cin)):
+        raise RuntimeError("conv16p: weights must be packed without padding")
+    out_f32 = 1 if out.dtype == torch.float32 else (0 if out.dtype == dt else 2)
+    Lout = (Lin + 2 * pad - ks) // stride + 1
+    nin = 2 if x2 is not None else 1
+    flops = 2.0 * B * Lout * N * (ks * cin + (cin if skip_pw is not None else 0))
+    nbytes = B * Lin * cin * 2.0 * nin + B * Lout * N * out.element_size() * (2 if skip_pw is not None else 1) + N * ks * cin * 2.0
+    _call("conv16p", L.sfm_conv16p, (_p(x1), _p(sc1), _p(sh1), _p(x2), _p(sc2), _p(sh2), _p(pw.w), _p(pw.bias), _p(out),
+                                     _p(gn_partial), _p(skip_pw.w if skip_pw is not None else None),
+                                     _p(skip_pw.bias if skip_pw is not None else None), _p(out_s), _p(gn_partial_s), B, Lin, cin, N,
+                                     ks, stride, pad, out_f32, gn_group, _dt(), _stream()),
+          flops, nbytes, tag="Lout%d Cin%d N%d k%d s%d in%d%s" % (B * Lout, cin, N, ks, stride, nin, " +skip" if skip_pw is not None else ""))
     return out
 
 

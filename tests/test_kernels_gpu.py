@@ -53,7 +53,7 @@ def test_mfma_layout_identity(ops):
     report("mfma identity", out.cpu(), ref, 1e-6)
 
 
-VARIANTS = [1, 2, 3]          # gemm16 kernels: register-staged, LDS-DMA ring x2, x3
+VARIANTS = [0, 2, 6, 9]       # gemm16 kernels: auto, 128-row tiles, persistent, wide tiles
 
 
 @pytest.fixture(autouse=True)
@@ -156,7 +156,7 @@ def test_gemm16_conv_and_groupnorm(ops, dt, cin, cout, k, s, p, L, variant):
     xcl = dev(x).transpose(1, 2).contiguous().to(dt)                            # [B, L, cin]
     pw = ops.pack_linear(dev(w), dev(b))
     out = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32)
-    G = 16 if cout >= 16 else cout
+    G = 16 if cout >= 128 else cout // 8           # group width 8 / 16 / 32 columns (what the GEMM epilogue reduces)
     gs = cout // G
     P = 2 * ((Lout + 127) // 128)
     part = torch.zeros(B, P, G, 2, device="cuda", dtype=torch.float32)
@@ -175,6 +175,72 @@ def test_gemm16_conv_and_groupnorm(ops, dt, cin, cout, k, s, p, L, variant):
     ops.gn_apply(o16, sc, sh, y16, B, Lout, cout, act=1, x2=o16, sc2=sc, sh2=sh)
     ref2 = orc.gelu(2.0 * orc.group_norm(ref, G, gw, gb))
     report("groupnorm two-branch 16-bit", y16.float().cpu().transpose(1, 2), ref2, 16 * EPS[dt])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,s,p,two,skip,L,B", [
+    (64, 128, 7, 2, 3, False, True, 301, 2),      # block 0: sinc output -> k7 s2 conv + fused 1x1 s2 skip conv
+    (128, 128, 7, 2, 3, True, True, 777, 3),      # block 1: residual input (two raw tensors), two 64-channel slabs, 4 tiles
+    (128, 256, 7, 2, 3, True, False, 300, 2),     # block 2 main conv: 256 outputs = two 128-column passes
+    (128, 256, 1, 2, 0, True, False, 300, 2),     # block 2 skip conv on its own (only the even input rows are read)
+    (128, 128, 3, 1, 1, False, False, 150, 2),    # second conv of a block
+    (256, 256, 3, 1, 1, False, False, 129, 1),    # ... with 4 slabs and a 1-row second tile
+    (256, 256, 5, 2, 2, True, False, 77, 2),      # downsample
+])
+def test_conv16p_normalises_its_input_while_staging(ops, dt, cin, cout, k, s, p, two, skip, L, B):
+    """sfm_conv16p against F.conv1d(GELU(sc1 x1 + sh1 [+ sc2 x2 + sh2])) with the 16-bit roundings of the kernel (raw inputs,
+    normalised operand, weights): outputs, GroupNorm partials of the outputs, the fused skip conv, ragged tile tails"""
+    ops.set_compute_dtype(dt)
+    x1 = arr("px1", (B, L, cin), 20)
+    x2 = arr("px2", (B, L, cin), 21) if two else None
+    sc1, sh1 = arr("ps1", (B, cin), 22) * 0.2 + 1.0, arr("ph1", (B, cin), 23) * 0.3
+    sc2, sh2 = (arr("ps2", (B, cin), 24) * 0.2 + 0.7, arr("ph2", (B, cin), 25) * 0.3) if two else (None, None)
+    w = arr("pw", (cout, cin, k), 26) / math.sqrt(cin * k)
+    b = arr("pb", (cout,), 27)
+    ws = arr("pws", (cout, cin, 1), 28) / math.sqrt(cin)
+    bs = arr("pbs", (cout,), 29)
+    z = q16(x1, dt) * sc1[:, None, :] + sh1[:, None, :]
+    if two:
+        z = z + q16(x2, dt) * sc2[:, None, :] + sh2[:, None, :]
+    xn = q16(orc.gelu(z), dt).transpose(1, 2)                                   # [B, cin, L], operand rounding
+    ref = F.conv1d(xn, q16(w, dt), b, stride=s, padding=p).transpose(1, 2)      # [B, Lout, cout]
+    Lout = ref.shape[1]
+    pw = ops.pack_linear(dev(w), dev(b))
+    spw = ops.pack_linear(dev(ws), dev(bs)) if skip else None
+    G = 16
+    P = 2 * ((Lout + 127) // 128)
+    out = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32)
+    part = torch.zeros(B, P, G, 2, device="cuda", dtype=torch.float32)
+    out_s = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32) if skip else None
+    part_s = torch.zeros(B, P, G, 2, device="cuda", dtype=torch.float32) if skip else None
+    d16 = lambda t: None if t is None else dev(t).to(dt).contiguous()
+    dd = lambda t: None if t is None else dev(t).contiguous()
+    ops.conv16p(d16(x1), dd(sc1), dd(sh1), pw, out, B=B, Lin=L, stride=s, pad=p, x2=d16(x2), sc2=dd(sc2), sh2=dd(sh2),
+                gn_partial=part, gn_group=cout // G, skip_pw=spw, out_s=out_s, gn_partial_s=part_s)
+    tol = 8 * EPS[dt]                      # one 16-bit rounding of the operand may differ (erf approximation 1.5e-7)
+    report("conv16p k%d s%d %d->%d in%d" % (k, s, cin, cout, 2 if two else 1), out.cpu(), ref, tol)
+    sums = part.cpu().double().sum(dim=1)                                       # [B, G, 2]
+    rg = ref.double().reshape(B, Lout, G, cout // G)
+    assert maxerr(sums[..., 0], rg.sum(dim=(1, 3))) < 2e-2 * Lout ** 0.5 and maxerr(sums[..., 1], (rg ** 2).sum(dim=(1, 3))) < 5e-2 * Lout ** 0.5
+    if skip:
+        refs = F.conv1d(xn, q16(ws, dt), bs, stride=2).transpose(1, 2)
+        report("conv16p fused skip conv", out_s.cpu(), refs, tol)
+        sums = part_s.cpu().double().sum(dim=1)
+        assert maxerr(sums[..., 0], refs.double().reshape(B, Lout, G, cout // G).sum(dim=(1, 3))) < 2e-2 * Lout ** 0.5
+    # 16-bit output in the stage's format
+    o16 = torch.empty(B, Lout, cout, device="cuda", dtype=dt)
+    ops.conv16p(d16(x1), dd(sc1), dd(sh1), pw, o16, B=B, Lin=L, stride=s, pad=p, x2=d16(x2), sc2=dd(sc2), sh2=dd(sh2),
+                skip_pw=spw, out_s=torch.empty_like(o16) if skip else None)
+    report("conv16p 16-bit out", o16.float().cpu(), ref, tol + 2 * EPS[dt] * float(ref.abs().max()))
+
+
+def test_conv16p_refuses_shapes_it_is_not_built_for(ops):
+    ops.set_compute_dtype(torch.float16)
+    x = torch.zeros(1, 64, 64, device="cuda", dtype=torch.float16)
+    sc = torch.ones(1, 64, device="cuda")
+    pw = ops.pack_linear(torch.zeros(128, 64, 3, device="cuda"))
+    with pytest.raises(RuntimeError):
+        ops.conv16p(x, sc, sc, pw, torch.empty(1, 32, 128, device="cuda"), B=1, Lin=64, stride=2, pad=1)
 
 
 # ---------------------------------------------------------------------------
