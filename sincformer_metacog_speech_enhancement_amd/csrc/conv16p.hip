@@ -72,8 +72,11 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
       float v[8] = {x0[0] + bia[0], x0[1] + bia[1], x0[2] + bia[2], x0[3] + bia[3],
                     x1[0] + bia[4], x1[1] + bia[5], x1[2] + bia[6], x1[3] + bia[7]};
       if (m < g.Lout) {
+        float ps = 0.f, pq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gsum += v[e]; gsq += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) { ps += v[e]; pq = __builtin_fmaf(v[e], v[e], pq); }
+        gsum += ps;
+        gsq += pq;
         const long long orow = obase + (long long)m * g.ldo + ncol0;
         if (g.out_f32 == 1) {
           float* op = reinterpret_cast<float*>(g.out) + orow;
@@ -88,6 +91,7 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
       }
     }
   if (g.gn_partial) {
+    asm volatile("" : "+v"(gsum), "+v"(gsq));
     for (int o = 8; o < 64; o <<= 1) {                 // lanes with the same column chunk hold different rows
       gsum += __shfl_xor(gsum, o, 64);
       gsq += __shfl_xor(gsq, o, 64);

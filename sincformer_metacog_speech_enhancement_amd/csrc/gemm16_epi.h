@@ -71,27 +71,40 @@ __device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32
   const bool lane_on = rsub < 8;
   
   const int ncol0 = glu ? ((colb >> 1) + c8) : (colb + c8);
-  float bia[8], big[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;
-    big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
-  }
   const long long obase = (long long)b * p.o_batch_stride;
   float gsum = 0.f, gsq = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+  // The 8 passes are a RUNTIME loop: only the strip write (which needs compile-time accumulator indices) is expanded 8 times,
+  // behind a wave-uniform switch; the heavy part - activations, residual, dropout, stores - exists once.  Fully unrolled,
+  // this epilogue was 28 k instructions per kernel and the instruction fetch of its sparse paths, not the arithmetic,
+  // bounded the short-K GEMMs of the path.
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    {
       __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
+#define SFM_STRIP_WRITE(I_, Q_)                                                                                      \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                     \
+  _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[I_][j][4 * Q_ + rr];
+      switch (pass) {
+        case 0: { SFM_STRIP_WRITE(0, 0) } break;
+        case 1: { SFM_STRIP_WRITE(0, 1) } break;
+        case 2: { SFM_STRIP_WRITE(0, 2) } break;
+        case 3: { SFM_STRIP_WRITE(0, 3) } break;
+        case 4: { SFM_STRIP_WRITE(1, 0) } break;
+        case 5: { SFM_STRIP_WRITE(1, 1) } break;
+        case 6: { SFM_STRIP_WRITE(1, 2) } break;
+        default: { SFM_STRIP_WRITE(1, 3) } break;
+      }
+#undef SFM_STRIP_WRITE
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
-      const int row = i * 32 + q * 8 + rsub;           // row inside the wave tile
+      float bia[8], big[8];                            // (re-read per pass from L1: keeps 16 registers out of the loop)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bia[e] = p.bias ? p.bias[colb + c8 + e] : 0.f;
+        big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
+      }
+      const int row = pass * 8 + rsub;                 // row inside the wave tile
       const int m = row_base + row;
       const bool mok = lane_on && m < p.Lout;
       float v[8];
@@ -226,6 +239,7 @@ float kp[8];
         }
       }
     }
+  }
   if (p.gn_partial) {
     for (int o = cpr; o < 64; o <<= 1) {               // lanes with the same column chunk hold different rows
       gsum += __shfl_xor(gsum, o, 64);

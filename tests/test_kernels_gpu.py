@@ -234,6 +234,44 @@ def test_conv16p_normalises_its_input_while_staging(ops, dt, cin, cout, k, s, p,
     report("conv16p 16-bit out", o16.float().cpu(), ref, tol + 2 * EPS[dt] * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,k,s,p,two,skip,L", [(64, 128, 7, 2, 3, False, True, 64000), (128, 128, 3, 1, 1, False, False, 32000),
+                                                       (256, 256, 5, 2, 2, True, False, 8000)])
+def test_conv16p_statistics_and_determinism_at_scale(ops, cin, cout, k, s, p, two, skip, L):
+    """thousands of tiles (B 8 at the bench's sequence lengths): the GroupNorm partial sums must equal the sums of the rows
+    the same launch wrote (fp32 output), in every slot, and two launches must agree bit for bit.  (A first version of the
+    epilogue, whose sum / sum-of-squares updates the compiler had packed into v_pk_* pairs, lost part of the sum of squares in
+    ~40 of 128 000 slots per launch, different ones each time: invisible at unit-test sizes.)"""
+    ops.set_compute_dtype(torch.float16)
+    dt, B, G = torch.float16, 8, 16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    R = lambda *shape: torch.randn(*shape, device="cuda", generator=g)
+    x1, x2 = R(B, L, cin).to(dt), (R(B, L, cin).to(dt) if two else None)
+    sc1, sh1 = R(B, cin) * 0.1 + 1, R(B, cin) * 0.1
+    sc2, sh2 = (R(B, cin) * 0.1 + 1, R(B, cin) * 0.1) if two else (None, None)
+    pw = ops.pack_linear(R(cout, cin, k) / (cin * k) ** 0.5, R(cout))
+    spw = ops.pack_linear(R(cout, cin, 1) / cin ** 0.5, R(cout)) if skip else None
+    Lout = (L + 2 * p - k) // s + 1
+    P = 2 * ((Lout + 127) // 128)
+
+    def run():
+        out = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32)
+        part = torch.zeros(B, P, G, 2, device="cuda")
+        outs = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32) if skip else None
+        parts = torch.zeros(B, P, G, 2, device="cuda") if skip else None
+        ops.conv16p(x1, sc1, sh1, pw, out, B=B, Lin=L, stride=s, pad=p, x2=x2, sc2=sc2, sh2=sh2, gn_partial=part,
+                    gn_group=cout // G, skip_pw=spw, out_s=outs, gn_partial_s=parts)
+        return [(out, part)] + ([(outs, parts)] if skip else [])
+    first, second = run(), run()
+    for (o1, p1), (o2, p2) in zip(first, second):
+        assert torch.equal(o1, o2) and torch.equal(p1, p2)
+        pad_rows = P * 64 - Lout
+        rows = torch.cat([o1.double(), torch.zeros(B, pad_rows, cout, device="cuda", dtype=torch.float64)], dim=1)
+        rows = rows.reshape(B, P, 64, G, cout // G)
+        want = torch.stack([rows.sum(dim=(2, 4)), (rows ** 2).sum(dim=(2, 4))], dim=-1)
+        err = (p1.double() - want).abs() / (1.0 + want.abs())
+        assert float(err.max()) < 1e-4, float(err.max())
+
+
 def test_conv16p_refuses_shapes_it_is_not_built_for(ops):
     ops.set_compute_dtype(torch.float16)
     x = torch.zeros(1, 64, 64, device="cuda", dtype=torch.float16)
