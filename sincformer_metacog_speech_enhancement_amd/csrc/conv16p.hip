@@ -38,90 +38,162 @@ __device__ __forceinline__ float gelu_as(float z) {    // z Phi(z), erf by A&S 7
   return z * (0.5f + 0.5f * copysignf(erfa, z));
 }
 
-// Epilogue of one 64 x 64 wave tile: bias, GroupNorm partial sums of the raw output, 16-byte row stores.  (The general
-// gemm16_epilogue_strips carries every activation / residual / dropout mode of sfm_gemm16 inline in each of its 8 unrolled
-// passes - 28 k instructions per instance; this kernel needs none of them, and two instances of that per kernel made the
-// instruction fetch, not the arithmetic, the bound.)
+// Epilogue of one 64 x 64 wave tile.  The accumulators hold the TRANSPOSED tile (weights were the A operand of the MFMAs):
+// lane (m = lane & 31, h = lane >> 5) of tile (n-block j, m-block i) holds, in register r, output row m, channel
+// n = (r & 3) + 8 (r >> 2) + 4 h: four consecutive channels per register quad.  So
+//   * the GroupNorm partial sums (per 8 / 16 / 32-channel group over the tile's 64 rows) are in-lane sums over register
+//     quads followed by DPP reductions over the lanes: no LDS;
+//   * the 16-bit result of a quad is one 8-byte LDS write into a row-major [64][64] 16-bit image (144-byte rows), ONE
+//     write -> read round trip for the whole tile, then eight 16-byte coalesced row stores.
+// (A first version passed 8 x 8-row fp32 strips through LDS like gemm16's epilogue: 8 round trips, 9 k cycles per tile - as much
+// as staging the patch and the MFMA loop together.  gemm16_epilogue_strips itself is not used here: it carries every
+// activation / residual / dropout mode of sfm_gemm16 inline, and two instances of it made instruction fetch the bound.)
 template <class T>
-__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], float* img, int lane, int b, int colb,
-                                               int row_base) {
-  constexpr int IMG_LD = 64 + 4;
+__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], unsigned char* img, int lane, int b,
+                                               int colb, int row_base) {
+  constexpr int ROWB = 144;                            // image row: 64 x 16-bit + 16 bytes of padding (fp32 mode: two passes)
   const int l31 = lane & 31, hl = lane >> 5;
-  const int c8 = (lane & 7) * 8, rsub = lane >> 3;     // 8 column chunks x 8 rows per pass
-  const int ncol0 = colb + c8;
-  float bia[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bia[e] = g.bias ? g.bias[ncol0 + e] : 0.f;
   const long long obase = (long long)b * g.o_batch_stride;
-  float gsum = 0.f, gsq = 0.f;
+  // ---- bias, statistics ----
+  float ps[2][4], pq[2][4];                            // per (n-block j, 8-channel quad-pair g): sums over this lane's rows
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the previous pass has been read out
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n0 = colb + j * 32 + 8 * gq + 4 * hl;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n0);
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool rowok = row_base + i * 32 + l31 < g.Lout;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[i][j][4 * gq + e] + bv[e];
+          acc[i][j][4 * gq + e] = v;
+          if (rowok) {
+            s_ += v;
+            q_ = __builtin_fmaf(v, v, q_);
+          }
+        }
+      }
+      ps[j][gq] = s_;
+      pq[j][gq] = q_;
+    }
+  if (g.gn_partial) {
+    // lanes = rows (and the two channel halves of a quad pair): wave-wide sums; groups wider than 8 channels fold quad pairs
+    const int cpg = g.gn_group >> 3;                   // 8-channel chunks per group: 1, 2 or 4
+    const int ngroups = g.N / g.gn_group;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float s_ = wave_sum_dpp(ps[j][gq]), q_ = wave_sum_dpp(pq[j][gq]);
+        ps[j][gq] = s_;
+        pq[j][gq] = q_;
+      }
+    if (cpg >= 2) {                                    // 16-channel groups: fold neighbouring chunks (static indices: no scratch)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+          ps[j][gq] += ps[j][gq + 1];
+          pq[j][gq] += pq[j][gq + 1];
+        }
+    }
+    if (cpg == 4) {                                    // 32-channel groups
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ps[j][0] += ps[j][2];
+        pq[j][0] += pq[j][2];
+      }
+    }
+    if (lane == 0 && (row_base >> 6) < g.gn_slots) {
+      const long long sl0 = ((long long)b * g.gn_slots + (row_base >> 6)) * ngroups;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          if ((gq % cpg) == 0) {                       // the chunk that now carries its group's sums
+            const long long sl = sl0 + (colb + j * 32 + 8 * gq) / g.gn_group;
+            g.gn_partial[sl * 2 + 0] = ps[j][gq];
+            g.gn_partial[sl * 2 + 1] = pq[j][gq];
+          }
+    }
+  }
+  // ---- store: 16-bit through one LDS image; fp32 (the latent heads' consumers) as two 32-row halves through the same image ----
+  if (g.out_f32 != 1) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          u32x2 w;
+          w[0] = pack2_out<T>(acc[i][j][4 * gq + 0], acc[i][j][4 * gq + 1], g.out_f32 == 2);
+          w[1] = pack2_out<T>(acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3], g.out_f32 == 2);
+          *reinterpret_cast<u32x2*>(img + (i * 32 + l31) * ROWB + (j * 32 + 8 * gq + 4 * hl) * 2) = w;
+        }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lane + 64 * k;
+      const int row = c >> 3, ch = c & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + row * ROWB + ch * 16);
+      const int m = row_base + row;
+      if (m < g.Lout) *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(g.out) + obase + (long long)m * g.ldo + colb + ch * 8) = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) img[(hl * 4 + rr) * IMG_LD + j * 32 + l31] = acc[i][j][4 * q + rr];
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<f32x4*>(img + l31 * 272 + (j * 32 + 8 * gq + 4 * hl) * 4) =
+              f32x4{acc[i][j][4 * gq + 0], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
-      const int m = row_base + i * 32 + q * 8 + rsub;
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[rsub * IMG_LD + c8]);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[rsub * IMG_LD + c8 + 4]);
-      float v[8] = {x0[0] + bia[0], x0[1] + bia[1], x0[2] + bia[2], x0[3] + bia[3],
-                    x1[0] + bia[4], x1[1] + bia[5], x1[2] + bia[6], x1[3] + bia[7]};
-      if (m < g.Lout) {
-        float ps = 0.f, pq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ps += v[e]; pq = __builtin_fmaf(v[e], v[e], pq); }
-        gsum += ps;
-        gsq += pq;
-        const long long orow = obase + (long long)m * g.ldo + ncol0;
-        if (g.out_f32 == 1) {
-          float* op = reinterpret_cast<float*>(g.out) + orow;
-          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-          u32x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(v[2 * e], v[2 * e + 1], g.out_f32 == 2);
-          *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(g.out) + orow) = pk;
-        }
+      for (int k = 0; k < 8; ++k) {
+        const int c = lane + 64 * k;
+        const int row = c >> 4, ch = c & 15;           // 32 rows x 16 chunks of 4 floats
+        const f32x4 v = *reinterpret_cast<const f32x4*>(img + row * 272 + ch * 16);
+        const int m = row_base + i * 32 + row;
+        if (m < g.Lout) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + obase + (long long)m * g.ldo + colb + ch * 4) = v;
       }
-    }
-  if (g.gn_partial) {
-    asm volatile("" : "+v"(gsum), "+v"(gsq));
-    for (int o = 8; o < 64; o <<= 1) {                 // lanes with the same column chunk hold different rows
-      gsum += __shfl_xor(gsum, o, 64);
-      gsq += __shfl_xor(gsq, o, 64);
-    }
-    const int cpg = g.gn_group >> 3;                   // 8-column chunks per group (1, 2 or 4)
-    for (int o = 1; o < cpg; o <<= 1) {
-      gsum += __shfl_xor(gsum, o, 64);
-      gsq += __shfl_xor(gsq, o, 64);
-    }
-    if (lane < 8 && (lane % cpg) == 0 && (row_base >> 6) < g.gn_slots) {
-      const int ngroups = g.N / g.gn_group;
-      const long long sl = ((long long)b * g.gn_slots + (row_base >> 6)) * ngroups + ncol0 / g.gn_group;
-      g.gn_partial[sl * 2 + 0] = gsum;
-      g.gn_partial[sl * 2 + 1] = gsq;
     }
   }
 }
+
+#ifdef SFM_CONVP_STAMPS
+// diagnostic build only: s_memtime stamps per workgroup (start, patch staged, k-loop done, end) -> sfm_conv16p_read_stamps
+__device__ unsigned long long sfm_convp_stamps[4 * 32768];
+#define SFM_STAMP(i) do { if (tid == 0 && blockIdx.x < 32768) sfm_convp_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int sfm_conv16p_read_stamps(void* host, int nblocks) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(sfm_convp_stamps), (size_t)nblocks * 32, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#else
+#define SFM_STAMP(i) do { } while (0)
+#endif
 
 template <class T, int KS, int STRIDE, int NPASS, bool SKIP, bool TWO_IN>
 __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
   constexpr int R = 127 * STRIDE + KS;                 // input rows of a 128-row output tile
   constexpr int PLANES = (STRIDE == 2 && KS > 1) ? 2 : 1;
-  constexpr int PR = (STRIDE == 2) ? ((R + 1) / 2 + 1) / 2 * 2 : (R + 1) / 2 * 2;   // rows per plane (even)
+  constexpr int PR = (((STRIDE == 2) ? (R + 1) / 2 : R) + 7) / 8 * 8;               // rows per plane (whole 1-KB DMA pieces)
   constexpr int PATCH = PLANES * PR * 128;             // bytes
   constexpr int WT = 128 * 128;                        // one weight tile: 128 output channels x 64 k
   constexpr int TPS = NPASS * KS + (SKIP ? 1 : 0);     // weight tiles per 64-channel slab
-  constexpr int IMG_LD = 64 + 4;
   static_assert(!SKIP || NPASS == 1, "the fused skip conv needs N = 128");
+  static_assert(PATCH + 2 * WT >= 4 * 9216, "epilogue images fit in the patch + ring area");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ring = smem + PATCH;
+  unsigned char* ring = smem + PATCH;                  // 2 weight tiles; TWO_IN: also the landing area of the second raw input
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,13 +262,41 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
     for (int s = 0; s < 4; ++s) fb_off[j][s] = row * 128 + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4);
   }
 
-  // ---- patch staging: thread = (16-byte chunk c of the 64-channel slab, row of a 32-row pass) ----
-  const int sc_ = tid & 7, srow = tid >> 3;
-  const u16* x1b = p.x1 + (long long)b * p.x_batch_stride;
-  const u16* x2b = TWO_IN ? p.x2 + (long long)b * p.x_batch_stride : nullptr;
+  // ---- patch staging.  (1) the RAW rows of the slab go global -> LDS by LDS-DMA, all at once (33 KB in flight per workgroup:
+  //      with register staging three dependent global round trips per slab left ~1 TB/s of read stream; rows outside
+  //      [0, Lin) and LDS rows beyond the patch are out of the descriptor's range and arrive as zeros); the second input of a
+  //      residual block lands in the weight ring, which is idle until the transform is done.  (2) every thread transforms
+  //      its 16-byte chunks IN PLACE (scale / shift [+ second input] -> GELU -> 16 bit); zero-filled padding rows stay zero,
+  //      as the conv's zero padding of x requires.  The chunk swizzle is applied on the DMA's source address, and
+  //      ((row >> 1) & 7) of a thread's rows (row = tid / 8 + 32 i) is constant, so a thread owns the same 8 channels in every
+  //      row: their scale / shift sit in registers. ----
+  constexpr int JSTEP = (PLANES == 1 && STRIDE == 2) ? 2 : 1;        // k = 1, stride 2: only the even input rows are read
+  constexpr int LROWS = PLANES * PR;                                 // LDS rows of the patch
+  constexpr int NPIECE = (LROWS + 7) / 8;                            // 1-KB DMA pieces
+  auto x1_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 + (long long)b * p.x_batch_stride), 0, p.Lin * p.Cin * 2, 0x00020000);
+  auto x2_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((TWO_IN ? p.x2 : p.x1) + (long long)b * p.x_batch_stride), 0,
+                                                 p.Lin * p.Cin * 2, 0x00020000);
+  // input position of LDS row lr (or -1): plane / index de-interleaving for stride 2
+  auto row_pos = [&](int lr) {
+    const int plane = (PLANES == 2) ? (lr >= PR ? 1 : 0) : 0;
+    const int idx = lr - plane * PR;
+    const int j = (PLANES == 2) ? 2 * idx + plane : idx * JSTEP;
+    const int pos = l0 * STRIDE - p.pad + j;
+    return (lr < LROWS && j < R && pos >= 0 && pos < p.Lin) ? pos : -1;
+  };
+  const int sp_ = tid & 7, srow = tid >> 3;
+  const int sc_ = sp_ ^ ((srow >> 1) & 7);                           // logical chunk (8 channels) this thread owns in every row
   auto stage_patch = [&](int slab) {
+    for (int pc = wave; pc < NPIECE; pc += 4) {
+      const int lr = pc * 8 + (lane >> 3);
+      const int pos = row_pos(lr);
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      const int voff = pos >= 0 ? (pos * p.Cin + slab * 64 + c * 8) * 2 : -1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x1_rs, (lds_ptr_t)(smem + pc * 1024), 16, voff, 0, 0, 0);
+      if (TWO_IN) __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rs, (lds_ptr_t)(ring + pc * 1024), 16, voff, 0, 0, 0);
+    }
     const int ch0 = slab * 64 + sc_ * 8;
-    float a1[8], d1[8], a2[8], d2[8];
+    float a1[8], d1[8], a2[8];
     {
       const f32x4* ps = reinterpret_cast<const f32x4*>(p.sc1 + (long long)b * p.Cin + ch0);
       const f32x4* ph = reinterpret_cast<const f32x4*>(p.sh1 + (long long)b * p.Cin + ch0);
@@ -211,48 +311,27 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
         for (int e = 0; e < 4; ++e) { a2[e] = t0[e]; a2[4 + e] = t1[e]; d1[e] += g0[e]; d1[4 + e] += g1[e]; }
       }
     }
-    constexpr int JSTEP = (PLANES == 1 && STRIDE == 2) ? 2 : 1;      // k = 1, stride 2: only the even input rows are read
-    constexpr int NROWS = (R + JSTEP - 1) / JSTEP;
-    constexpr int NP = (NROWS + 31) / 32;                            // 32-row passes
-    constexpr int UN = TWO_IN ? 2 : 3;                               // passes in flight (registers: 4 per input and pass)
-#pragma unroll 1
-    for (int p0 = 0; p0 < NP; p0 += UN) {
-      u32x4 v1[UN], v2[UN];
-      bool ok[UN];
+    wait_vmcnt<0>();                                   // this wave's pieces have landed ...
+    __syncthreads();                                   // ... everyone's have
+#pragma unroll 2
+    for (int lr = srow; lr < LROWS; lr += 32) {
+      if (row_pos(lr) < 0) continue;                   // zero-filled row: stays the conv's zero padding
+      unsigned char* q1 = smem + lr * 128 + sp_ * 16;
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(q1);
+      u32x4 v2 = {0u, 0u, 0u, 0u};
+      if (TWO_IN) v2 = *reinterpret_cast<const u32x4*>(ring + lr * 128 + sp_ * 16);
+      u32x4 o;
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int jr = (p0 + u) * 32 + srow;
-        const int pos = l0 * STRIDE - p.pad + jr * JSTEP;
-        ok[u] = (p0 + u) < NP && jr < NROWS && pos >= 0 && pos < p.Lin;
-        v1[u] = u32x4{0u, 0u, 0u, 0u};
-        v2[u] = u32x4{0u, 0u, 0u, 0u};
-        if (ok[u]) {
-          v1[u] = *reinterpret_cast<const u32x4*>(x1b + (long long)pos * p.Cin + ch0);
-          if (TWO_IN) v2[u] = *reinterpret_cast<const u32x4*>(x2b + (long long)pos * p.Cin + ch0);
+      for (int e = 0; e < 4; ++e) {
+        float z0 = T::to_f32((u16)(v1[e] & 0xffffu)) * a1[2 * e] + d1[2 * e];
+        float z1 = T::to_f32((u16)(v1[e] >> 16)) * a1[2 * e + 1] + d1[2 * e + 1];
+        if (TWO_IN) {
+          z0 += T::to_f32((u16)(v2[e] & 0xffffu)) * a2[2 * e];
+          z1 += T::to_f32((u16)(v2[e] >> 16)) * a2[2 * e + 1];
         }
+        o[e] = pack2<T>(gelu_as(z0), gelu_as(z1));
       }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int jr = (p0 + u) * 32 + srow;
-        if ((p0 + u) < NP && jr < NROWS) {
-          u32x4 o = {0u, 0u, 0u, 0u};                                // rows outside [0, Lin): the conv's zero padding of x
-          if (ok[u]) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float z0 = T::to_f32((u16)(v1[u][e] & 0xffffu)) * a1[2 * e] + d1[2 * e];
-              float z1 = T::to_f32((u16)(v1[u][e] >> 16)) * a1[2 * e + 1] + d1[2 * e + 1];
-              if (TWO_IN) {
-                z0 += T::to_f32((u16)(v2[u][e] & 0xffffu)) * a2[2 * e];
-                z1 += T::to_f32((u16)(v2[u][e] >> 16)) * a2[2 * e + 1];
-              }
-              o[e] = pack2<T>(gelu_as(z0), gelu_as(z1));
-            }
-          }
-          const int j = jr * JSTEP;
-          const int lrow = (PLANES == 2) ? (j & 1) * PR + (j >> 1) : jr;
-          *reinterpret_cast<u32x4*>(smem + lrow * 128 + ((sc_ ^ ((lrow >> 1) & 7)) << 4)) = o;
-        }
-      }
+      *reinterpret_cast<u32x4*>(q1) = o;
     }
   };
 
@@ -276,22 +355,25 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) a[i][j] = T::mfma(fa[i], fb[j], a[i][j]);
+        for (int j = 0; j < 2; ++j) a[i][j] = T::mfma(fb[j], fa[i], a[i][j]);      // transposed tile: rows of C^T = channels
     }
   };
 
-  issue_w(0);
+  SFM_STAMP(0);
+  if (!TWO_IN) issue_w(0);
   for (int slab = 0; slab < nslab; ++slab) {
-    if (slab > 0) __syncthreads();                     // every wave is done reading the previous slab's patch
+    if (slab > 0) __syncthreads();                     // every wave is done reading the previous slab's patch (and weight tiles)
     stage_patch(slab);
     __syncthreads();                                   // patch complete
+    if (slab == 0) SFM_STAMP(1);
     const int q0 = slab * TPS;
+    if (TWO_IN) issue_w(q0);                           // the ring held the second raw input until now
 #pragma unroll
     for (int j = 0; j < TPS; ++j) {
       const int q = q0 + j;
       wait_vmcnt<0>();                                 // this wave's share of weight tile q has landed
       __builtin_amdgcn_s_barrier();                    // ... everyone's has, and tile q-1 is no longer being read
-      if (q + 1 < Q) issue_w(q + 1);
+      if (q + 1 < Q && (!TWO_IN || j + 1 < TPS)) issue_w(q + 1);
       if (SKIP && j == TPS - 1) {
         mma_tile(q, p.pad, accs);                      // 1x1 stride-2 conv = the centre tap of the same patch
       } else {
@@ -302,18 +384,21 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
     }
   }
   __syncthreads();                                     // the ring becomes the epilogue strips
-  float* img = reinterpret_cast<float*>(ring) + wave * (8 * IMG_LD);
+  SFM_STAMP(2);
+  unsigned char* img = smem + wave * 9216;             // 64 x 144 B per wave, in the (now free) patch + ring area
 #pragma unroll
   for (int n = 0; n < NPASS; ++n) convp_epilogue<T>(p.g, acc[n], img, lane, b, n * 128 + wn * 64, l0 + wm * 64);
   if (SKIP) convp_epilogue<T>(p.gs, accs, img, lane, b, wn * 64, l0 + wm * 64);
+  SFM_STAMP(3);
 }
 
 template <class T, int KS, int STRIDE, int NPASS, bool SKIP, bool TWO_IN>
 static int launch_convp(const ConvPParams& p, hipStream_t stream) {
   constexpr int R = 127 * STRIDE + KS;
   constexpr int PLANES = (STRIDE == 2 && KS > 1) ? 2 : 1;
-  constexpr int PR = (STRIDE == 2) ? ((R + 1) / 2 + 1) / 2 * 2 : (R + 1) / 2 * 2;
-  constexpr int lds = PLANES * PR * 128 + 2 * 128 * 128;
+  constexpr int PR = (((STRIDE == 2) ? (R + 1) / 2 : R) + 7) / 8 * 8;
+  constexpr int patch = PLANES * PR * 128;
+  constexpr int lds = patch + ((TWO_IN && patch > 2 * 128 * 128) ? patch : 2 * 128 * 128);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv16p_kernel<T, KS, STRIDE, NPASS, SKIP, TWO_IN>,

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic (library built with -DSFM_CONVP_STAMPS: tools/convp_variants.sh stamps -DSFM_CONVP_STAMPS): where a conv16p
+workgroup spends its cycles - staging the patch, the weight-tile loop, the epilogue(s)."""
+import ctypes, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from sincformer_metacog_speech_enhancement_amd import ops, lib
+ops.set_compute_dtype("f16")
+dt = torch.float16
+B = 64
+g = torch.Generator(device="cuda").manual_seed(0)
+R = lambda *s: torch.randn(*s, device="cuda", generator=g)
+L_ = lib.load()
+rd = ctypes.CDLL(lib.LIB_PATH).sfm_conv16p_read_stamps
+for name, cin, cout, k, s, p, two, skip, L in [("b0.c1+cs", 64, 128, 7, 2, 3, False, True, 64000), ("b0.c2", 128, 128, 3, 1, 1, False, False, 32000),
+                                               ("b1.c1+cs", 128, 128, 7, 2, 3, True, True, 32000), ("b2.c2", 256, 256, 3, 1, 1, False, False, 8000)]:
+    x1, x2 = R(B, L, cin).to(dt), (R(B, L, cin).to(dt) if two else None)
+    sc1, sh1 = R(B, cin) * 0.1 + 1, R(B, cin) * 0.1
+    sc2, sh2 = (R(B, cin) * 0.1 + 1, R(B, cin) * 0.1) if two else (None, None)
+    pw = ops.pack_linear(R(cout, cin, k) / (cin * k) ** 0.5, R(cout))
+    spw = ops.pack_linear(R(cout, cin, 1) / cin ** 0.5, R(cout)) if skip else None
+    Lout = (L + 2 * p - k) // s + 1
+    P = 2 * ((Lout + 127) // 128)
+    out = torch.empty(B, Lout, cout, device="cuda", dtype=dt)
+    part = torch.zeros(B, P, 16, 2, device="cuda")
+    outs = torch.empty(B, Lout, cout, device="cuda", dtype=dt) if skip else None
+    parts = torch.zeros(B, P, 16, 2, device="cuda") if skip else None
+    for _ in range(3):
+        ops.conv16p(x1, sc1, sh1, pw, out, B=B, Lin=L, stride=s, pad=p, x2=x2, sc2=sc2, sh2=sh2, gn_partial=part, gn_group=cout // 16,
+                    skip_pw=spw, out_s=outs, gn_partial_s=parts)
+    torch.cuda.synchronize()
+    n = min(32768, B * ((Lout + 127) // 128))
+    buf = np.zeros((n, 4), dtype=np.uint64)
+    assert rd(buf.ctypes.data_as(ctypes.c_void_p), n) == 0
+    st = buf.astype(np.float64)
+    d = np.diff(st, axis=1)
+    tot = st[:, 3] - st[:, 0]
+    print(json.dumps({"layer": name, "cycles_p50": {"stage_first_slab": float(np.median(d[:, 0])), "rest_slabs+k_loop": float(np.median(d[:, 1])),
+                                                   "epilogue": float(np.median(d[:, 2])), "total": float(np.median(tot))}}))
