@@ -112,7 +112,7 @@ def test_training_backward_directional_derivative_at_full_size():
     for f(theta) = <cotangent, model(theta)> the HIP backward's gradient g must predict the change of f along its own
     direction, f(theta + e d) - f(theta - e d) = 2 e |g| with d = g / |g| (dropout off: f is a deterministic function).
     A fixed cotangent is used instead of the objective because the objective's own gradient (1 / |STFT bin| terms) turns the
-    16-bit rounding noise of the forward into tens of per cent of gradient noise (tools/grad_repro2.py); the objective's
+    16-bit rounding noise of the forward into tens of per cent of gradient noise; the objective's
     backward is checked on identical inputs in tests/test_train_gpu.py."""
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft
