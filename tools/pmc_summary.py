@@ -9,7 +9,7 @@ coalesced stream, i.e. reports half of the bytes -> doubled here (`fetch_correct
 exact for 16-B-per-lane streaming stores.  Both counters are in KiB."""
 import collections, csv, json, re, sys
 
-FAMILY = [("gemm16_tn", "gemm16_tn"), ("attn_bwd", "attention_bwd"), ("layernorm_bwd", "layernorm_bwd"), ("ew_train", "ew_train"),
+FAMILY = [("conv16p_kernel", "conv16p"), ("gemm16_tn", "gemm16_tn"), ("attn_bwd", "attention_bwd"), ("layernorm_bwd", "layernorm_bwd"), ("ew_train", "ew_train"),
           ("framed_gemm_split16", "framed_gemm_split16"), ("gemm16v2_kernel", "gemm16"), ("gemm16w_kernel", "gemm16"), ("gemm16p_kernel", "gemm16"), ("gemm16_kernel", "gemm16"), ("attn_fwd", "attention_fwd"),
           ("framed_gemm", "framed_gemm_f32"), ("sinc_fir16_kernel", "sinc_fir16"), ("ffn_fused", "ffn_fused"), ("gn_apply", "gn_apply"),
           ("layernorm", "layernorm"), ("bilstm", "bilstm_layer"), ("dwconv", "dwconv_bn_swish"),
