@@ -22,7 +22,7 @@ for k, cs in acc.items():
     d["dispatches"] = max(v[0] for v in cs.values())
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
         d["mfma_util_pct"] = 100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-    if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
+    if "SQ_LDS_BANK_CONFLICT" in d and d.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
         d["lds_conflict_pct"] = 100.0 * d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]
     if "SQ_WAIT_INST_ANY" in d and "SQ_WAVE_CYCLES" in d:
         d["wait_pct"] = 100.0 * d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"]
