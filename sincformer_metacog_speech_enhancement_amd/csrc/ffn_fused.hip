@@ -2,13 +2,20 @@
 //     out = x + alpha * ( W2 * swish(W1 * LayerNorm(x) + b1) + b2 )          D = 256, FF % 64 == 0
 // One workgroup (8 waves) owns 128 rows.  x is read from HBM once, normalised in registers and kept
 // as the 16-bit A operand [128 x 256] in LDS for the whole kernel; the FF-wide hidden activation never
-// leaves the CU: per 64-unit chunk  S1 = H W1c^T (MFMA) -> +b1, swish -> 16-bit U in LDS ->
-// acc2 += U W2c^T (MFMA).  The GEMM1 A operand of a wave (its 32 rows of LN(x), all 256 k) stays in
-// registers for the whole kernel; weight chunks (W1c + W2c = 64 KB) stream from L2 by LDS-DMA into a
-// 2-stage ring one full chunk ahead; two raw barriers per chunk, counted vmcnt.
-// HBM traffic: x in (1 KB/row) + out (1 KB/row) instead of ~8 KB/row for LN + two GEMM launches.
+// leaves the CU: per 64-unit chunk  S1 = H W1c^T + b1 (MFMA, accumulator started from the bias) -> swish -> 16-bit U in
+// LDS -> acc2 += U W2c^T (MFMA).  The GEMM1 A operand of a wave (its 32 rows of LN(x), all 256 k) stays in registers for
+// the whole kernel; weight chunks (W1c + W2c = 64 KB) stream from L2 by LDS-DMA into a 2-stage ring.
+// Schedule (round 2; stamps and ablations in profiles/README.md): the Swish of chunk c shares an instruction stream with the
+// GEMM1 MFMAs of chunk c+1, the weight refills are issued from inside the MFMA streams (a burst of 8 pieces after a barrier
+// cost every wave ~500 issue cycles per chunk), two raw barriers per chunk with counted vmcnt waits; the epilogue works in
+// the prologue's row layout (no second read of x from a far cache line, LayerNorm of the next sub-layer by DPP adds).
+// HBM traffic: x in (1 KB/row, read twice: the residual re-read comes from L2 / Infinity Cache) + out (1 KB/row) instead of
+// ~8 KB/row for LN + two GEMM launches.
 #include "sfm_common.h"
 
+#ifndef SFM_FFN_ABL
+#define SFM_FFN_ABL 0                   // diagnostic builds only (tools/variant_lib.sh): 1 no weight refills, 2 no Swish (results wrong)
+#endif
 #define FF_D 256
 #define FF_BM 128
 #define FF_CH 64                        // hidden units per chunk
@@ -19,6 +26,13 @@ template <int N>
 __device__ __forceinline__ void ff_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+__device__ __forceinline__ void ff_frag_read(u32x4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ff_frag_wait(u32x4& frag) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
+}
 __device__ __forceinline__ void ff_barrier() {
   // LDS writes of this wave must have completed before other waves pass the barrier; the LDS-DMA
   // queue (vmcnt) is deliberately NOT drained here - that is what the counted waits are for.
@@ -26,6 +40,17 @@ __device__ __forceinline__ void ff_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+
+#ifdef SFM_FFN_STAMPS
+// diagnostic build only (tools/variant_lib.sh): s_memtime stamps per workgroup -> sfm_ffn_read_stamps
+__device__ unsigned long long sfm_ffn_stamps[8 * 4096];
+#define FF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) sfm_ffn_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int sfm_ffn_read_stamps(void* host, int nblocks) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(sfm_ffn_stamps), (size_t)nblocks * 64, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
 
 template <class T>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict__ x, const float* __restrict__ lnw,
@@ -47,32 +72,12 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hl = lane >> 5;
   const int m0 = blockIdx.x * FF_BM;
+  FF_STAMP(0);
   auto w1_rs = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, w1_bytes, 0x00020000);
   auto w2_rs = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, w2_bytes, 0x00020000);
 
-  // LDS-DMA pieces: W1 chunk = 64 rows x 512 B (4 x 1 KB per wave, 2 rows each, chunk c at c ^ (row & 15));
-  //                 W2 chunk = 256 rows x 128 B (4 x 1 KB per wave, 8 rows each, chunk c at c ^ ((row >> 1) & 7))
-  auto issue_w = [&](int c, int stage) {
-    unsigned char* w1s = smem + stage * STG;
-    unsigned char* w2s = w1s + FF_CH * 512;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int inst = wave * 4 + i;
-      const int row = inst * 2 + (lane >> 5);
-      const int lc = (lane & 31) ^ (row & 15);
-      const int voff = ((c * FF_CH + row) * FF_D + lc * 8) * 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rs, (lds_ptr_t)(w1s + inst * 1024), 16, voff, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int inst = wave * 4 + i;
-      const int row = inst * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      const int voff = (row * FF + c * FF_CH + lc * 8) * 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rs, (lds_ptr_t)(w2s + inst * 1024), 16, voff, 0, 0, 0);
-    }
-  };
-
+  // LDS-DMA pieces (issue_group below): W1 chunk = 64 rows x 512 B (4 x 1 KB per wave, 2 rows each, chunk c at
+  // c ^ (row & 15)); W2 chunk = 256 rows x 128 B (4 x 1 KB per wave, 8 rows each, chunk c at c ^ ((row >> 1) & 7))
   // ---- LayerNorm prologue: wave w normalises rows 16w .. 16w+15, 4 consecutive columns per lane.
   //      All 16 row loads are issued before the first use; row statistics by DPP adds (no LDS round trips).
   {
@@ -108,12 +113,48 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   for (int s = 0; s < 16; ++s)
     hf[s] = *reinterpret_cast<const u32x4*>(Hs + r1 * 512 + (((2 * s + hl) ^ (r1 & 15)) << 4));
   __syncthreads();                                         // LN image consumed: the weight ring may overwrite it
+  FF_STAMP(1);
   const int nch = FF / FF_CH;
-  issue_w(0, 0);
-  if (nch > 1) issue_w(1, 1);
+  // Weight pieces: a wave moves 4 x 1 KB of every W1 chunk and 4 x 1 KB of every W2 chunk (ring stage c & 1).  A chunk index
+  // past the end is issued all the same: the buffer range check turns it into zeros written to ring bytes nobody reads
+  // again, and the counted vmcnt waits below stay the same from the first chunk to the last.
+  auto w1_piece = [&](int c, int i) {
+    unsigned char* w1s = smem + (c & 1) * STG;
+    const int inst = wave * 4 + i;
+    const int row = inst * 2 + (lane >> 5);
+    const int lc = (lane & 31) ^ (row & 15);
+    const int voff = ((c * FF_CH + row) * FF_D + lc * 8) * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rs, (lds_ptr_t)(w1s + inst * 1024), 16, voff, 0, 0, 0);
+  };
+  auto w2_piece = [&](int c, int i) {
+    unsigned char* w2s = smem + (c & 1) * STG + FF_CH * 512;
+    const int inst = wave * 4 + i;
+    const int row = inst * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int voff = c < nch ? (row * FF + c * FF_CH + lc * 8) * 2 : w2_bytes;   // W2 rows interleave the chunks: force the miss
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rs, (lds_ptr_t)(w2s + inst * 1024), 16, voff, 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w1_piece(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w2_piece(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w1_piece(1, i);
 
-  // wave roles: GEMM1 tile = rows 32*(w>>1), hidden cols 32*(w&1); GEMM2 tile = rows 64*(w>>2), out cols 64*(w&3)
+  // wave roles: GEMM1 tile = rows 32*(w>>1), hidden cols 32*(w&1); GEMM2 tile = rows 64*(w>>2), out cols 64*(w&3).
+  // A chunk period has two phases with a barrier after each:
+  //   X(c): GEMM1 of chunk c+1 (MFMA) in the same instruction stream as the Swish of chunk c (VALU on the previous
+  //         GEMM1's accumulator) -> U(c);  plus the refill W2(c+1) (its ring bytes held W2(c-1), read in Y(c-1))
+  //   Y(c): GEMM2 of chunk c (MFMA);       plus the refill W1(c+3) (held W1(c+1), read in X(c))
+  // so the matrix pipe has work in both phases and the Swish never runs alone.  A wave's pieces in issue order:
+  // W1(0) W2(0) W1(1) | W1(2) | X(0): W2(1) | Y(0): W1(3) | X(1): W2(2) | Y(1): W1(4) ... ; the barrier after X(c) needs
+  // W2(c) and the one after Y(c) needs W1(c+2): both have exactly two younger groups behind them (vmcnt 8).
   const int wm2 = wave >> 2, wn2 = wave & 3;
+  const int row1 = (wave >> 1) * 32 + l31;                  // GEMM1 / Swish: x row of this lane
+  // W1 fragment k of ring stage s sits at s * STG + n1 * 512 + (((2k + hl) ^ (n1 & 15)) << 4) = w1_lane + s * STG + (hx4 ^ (k << 5))
+  const uint32_t w1_lane = (uint32_t)(uintptr_t)(lds_ptr_t)smem + (uint32_t)(n1 * 512);
+  const int hx4 = (hl ^ (n1 & 15)) << 4;
+  const int ub = (wave & 1) * 32;                           // first hidden unit (inside the chunk) of this wave
   f32x16 acc2[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -122,159 +163,189 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
 
-  if (nch > 1) ff_wait_vmcnt<8>(); else ff_wait_vmcnt<0>();   // chunk 0 landed (chunk 1 may be in flight)
-  ff_barrier();
-  for (int c = 0; c < nch; ++c) {
-    const unsigned char* W1s = smem + (c & 1) * STG;
-    const unsigned char* W2s = W1s + FF_CH * 512;
-    // ---- GEMM1 (transposed): S1^T[32 units x 32 rows] = W1c[32 units x 256] * H[32 rows x 256]^T ----
-    // (W1c is the MFMA A operand, the register-resident H the B operand: a lane then holds 4 CONSECUTIVE
-    //  hidden units of one row per register quad, so U goes to LDS with 8-byte stores)
-    f32x16 s1;
+  // GEMM1 (transposed): S1^T[32 units x 32 rows] = W1c[32 units x 256] * H[32 rows x 256]^T + b1 (the accumulator starts
+  // from the bias).  W1c is the MFMA A operand, the register-resident H the B operand: a lane then holds 4 CONSECUTIVE hidden
+  // units of one row per register quad, so U goes to LDS with 8-byte stores.
+  auto s1_init = [&](int c, f32x16& s1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + c * FF_CH + ub + 8 * q + 4 * hl);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const u32x4 fw = *reinterpret_cast<const u32x4*>(W1s + n1 * 512 + (((2 * s + hl) ^ (n1 & 15)) << 4));
-      s1 = T::mfma(fw, hf[s], s1);
+      for (int e = 0; e < 4; ++e) s1[4 * q + e] = bv[e];
     }
-    {
-      const int row = (wave >> 1) * 32 + l31;                // x row of this lane
-      const int ub = (wave & 1) * 32;                        // first hidden unit (inside the chunk) of this wave
+  };
+  auto w1_frag = [&](int c, int k) {
+    return *reinterpret_cast<const u32x4*>(smem + (c & 1) * STG + n1 * 512 + (((2 * k + hl) ^ (n1 & 15)) << 4));
+  };
+  // Swish of 4 accumulator registers (units u0..u0+3 of this lane's row) -> 8 bytes of U
+  auto swish_quad = [&](const f32x16& s1, int q) {
+    float y[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int u0 = ub + 8 * q + 4 * hl;                  // units u0 .. u0+3 = registers 4q .. 4q+3
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + c * FF_CH + u0);
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = s1[4 * q + e] + bv[e];
-          y[e] = z * __frcp_rn(1.0f + __expf(-z));
-        }
-        u32x2 pk;
-        pk[0] = pack2<T>(y[0], y[1]);
-        pk[1] = pack2<T>(y[2], y[3]);
-        const int chunk = (u0 >> 3) ^ ((row >> 1) & 7);
-        *reinterpret_cast<u32x2*>(Us + row * 128 + chunk * 16 + (u0 & 7) * 2) = pk;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float z = s1[4 * q + e];
+#if SFM_FFN_ABL == 2
+      y[e] = z;
+#else
+      y[e] = z * __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+#endif
     }
-    ff_barrier();                                           // U(c) complete (U(c-1) readers finished before the last barrier)
-    // ---- GEMM2: acc2[64 x 64] += U[64 rows x 64] * W2c[64 out cols x 64]^T ----
+    u32x2 pk;
+    pk[0] = pack2<T>(y[0], y[1]);
+    pk[1] = pack2<T>(y[2], y[3]);
+    const int u0 = ub + 8 * q + 4 * hl;
+    const int chunk = (u0 >> 3) ^ ((row1 >> 1) & 7);
+    *reinterpret_cast<u32x2*>(Us + row1 * 128 + chunk * 16 + (u0 & 7) * 2) = pk;
+  };
+  auto gemm2 = [&](int c, bool refill) {
+    const unsigned char* W2s = smem + (c & 1) * STG + FF_CH * 512;
+    u32x4 fa[4][2], fb[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32x4 fa[2], fb[2];
+    for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = wm2 * 64 + i * 32 + l31;
-        fa[i] = *reinterpret_cast<const u32x4*>(Us + row * 128 + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4));
+        fa[k][i] = *reinterpret_cast<const u32x4*>(Us + row * 128 + (((2 * k + hl) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = wn2 * 64 + j * 32 + l31;
-        fb[j] = *reinterpret_cast<const u32x4*>(W2s + row * 128 + (((2 * s + hl) ^ ((row >> 1) & 7)) << 4));
+        fb[k][j] = *reinterpret_cast<const u32x4*>(W2s + row * 128 + (((2 * k + hl) ^ ((row >> 1) & 7)) << 4));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc2[i][j] = T::mfma(fa[i], fb[j], acc2[i][j]);
-    }
-    ff_wait_vmcnt<0>();                                      // own pieces of chunk c+1 have landed
-    ff_barrier();                                           // stage (c & 1) and U are free; chunk c+1 complete for all
-    if (c + 2 < nch) issue_w(c + 2, c & 1);
-  }
+        for (int j = 0; j < 2; ++j) {
+          acc2[i][j] = T::mfma(fa[k][i], fb[k][j], acc2[i][j]);
+          const int m = k * 4 + i * 2 + j;
+#if SFM_FFN_ABL != 1
+          if (refill && (m & 3) == 1) w1_piece(c + 3, m >> 2);
+#endif
+        }
+  };
 
-  // ---- epilogue: acc2 -> per-wave fp32 image [64][68] -> out = x + alpha * (acc2 + b2), 16-byte row stores ----
-  float* img = reinterpret_cast<float*>(smem) + wave * (64 * 68);
+  f32x16 s1;                                                // GEMM1 accumulator of the chunk whose Swish comes next
+  ff_wait_vmcnt<8>();                                       // W1(0) is in
+  ff_barrier();
+  FF_STAMP(2);
+  s1_init(0, s1);
+  {
+    u32x4 fw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fw[k] = w1_frag(0, k);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      s1 = T::mfma(fw[k & 3], hf[k], s1);
+      if (k + 4 < 16) fw[k & 3] = w1_frag(0, k + 4);
+    }
+  }
+  ff_wait_vmcnt<0>();                                       // W2(0), W1(1) are in
+  ff_barrier();                                             // W1(0) has been read by everyone
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w1_piece(2, i);
+  for (int c = 0; c + 1 < nch; ++c) {
+    // ---- X(c) ----
+    {
+      f32x16 s1n;
+      s1_init(c + 1, s1n);
+      // W1 fragments by inline-asm reads kept FOUR MFMAs ahead of their use (left to the compiler the reads sink to one
+      // MFMA ahead to save registers).  ff_frag_wait is the lgkmcnt wait the compiler no longer inserts (N = this wave's
+      // younger fragment reads), tied to the registers.
+      const uint32_t fbase = w1_lane + (uint32_t)(((c + 1) & 1) * STG);
+      u32x4 fw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ff_frag_read(fw[k], fbase + (uint32_t)(hx4 ^ (k << 5)));
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k <= 12) ff_frag_wait<3>(fw[k & 3]);
+        else if (k == 13) ff_frag_wait<2>(fw[k & 3]);
+        else if (k == 14) ff_frag_wait<1>(fw[k & 3]);
+        else ff_frag_wait<0>(fw[k & 3]);
+        s1n = T::mfma(fw[k & 3], hf[k], s1n);
+        if (k + 4 < 16) ff_frag_read(fw[k & 3], fbase + (uint32_t)(hx4 ^ ((k + 4) << 5)));
+        if ((k & 3) == 1) swish_quad(s1, k >> 2);
+#if SFM_FFN_ABL != 1
+        if ((k & 3) == 3) w2_piece(c + 1, k >> 2);
+#endif
+      }
+      s1 = s1n;
+    }
+    ff_wait_vmcnt<8>();                                     // W2(c) is in
+    ff_barrier();                                           // U(c) complete; W1(c+1) and W2(c-1) have been read
+    // ---- Y(c): acc2[64 x 64] += U[64 rows x 64] * W2c[64 out cols x 64]^T ----
+    gemm2(c, true);
+    ff_wait_vmcnt<8>();                                     // W1(c+2) is in
+    ff_barrier();                                           // U(c) and W2(c) have been read
+  }
+  // ---- last chunk: no GEMM1 left, so H's registers take the residual rows of x now (prologue layout: wave w rows 16w..+15,
+  //      4 consecutive columns per lane) and the loads fly under the last Swish and GEMM2; no refills either ----
+  int ln = lane;                                           // opaque: addresses built from it are computed here, not
+  asm volatile("" : "+v"(ln));                             // hoisted above the chunk loop and spilled across it
+  f32x4 xv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int m = m0 + wave * 16 + r;
+    m = m < M ? m : M - 1;
+    xv[r] = *reinterpret_cast<const f32x4*>(x + (long long)m * FF_D + ln * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) swish_quad(s1, q);
+  ff_wait_vmcnt<20>();                                      // W2(nch-1) is in (behind it: the zeros of W1(nch+1), the 16 rows)
+  ff_barrier();
+  gemm2(nch - 1, false);
+  ff_wait_vmcnt<0>();                                       // the refills past the last chunk (zeros) have landed in the
+  ff_barrier();                                             // ring bytes the epilogue image is about to take
+
+  FF_STAMP(3);
+  // ---- epilogue in the prologue's row layout: acc2 -> fp32 image [128][260] -> wave w takes rows 16w..16w+15, a lane 4
+  //      consecutive columns: out = x + alpha * (acc2 + b2) leaves as 1-KB row stores, and the LayerNorm of the NEXT sub-layer
+  //      (mhsa.layer_norm after ff1, final_norm after ff2; models/conformer.py:66, 151) is a per-wave DPP reduction ----
+  constexpr int IW = 260;
+  float* img = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) img[(i * 32 + mfma_row(r, lane)) * 68 + j * 32 + l31] = acc2[i][j][r];
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_wave_barrier();
-  const int c8 = (lane & 7) * 8, rsub = lane >> 3;
-  const int ncol = wn2 * 64 + c8;
-  const f32x4 bb0 = *reinterpret_cast<const f32x4*>(b2 + ncol);
-  const f32x4 bb1 = *reinterpret_cast<const f32x4*>(b2 + ncol + 4);
-  float ov[8][8];                                        // this lane's 8 rows x 8 columns of y = x + alpha * ffn(x)
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + rsub;
-    const int m = m0 + wm2 * 64 + row;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(&img[row * 68 + c8]);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(&img[row * 68 + c8 + 4]);
-    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-    if (m < M) {
-      const float* xp = x + (long long)m * FF_D + ncol;
-      x0 = *reinterpret_cast<const f32x4*>(xp);
-      x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ov[it][e] = x0[e] + alpha * (a0[e] + bb0[e]);
-      ov[it][4 + e] = x1[e] + alpha * (a1[e] + bb1[e]);
-    }
-    if (out && m < M) {
-      float* op = out + (long long)m * FF_D + ncol;
-      *reinterpret_cast<f32x4*>(op) = f32x4{ov[it][0], ov[it][1], ov[it][2], ov[it][3]};
-      *reinterpret_cast<f32x4*>(op + 4) = f32x4{ov[it][4], ov[it][5], ov[it][6], ov[it][7]};
-    }
+      for (int r = 0; r < 16; ++r)
+        img[(wm2 * 64 + i * 32 + mfma_row(r, lane)) * IW + wn2 * 64 + j * 32 + l31] = acc2[i][j][r];
+  ff_barrier();
+  FF_STAMP(4);
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + ln * 4);
+  f32x4 g2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
+  if (ln2w != nullptr) {
+    g2 = *reinterpret_cast<const f32x4*>(ln2w + ln * 4);
+    h2 = *reinterpret_cast<const f32x4*>(ln2b + ln * 4);
   }
-  if (ln2w == nullptr) return;                           // block-uniform
-
-  // ---- fused LayerNorm of the NEXT sub-layer on y (mhsa.layer_norm after ff1, final_norm after ff2; models/conformer.py:
-  // 66, 151): a row's 256 columns live in the 4 waves wn2 = 0..3, so the row statistics cross the waves through LDS ----
-  float* red = reinterpret_cast<float*>(smem + 8 * 64 * 68 * 4);   // [128 rows][4] behind the images
-  float mean[8], rstd[8];
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int r = 0; r < 16; ++r) {
+    const int row = wave * 16 + r;
+    const int m = m0 + row;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&img[row * IW + ln * 4]);
+    f32x4 y;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      float v = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = pass ? (ov[it][e] - mean[it]) : ov[it][e];
-        v += pass ? d * d : d;
-      }
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      if ((lane & 7) == 0) red[(wm2 * 64 + it * 8 + rsub) * 4 + wn2] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const f32x4 q = *reinterpret_cast<const f32x4*>(&red[(wm2 * 64 + it * 8 + rsub) * 4]);
-      const float t = (q[0] + q[1] + q[2] + q[3]) * (1.0f / FF_D);
-      if (pass == 0) mean[it] = t;
-      else rstd[it] = rsqrtf(t + eps);
-    }
-    __syncthreads();
-  }
-  const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln2w + ncol), g1 = *reinterpret_cast<const f32x4*>(ln2w + ncol + 4);
-  const f32x4 h0 = *reinterpret_cast<const f32x4*>(ln2b + ncol), h1 = *reinterpret_cast<const f32x4*>(ln2b + ncol + 4);
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int m = m0 + wm2 * 64 + it * 8 + rsub;
+    for (int e = 0; e < 4; ++e) y[e] = xv[r][e] + alpha * (a[e] + bb[e]);
+    if (out && m < M) *reinterpret_cast<f32x4*>(out + (long long)m * FF_D + ln * 4) = y;
+    if (ln2w == nullptr) continue;                         // block-uniform
+    const float mean = wave_sum_dpp(y[0] + y[1] + y[2] + y[3]) * (1.0f / FF_D);
+    const float d0 = y[0] - mean, d1 = y[1] - mean, d2 = y[2] - mean, d3 = y[3] - mean;
+    const float rstd = rsqrtf(wave_sum_dpp(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / FF_D) + eps);
+    const float z0 = d0 * rstd * g2[0] + h2[0], z1 = d1 * rstd * g2[1] + h2[1];
+    const float z2 = d2 * rstd * g2[2] + h2[2], z3 = d3 * rstd * g2[3] + h2[3];
     if (m >= M) continue;
-    float y[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      y[e] = (ov[it][e] - mean[it]) * rstd[it] * g0[e] + h0[e];
-      y[4 + e] = (ov[it][4 + e] - mean[it]) * rstd[it] * g1[e] + h1[e];
-    }
     if (ln_out_f32) {
-      float* op = reinterpret_cast<float*>(ln_out) + (long long)m * FF_D + ncol;
-      *reinterpret_cast<f32x4*>(op) = f32x4{y[0], y[1], y[2], y[3]};
-      *reinterpret_cast<f32x4*>(op + 4) = f32x4{y[4], y[5], y[6], y[7]};
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ln_out) + (long long)m * FF_D + ln * 4) = f32x4{z0, z1, z2, z3};
     } else {
-      u32x4 pk;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(y[2 * e], y[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(ln_out) + (long long)m * FF_D + ncol) = pk;
+      u32x2 pk;
+      pk[0] = pack2<T>(z0, z1);
+      pk[1] = pack2<T>(z2, z3);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(ln_out) + (long long)m * FF_D + ln * 4) = pk;
     }
   }
+  FF_STAMP(5);
 }
 
 // x, out [M, 256] fp32 contiguous rows; W1 [FF, 256], W2 [256, FF] 16-bit row-major (nn.Linear layout); fp32 biases.
@@ -290,7 +361,7 @@ extern "C" int sfm_ffn_fused_ln(const float* x, const float* lnw, const float* l
   if ((ln2w || ln2b || ln_out) && !(ln2w && ln2b && ln_out)) return SFM_ERR_ARG;
   if (D != FF_D || FF <= 0 || FF % FF_CH != 0 || FF > 2048 || M <= 0) return SFM_ERR_SHAPE;
   const int lds_ring = 2 * (FF_CH * 512 + FF_D * 128) + FF_BM * 128 + FF * 4;
-  const int lds_img = 8 * 64 * 68 * 4 + 128 * 4 * 4;       // images + the row-statistics exchange of the fused LayerNorm
+  const int lds_img = 128 * 260 * 4;                        // the fp32 image of the epilogue
   const int lds = lds_ring > lds_img ? lds_ring : lds_img;
   const int wbytes = FF * FF_D * 2;
   dim3 grid((M + FF_BM - 1) / FF_BM), block(512);
