@@ -49,8 +49,8 @@ __device__ __forceinline__ float gelu_as(float z) {    // z Phi(z), erf by A&S 7
 // as staging the patch and the MFMA loop together.  gemm16_epilogue_strips itself is not used here: it carries every
 // activation / residual / dropout mode of sfm_gemm16 inline, and two instances of it made instruction fetch the bound.)
 template <class T>
-__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], unsigned char* img, int lane, int b,
-                                               int colb, int row_base) {
+__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], unsigned char* img, const float* bias_s,
+                                               int lane, int b, int colb, int row_base) {
   constexpr int ROWB = 144;                            // image row: 64 x 16-bit + 16 bytes of padding (fp32 mode: two passes)
   const int l31 = lane & 31, hl = lane >> 5;
   const long long obase = (long long)b * g.o_batch_stride;
@@ -61,8 +61,7 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int n0 = colb + j * 32 + 8 * gq + 4 * hl;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n0);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n0);     // LDS copy made at kernel start (zeros without a bias)
       float s_ = 0.f, q_ = 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -81,44 +80,26 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
       pq[j][gq] = q_;
     }
   if (g.gn_partial) {
-    // lanes = rows (and the two channel halves of a quad pair): wave-wide sums; groups wider than 8 channels fold quad pairs
+    // lanes = rows (and the two channel halves of a quad pair): the 16 per-lane sums (8 chunks of 8 channels x {sum, sum of
+    // squares}) go through ONE transposing reduction; lane v < 16 then holds the tile total of (stat = v >> 3, j = (v >> 2) & 1,
+    // gq = v & 3).  Groups wider than 8 channels add the neighbouring lanes' chunks (gq pairs: xor 1, quads: xor 2).
     const int cpg = g.gn_group >> 3;                   // 8-channel chunks per group: 1, 2 or 4
     const int ngroups = g.N / g.gn_group;
+    float v16[16];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        float s_ = wave_sum_dpp(ps[j][gq]), q_ = wave_sum_dpp(pq[j][gq]);
-        ps[j][gq] = s_;
-        pq[j][gq] = q_;
+        v16[j * 4 + gq] = ps[j][gq];
+        v16[8 + j * 4 + gq] = pq[j][gq];
       }
-    if (cpg >= 2) {                                    // 16-channel groups: fold neighbouring chunks (static indices: no scratch)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; gq += 2) {
-          ps[j][gq] += ps[j][gq + 1];
-          pq[j][gq] += pq[j][gq + 1];
-        }
-    }
-    if (cpg == 4) {                                    // 32-channel groups
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        ps[j][0] += ps[j][2];
-        pq[j][0] += pq[j][2];
-      }
-    }
-    if (lane == 0 && (row_base >> 6) < g.gn_slots) {
-      const long long sl0 = ((long long)b * g.gn_slots + (row_base >> 6)) * ngroups;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          if ((gq % cpg) == 0) {                       // the chunk that now carries its group's sums
-            const long long sl = sl0 + (colb + j * 32 + 8 * gq) / g.gn_group;
-            g.gn_partial[sl * 2 + 0] = ps[j][gq];
-            g.gn_partial[sl * 2 + 1] = pq[j][gq];
-          }
+    float tot = wave_sum16_transpose(v16, lane);
+    if (cpg >= 2) tot += dpp_perm<0xB1>(tot);
+    if (cpg == 4) tot += dpp_perm<0x4E>(tot);
+    const int gq_ = lane & 3, j_ = (lane >> 2) & 1, stat = (lane >> 3) & 1;
+    if (lane < 16 && (gq_ & (cpg - 1)) == 0 && (row_base >> 6) < g.gn_slots) {
+      const long long sl = ((long long)b * g.gn_slots + (row_base >> 6)) * ngroups + (colb + j_ * 32 + 8 * gq_) / g.gn_group;
+      g.gn_partial[sl * 2 + stat] = tot;
     }
   }
   // ---- store: 16-bit through one LDS image; fp32 (the latent heads' consumers) as two 32-row halves through the same image ----
@@ -194,12 +175,17 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
   static_assert(PATCH + 2 * WT >= 4 * 9216, "epilogue images fit in the patch + ring area");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ring = smem + PATCH;                  // 2 weight tiles; TWO_IN: also the landing area of the second raw input
+  constexpr int RING = (TWO_IN && PATCH > 2 * WT) ? PATCH : 2 * WT;
+  float* bias_s = reinterpret_cast<float*>(smem + PATCH + RING);     // [256 main | 128 skip]: a global load in the epilogue
+                                                                     // would put a memory round trip in front of the statistics
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hl = lane >> 5;
 
+  for (int i = tid; i < NPASS * 128; i += 256) bias_s[i] = p.g.bias ? p.g.bias[i] : 0.f;
+  if (SKIP && tid < 128) bias_s[256 + tid] = p.gs.bias ? p.gs.bias[tid] : 0.f;
   int id = blockIdx.x;                                 // XCD-aware order: neighbouring tiles (shared halo rows) on one XCD
   {
     const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
@@ -387,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
   SFM_STAMP(2);
   unsigned char* img = smem + wave * 9216;             // 64 x 144 B per wave, in the (now free) patch + ring area
 #pragma unroll
-  for (int n = 0; n < NPASS; ++n) convp_epilogue<T>(p.g, acc[n], img, lane, b, n * 128 + wn * 64, l0 + wm * 64);
-  if (SKIP) convp_epilogue<T>(p.gs, accs, img, lane, b, wn * 64, l0 + wm * 64);
+  for (int n = 0; n < NPASS; ++n) convp_epilogue<T>(p.g, acc[n], img, bias_s, lane, b, n * 128 + wn * 64, l0 + wm * 64);
+  if (SKIP) convp_epilogue<T>(p.gs, accs, img, bias_s + 256, lane, b, wn * 64, l0 + wm * 64);
   SFM_STAMP(3);
 }
 
@@ -398,7 +384,7 @@ static int launch_convp(const ConvPParams& p, hipStream_t stream) {
   constexpr int PLANES = (STRIDE == 2 && KS > 1) ? 2 : 1;
   constexpr int PR = (((STRIDE == 2) ? (R + 1) / 2 : R) + 7) / 8 * 8;
   constexpr int patch = PLANES * PR * 128;
-  constexpr int lds = patch + ((TWO_IN && patch > 2 * 128 * 128) ? patch : 2 * 128 * 128);
+  constexpr int lds = patch + ((TWO_IN && patch > 2 * 128 * 128) ? patch : 2 * 128 * 128) + 384 * 4;   // + the bias copy
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv16p_kernel<T, KS, STRIDE, NPASS, SKIP, TWO_IN>,

@@ -667,17 +667,14 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   p.vec_ok = (o_al && r_al) ? 1 : 0;
   const bool bn128 = (Npad % 128 == 0);
   const int BNv = bn128 ? 128 : 64;
-  // 256-row tiles, 8 or 16 waves (variant 9); auto picks the 256 x 256 form when the columns allow it and there are at
-  // least two tiles per CU: +15..37 % on those shapes, the 256 x 128 form (one 8-wave workgroup per CU) is slower than
-  // the default (tools/gemm_bench.py)
+  // 256-row tiles on 8 or 16 waves (variant 9) and 512 x 128 tiles on 16 waves (variant 10) stay selectable, but auto no longer
+  // picks them for the inference GEMMs: since the PerceptionAgent convs left for conv16p the shapes that remain are K = 256 /
+  // 1024 linears, and there the 128 x 128 kernel wins on every one (tools/gemm_bench.py, round 2: M 51264, K 256, N 768:
+  // 49 us against 75 us wide, 108 us wide inside the pass; bench c2 8.00 -> 7.83 ms per step).  The fused-Swish epilogues of the
+  // training step still run best on the wide tiles (52.3 ms per step against 55.4 ms on the persistent 128 x 128 kernel).
   const long long tiles256 = (long long)((Lout + 255) / 256) * (Npad / 256) * B;
-  // (the fused-Swish epilogues also run best on the wide tiles: 52.3 ms per training step against 55.4 ms on the persistent
-  // 128 x 128 kernel, A/B/A/B in one call)
-  const bool auto_wide = (variant == 0) && (Npad % 256 == 0) && tiles256 >= 512;
-  // 512 x 128 tiles on 16 waves (variant 10; 9.8 B of operand stream per kFLOP): auto for the 128-column GEMMs with a short
-  // K (the first PerceptionAgent convs: +11..25 %; with 14 k-tiles the default kernel is already at 700 TF/s and wins)
-  const long long tiles512 = (long long)((Lout + 511) / 512) * B;
-  const bool auto_tall = (variant == 0) && Npad == 128 && Kpad <= 512 && tiles512 >= 512;
+  const bool auto_wide = (variant == 0) && swish && (Npad % 256 == 0) && tiles256 >= 512;
+  const bool auto_tall = false;
   const bool tall = ((variant == 10) && bn128) || auto_tall;
   const bool wide = ((variant == 9) && bn128) || auto_wide;
   const bool wide256 = wide && (Npad % 256 == 0);

@@ -141,6 +141,36 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// Sixteen wave-wide sums at once: lane l returns the sum over all 64 lanes of v[l & 15].  A transposing butterfly: at each
+// of the four in-row stages a lane keeps half of its values and hands the other half to a partner lane that keeps those, so
+// the work halves per stage (8 + 4 + 2 + 1 DPP adds instead of 16 x 4).  gfx9 DPP has no xor-4 / xor-8 lane permutation; the
+// mirrors (xor 15, xor 7) do, provided they come FIRST - a partner must agree with the lane on every bit already used for
+// selecting (row_mirror flips bits 3..0: used when none is; row_half_mirror flips 2..0: after bit 3 only; then xor 2, xor 1).
+// The four 16-lane rows are then added by the gfx950 lane swaps.  ~55 VALU instructions against ~190 for 16 wave_sum_dpp.
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum16_transpose(const float (&v)[16], int lane) {
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+  float w[8], x[4], y[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (b3 ? v[i + 8] : v[i]) + dpp_perm<0x140>(b3 ? v[i] : v[i + 8]);      // row_mirror
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = (b2 ? w[i + 4] : w[i]) + dpp_perm<0x141>(b2 ? w[i] : w[i + 4]);      // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y[i] = (b1 ? x[i + 2] : x[i]) + dpp_perm<0x4E>(b1 ? x[i] : x[i + 2]);       // quad_perm [2,3,0,1]
+  float z = (b0 ? y[1] : y[0]) + dpp_perm<0xB1>(b0 ? y[0] : y[1]);                                         // quad_perm [1,0,3,2]
+  // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane{16,32}_swap into one register when both
+  //  inputs are the same value; s_nop 1 = the VALU-write -> permlane-swap hazard the compiler would have covered)
+  float a = z, c = z;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));     // a: rows (0,0,2,2), c: rows (1,1,3,3)
+  z = a + c;
+  a = z, c = z;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));     // a: halves (lo,lo), c: (hi,hi)
+  return a + c;
+}
+
 // hipGetLastError() is sticky on ROCm 7 (it reports the last *error* of any earlier runtime call
 // in this thread, e.g. a benign hipErrorNotReady from an event query made by the caller's
 // framework), so the state is cleared right before the launch and read right after it.
