@@ -154,10 +154,10 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
 
 #ifdef SFM_CONVP_STAMPS
 // diagnostic build only: s_memtime stamps per workgroup (start, patch staged, k-loop done, end) -> sfm_conv16p_read_stamps
-__device__ unsigned long long sfm_convp_stamps[4 * 32768];
-#define SFM_STAMP(i) do { if (tid == 0 && blockIdx.x < 32768) sfm_convp_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long sfm_convp_stamps[8 * 32768];
+#define SFM_STAMP(i) do { if (tid == 0 && blockIdx.x < 32768) sfm_convp_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int sfm_conv16p_read_stamps(void* host, int nblocks) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(sfm_convp_stamps), (size_t)nblocks * 32, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(sfm_convp_stamps), (size_t)nblocks * 64, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 #else
 #define SFM_STAMP(i) do { } while (0)
@@ -297,8 +297,10 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
         for (int e = 0; e < 4; ++e) { a2[e] = t0[e]; a2[4 + e] = t1[e]; d1[e] += g0[e]; d1[4 + e] += g1[e]; }
       }
     }
+    if (slab == 0) SFM_STAMP(4);
     wait_vmcnt<0>();                                   // this wave's pieces have landed ...
     __syncthreads();                                   // ... everyone's have
+    if (slab == 0) SFM_STAMP(5);
 #pragma unroll 2
     for (int lr = srow; lr < LROWS; lr += 32) {
       if (row_pos(lr) < 0) continue;                   // zero-filled row: stays the conv's zero padding

@@ -137,9 +137,11 @@ def test_training_backward_directional_derivative_at_full_size():
     assert abs(slope - gnorm) < 0.05 * gnorm, (slope, gnorm)
 
 
-def test_path_backward_directional_derivative_at_full_size():
-    """the same check for the whole composition (PerceptionAgent + CPEA + MaskSynthesisAgent) at B 64 x 4 s, cotangent on
-    the enhanced spectrum"""
+@pytest.mark.parametrize("Bp", [64, 256])
+def test_path_backward_directional_derivative_at_full_size(Bp):
+    """the same check for the whole composition (PerceptionAgent + CPEA + MaskSynthesisAgent), cotangent on the enhanced
+    spectrum: at B 64 x 4 s (BASELINE configs[1], bench workload c2t) and at B 256 x 4 s (configs[2] on the north-star
+    composition, bench workload c3t), in the operand formats the bench runs"""
     from sincformer_metacog_speech_enhancement_amd import ops
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
     ops.reset_precision()                 # the bench's operand formats (default policy "mixed": ops.POLICIES)
@@ -154,12 +156,12 @@ def test_path_backward_directional_derivative_at_full_size():
             mod.dropout = 0.0
     path.cpea.lstm.dropout = 0.0
     path = path.cuda().train()
-    noisy, _ = syn.synth_wave(B, L, 778)
+    noisy, _ = syn.synth_wave(Bp, L, 778)
     wave = torch.from_numpy(noisy).cuda()
     T = 1 + L // 80
     g = torch.Generator(device="cuda").manual_seed(6)
-    cot_r = torch.randn(B, T, 129, device="cuda", generator=g) * 1e-3
-    cot_i = torch.randn(B, T, 129, device="cuda", generator=g) * 1e-3
+    cot_r = torch.randn(Bp, T, 129, device="cuda", generator=g) * 1e-3
+    cot_i = torch.randn(Bp, T, 129, device="cuda", generator=g) * 1e-3
 
     def objective():
         out = path(wave, want=("mask", "spectrum"))
@@ -167,7 +169,7 @@ def test_path_backward_directional_derivative_at_full_size():
 
     params = [p_ for n, p_ in path.named_parameters() if "uncertainty_head" not in n]
     val, gnorm, slope = _central_difference_along_gradient(params, objective, eps=0.01)
-    print("full-size path backward: f %.5f, |g| %.4f, central-difference slope along g %.4f" % (val, gnorm, slope))
+    print("full-size path backward (B %d): f %.5f, |g| %.4f, central-difference slope along g %.4f" % (Bp, val, gnorm, slope))
     assert abs(slope - gnorm) < 0.05 * gnorm, (slope, gnorm)
 
 

@@ -113,7 +113,10 @@ def test_perception_agent_vs_golden(pkg, prec, tag, scale):
     noisy, _ = syn.synth_wave(2, 1600, 22)
     zr, zi, sg = pa(torch.from_numpy(noisy).cuda())
     assert zr.shape == (2, 256, 100) and sg.shape == (2, 1, 100)
-    tol = 4e-2 if prec != "fp16" else 6e-3          # relative RMSE after 11 conv layers of 16-bit operands
+    # relative RMSE after 11 conv layers of 16-bit operands.  Measured (round 2): fp16 operands - which is what the default
+    # "mixed" policy gives the PerceptionAgent - 1.2e-3 .. 1.5e-3 (sigma 3e-4); bf16 operands 0.95e-2 .. 1.2e-2.  Bounds = 2 x
+    # / 1.7 x that: a defect in one of the 11 layers moves the figure by far more.
+    tol = 2e-2 if prec == "bf16" else 3e-3
     for n, a, b in (("z_real", zr, g["z_real"]), ("z_imag", zi, g["z_imag"]), ("sigma", sg, g["sigma"])):
         _, rl = show("PA %s %s %s" % (tag, prec, n), a, b)
         assert rl < tol
@@ -129,7 +132,7 @@ def test_complex_conformer_small_vs_golden(pkg, prec):
     sr, si = arr("g4_sr", (2, 20, 32), 42).cuda(), arr("g4_si", (2, 20, 32), 42).cuda()
     mr, mi = cc(sr, si)
     assert mr.shape == (2, 20, 32) and mi.shape == (2, 20, 32)
-    tol = 3e-2 if prec != "fp16" else 4e-3
+    tol = 8e-3 if prec == "bf16" else 1.5e-3         # measured 3.8e-3 (bf16) / 4.8e-4 (fp16 and the default policy)
     assert show("cconf small %s mask_real" % prec, mr, g["mask_real"])[1] < tol
     assert show("cconf small %s mask_imag" % prec, mi, g["mask_imag"])[1] < tol
     er, ei = cc.apply_mask(sr, si, mr, mi)

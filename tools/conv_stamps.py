@@ -31,10 +31,12 @@ for name, cin, cout, k, s, p, two, skip, L in [("b0.c1+cs", 64, 128, 7, 2, 3, Fa
                     skip_pw=spw, out_s=outs, gn_partial_s=parts)
     torch.cuda.synchronize()
     n = min(32768, B * ((Lout + 127) // 128))
-    buf = np.zeros((n, 4), dtype=np.uint64)
+    buf = np.zeros((n, 8), dtype=np.uint64)
     assert rd(buf.ctypes.data_as(ctypes.c_void_p), n) == 0
     st = buf.astype(np.float64)
-    d = np.diff(st, axis=1)
+    d = np.diff(st[:, :4], axis=1)
     tot = st[:, 3] - st[:, 0]
+    fine = {"dma_issue+scale_loads": float(np.median(st[:, 4] - st[:, 0])), "raw_rows_wait": float(np.median(st[:, 5] - st[:, 4])),
+            "transform": float(np.median(st[:, 1] - st[:, 5]))}
     print(json.dumps({"layer": name, "cycles_p50": {"stage_first_slab": float(np.median(d[:, 0])), "rest_slabs+k_loop": float(np.median(d[:, 1])),
-                                                   "epilogue": float(np.median(d[:, 2])), "total": float(np.median(tot))}}))
+                                                   "epilogue": float(np.median(d[:, 2])), "total": float(np.median(tot))}, "stage_first_slab": fine}))
