@@ -36,7 +36,31 @@ for name, cin, cout, k, s, p, two, skip, L in [("b0.c1+cs", 64, 128, 7, 2, 3, Fa
     st = buf.astype(np.float64)
     d = np.diff(st[:, :4], axis=1)
     tot = st[:, 3] - st[:, 0]
+    # co-residency: workgroups by CU (XCC_ID, SE/SH/CU of HW_ID); for every workgroup, what its CU neighbour was doing while it
+    # was in its k-loop (stamps 1..2): fraction of that interval the OTHER workgroup on the CU spent in ITS k-loop
+    hw = buf[:, 6]
+    cu = ((hw >> 32) & 0xf) * 4096 + ((hw >> 8) & 0xff)           # xcc | se, sh, cu bits of HW_ID
+    tg = (hw >> 16) & 0xf
+    order = np.argsort(cu, kind="stable")
+    ov = []
+    by = {}
+    for i in order:
+        by.setdefault(int(cu[i]), []).append(i)
+    for k, ids in by.items():
+        ids = sorted(ids, key=lambda i: st[i, 0])
+        for a_ in range(len(ids)):
+            i = ids[a_]
+            lo, hi = st[i, 1], st[i, 2]
+            o = 0.0
+            for b_ in range(max(0, a_ - 3), min(len(ids), a_ + 4)):
+                if b_ == a_:
+                    continue
+                j = ids[b_]
+                o += max(0.0, min(hi, st[j, 2]) - max(lo, st[j, 1]))
+            ov.append(o / max(hi - lo, 1.0))
+    coloc = {"cus": len(by), "workgroups_per_cu_p50": float(np.median([len(v) for v in by.values()])), "tg_ids": sorted(set(int(x) for x in tg))[:8],
+             "kloop_overlap_with_neighbour_kloop_p50": float(np.median(ov)), "mean": float(np.mean(ov))}
     fine = {"dma_issue+scale_loads": float(np.median(st[:, 4] - st[:, 0])), "raw_rows_wait": float(np.median(st[:, 5] - st[:, 4])),
             "transform": float(np.median(st[:, 1] - st[:, 5]))}
     print(json.dumps({"layer": name, "cycles_p50": {"stage_first_slab": float(np.median(d[:, 0])), "rest_slabs+k_loop": float(np.median(d[:, 1])),
-                                                   "epilogue": float(np.median(d[:, 2])), "total": float(np.median(tot))}, "stage_first_slab": fine}))
+                                                   "epilogue": float(np.median(d[:, 2])), "total": float(np.median(tot))}, "stage_first_slab": fine, "co_residency": coloc}))
