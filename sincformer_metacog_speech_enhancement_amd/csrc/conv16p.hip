@@ -348,6 +348,11 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
   };
 
   SFM_STAMP(0);
+#ifdef SFM_CONVP_STAMPS
+  if (tid == 0 && blockIdx.x < 32768)                  // which CU / thread-group slot this workgroup ran on (HW_ID, XCC_ID)
+    sfm_convp_stamps[blockIdx.x * 8 + 6] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+                                           ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+#endif
   if (!TWO_IN) issue_w(0);
   for (int slab = 0; slab < nslab; ++slab) {
     if (slab > 0) __syncthreads();                     // every wave is done reading the previous slab's patch (and weight tiles)
