@@ -33,6 +33,9 @@ template <int N>
 __device__ __forceinline__ void ff_frag_wait(u32x4& frag) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
 }
+__device__ __forceinline__ float ff_lane_bcast(float v, int r) {       // lane r's value in every lane (r static: v_readlane)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r));
+}
 __device__ __forceinline__ void ff_barrier() {
   // LDS writes of this wave must have completed before other waves pass the barrier; the LDS-DMA
   // queue (vmcnt) is deliberately NOT drained here - that is what the counted waits are for.
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
       xv[r] = *reinterpret_cast<const f32x4*>(x + (long long)m * FF_D + lane * 4);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wave * 16 + r;
-      const f32x4 v = xv[r];
+    for (int r = 0; r < 16; ++r) {                           // row by row as the loads return (the phase is load-latency bound:
+      const int row = wave * 16 + r;                         // one transposing reduction over all 16 rows was slower here,
+      const f32x4 v = xv[r];                                 // it cannot start before the last row has arrived)
       const float mean = wave_sum_dpp(v[0] + v[1] + v[2] + v[3]) * (1.0f / FF_D);
       const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
       const float rstd = rsqrtf(wave_sum_dpp(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / FF_D) + eps);
@@ -320,29 +323,46 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
     g2 = *reinterpret_cast<const f32x4*>(ln2w + ln * 4);
     h2 = *reinterpret_cast<const f32x4*>(ln2b + ln * 4);
   }
+  f32x4 yv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wave * 16 + r;
     const int m = m0 + row;
     const f32x4 a = *reinterpret_cast<const f32x4*>(&img[row * IW + ln * 4]);
-    f32x4 y;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = xv[r][e] + alpha * (a[e] + bb[e]);
-    if (out && m < M) *reinterpret_cast<f32x4*>(out + (long long)m * FF_D + ln * 4) = y;
-    if (ln2w == nullptr) continue;                         // block-uniform
-    const float mean = wave_sum_dpp(y[0] + y[1] + y[2] + y[3]) * (1.0f / FF_D);
-    const float d0 = y[0] - mean, d1 = y[1] - mean, d2 = y[2] - mean, d3 = y[3] - mean;
-    const float rstd = rsqrtf(wave_sum_dpp(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / FF_D) + eps);
-    const float z0 = d0 * rstd * g2[0] + h2[0], z1 = d1 * rstd * g2[1] + h2[1];
-    const float z2 = d2 * rstd * g2[2] + h2[2], z3 = d3 * rstd * g2[3] + h2[3];
-    if (m >= M) continue;
-    if (ln_out_f32) {
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ln_out) + (long long)m * FF_D + ln * 4) = f32x4{z0, z1, z2, z3};
-    } else {
-      u32x2 pk;
-      pk[0] = pack2<T>(z0, z1);
-      pk[1] = pack2<T>(z2, z3);
-      *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(ln_out) + (long long)m * FF_D + ln * 4) = pk;
+    for (int e = 0; e < 4; ++e) yv[r][e] = xv[r][e] + alpha * (a[e] + bb[e]);
+    if (out && m < M) *reinterpret_cast<f32x4*>(out + (long long)m * FF_D + ln * 4) = yv[r];
+  }
+  if (ln2w != nullptr) {                                   // block-uniform
+    // the 16 row means, then the 16 centred variances, each by ONE transposing reduction (lane l gets the sum of row l & 15;
+    // v_readlane hands row r's value back to every lane): ~150 instructions where 32 wave_sum_dpp chains took ~450
+    float st[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = (yv[r][0] + yv[r][1]) + (yv[r][2] + yv[r][3]);
+    const float mean_l = wave_sum16_transpose(st, lane) * (1.0f / FF_D);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float mean = ff_lane_bcast(mean_l, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) yv[r][e] -= mean;
+      st[r] = (yv[r][0] * yv[r][0] + yv[r][1] * yv[r][1]) + (yv[r][2] * yv[r][2] + yv[r][3] * yv[r][3]);
+    }
+    const float rstd_l = rsqrtf(wave_sum16_transpose(st, lane) * (1.0f / FF_D) + eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 16 + r;
+      if (m >= M) break;                                   // wave-uniform
+      const float rstd = ff_lane_bcast(rstd_l, r);
+      const float z0 = yv[r][0] * rstd * g2[0] + h2[0], z1 = yv[r][1] * rstd * g2[1] + h2[1];
+      const float z2 = yv[r][2] * rstd * g2[2] + h2[2], z3 = yv[r][3] * rstd * g2[3] + h2[3];
+      if (ln_out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ln_out) + (long long)m * FF_D + ln * 4) = f32x4{z0, z1, z2, z3};
+      } else {
+        u32x2 pk;
+        pk[0] = pack2<T>(z0, z1);
+        pk[1] = pack2<T>(z2, z3);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<u16*>(ln_out) + (long long)m * FF_D + ln * 4) = pk;
+      }
     }
   }
   FF_STAMP(5);
