@@ -59,9 +59,16 @@ class FlatGradSynchronizer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self.overlap = overlap and self.world > 1
-        if self.overlap:
-            for p in self.params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+        # which parameters autograd accumulated into since zero(): a parameter off the loss's graph keeps its (zero) flat
+        # gradient view but must not be stepped - torch.optim skips `p.grad is None` (optim.FlatAdamW.step)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._touched = [False] * len(self.params)
+        self._spans, off = [], 0
+        for p in self.params:
+            self._spans.append((off, p.numel()))
+            off += p.numel()
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
 
     # -- overlap machinery ---------------------------------------------------------------------------------------
     def _launch(self, b):
@@ -70,13 +77,24 @@ class FlatGradSynchronizer:
         self._works.append(dist.all_reduce(self.buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
+        self._touched[self._index[id(p)]] = True
+        if not self.overlap:
+            return
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0 and b != 0:       # bucket 0 carries the flag: launched by finish()
             self._launch(b)
 
+    def untouched(self):
+        """(offset, numel) in the flat buffers of every parameter that received no gradient since zero().  When autograd
+        accumulated into none of them the gradients were written into the flat views by hand: nothing is idle then."""
+        if not any(self._touched):
+            return []
+        return [sp for sp, t in zip(self._spans, self._touched) if not t]
+
     def zero(self):
         self.buf.zero_()
+        self._touched = [False] * len(self.params)
         self._pending = list(self._members)
         self._launched = [False] * len(self.buckets)
         self._works = []

@@ -295,6 +295,31 @@ def test_flat_adamw_matches_torch_adamw_with_clip_and_skip():
     assert all(torch.equal(x, y.detach()) for x, y in zip(before, b.parameters()))
 
 
+def test_flat_adamw_leaves_parameters_without_a_gradient_alone():
+    """torch.optim.AdamW skips a parameter whose grad is None (no weight decay, no update); the flat optimiser, whose
+    gradient views always exist, must do the same for parameters the backward pass never reached."""
+    from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    used, idle = torch.nn.Linear(16, 16).cuda(), torch.nn.Linear(16, 4).cuda()
+    ref_used = torch.nn.Linear(16, 16).cuda()
+    ref_used.load_state_dict(used.state_dict())
+    idle0 = {k: v.clone() for k, v in idle.state_dict().items()}
+    opt = FlatAdamW(list(used.parameters()) + list(idle.parameters()), lr=1e-2, betas=(0.9, 0.98), weight_decay=0.1, max_norm=0.0)
+    ref = torch.optim.AdamW(ref_used.parameters(), lr=1e-2, betas=(0.9, 0.98), weight_decay=0.1)
+    x = torch.randn(8, 16, device="cuda")
+    for _ in range(3):
+        opt.zero_grad()
+        ref.zero_grad()
+        used(x).pow(2).sum().backward()
+        ref_used(x).pow(2).sum().backward()
+        opt.step()
+        ref.step()
+    for k, v in idle.state_dict().items():
+        assert torch.equal(v, idle0[k]), k                     # bitwise untouched: no decay either
+    for a, b in zip(used.parameters(), ref_used.parameters()):
+        assert maxerr(a.detach().cpu(), b.detach().cpu()) < 1e-5
+
+
 def test_speech_enhancer_learns_with_flat_adamw():
     """whole training step on the HIP path: STFT -> SpeechEnhancer(train) -> objective -> backward -> clip -> AdamW."""
     from sincformer_metacog_speech_enhancement_amd import ops
