@@ -162,6 +162,10 @@ int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, i
  * output (glue G1 applied to agents/perception.py:244-246 without materialising the full-rate normalised tensor) */
 int sfm_pool_time_affine(const float* src, const float* scale, const float* shift, void* dst16, float* dst32, int B,
                          int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype, void* stream);
+/* sfm_pool_time_affine on a 16-bit source [B, Tin, ld_src] in the format `src_dtype` (the fused path writes the raw latent
+ * heads in the PerceptionAgent stage's operand format: agents/perception.py:244-246 + glue G1); dst16 in the format `dtype` */
+int sfm_pool_time_affine16(const void* src16, int src_dtype, const float* scale, const float* shift, void* dst16, float* dst32,
+                           int B, int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype, void* stream);
 /* mean over time (glue G2: episodic-memory key), src fp32 [B, T, ld_src] cols [0, C) -> dst fp32 [B, C]; deterministic
  * two-pass sum, scratch: sfm_mean_time_scratch_floats floats */
 long long sfm_mean_time_scratch_floats(int B, int T, int C);

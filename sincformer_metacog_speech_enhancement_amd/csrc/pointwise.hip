@@ -476,8 +476,8 @@ extern "C" int sfm_transpose(const void* src, void* dst, int B, int R, int C, lo
 
 // adaptive average pool along time (glue G1): src fp32 [B, Tin, ld_src] cols [0,C)
 // -> dst 16-bit [B, Tout, ld_dst] cols [0, C).  window i = [floor(i*Tin/Tout), ceil((i+1)*Tin/Tout))
-template <class T>
-__global__ __launch_bounds__(256) void pool_time_kernel(const float* __restrict__ src, u16* dst16, float* dst32,
+template <class T, int SRC>                            // SRC: 0 fp32, 1 fp16, 2 bf16 source
+__global__ __launch_bounds__(256) void pool_time_kernel(const void* __restrict__ src_, u16* dst16, float* dst32,
                                                         int Tin, int Tout, int C, long long ld_src, long long ld_dst,
                                                         const float* __restrict__ scale, const float* __restrict__ shift) {
   const int b = blockIdx.z, i = blockIdx.y;
@@ -486,12 +486,97 @@ __global__ __launch_bounds__(256) void pool_time_kernel(const float* __restrict_
   long long s = ((long long)i * Tin) / Tout;
   long long e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
   float acc = 0.f;
-  for (long long t = s; t < e; ++t) acc += src[((long long)b * Tin + t) * ld_src + c];
+  for (long long t = s; t < e; ++t) {
+    const long long o = ((long long)b * Tin + t) * ld_src + c;
+    if (SRC == 0) acc += reinterpret_cast<const float*>(src_)[o];
+    else if (SRC == 1) acc += F16::to_f32(reinterpret_cast<const u16*>(src_)[o]);
+    else acc += BF16::to_f32(reinterpret_cast<const u16*>(src_)[o]);
+  }
   acc /= (float)(e - s);
   if (scale) acc = acc * scale[(long long)b * C + c] + shift[(long long)b * C + c];   // affine commutes with the average
   long long o = ((long long)b * Tout + i) * ld_dst + c;
   if (dst16) dst16[o] = T::from_f32(acc);
   if (dst32) dst32[o] = acc;
+}
+
+// 8 channels per thread (16-byte loads of a 16-bit source, 2 x 16 bytes of an fp32 one): a 256-thread workgroup covers (256 / (C / 8)) output frames of one utterance; needs C % 8 == 0, C / 8 a divisor of 256 and
+// 16-byte aligned rows.  The scalar kernel above moved 2 or 4 bytes per lane and was bound by its load count, not by HBM.
+template <class T, int SRC>
+__global__ __launch_bounds__(256) void pool_time_vec_kernel(const void* __restrict__ src_, u16* dst16, float* dst32, int Tin, int Tout,
+                                                            int C, long long ld_src, long long ld_dst,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift) {
+  const int tpf = C >> 3;                                  // threads per output frame
+  const int fpb = 256 / tpf;                               // output frames per workgroup
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * fpb + threadIdx.x / tpf;
+  const int c = (threadIdx.x % tpf) * 8;
+  if (i >= Tout) return;
+  const long long s = ((long long)i * Tin) / Tout;
+  const long long e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long t = s; t < e; ++t) {
+    const long long o = ((long long)b * Tin + t) * ld_src + c;
+    if (SRC == 0) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
+    } else {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(src_) + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u16 lo = (u16)(a[j] & 0xffffu), hi = (u16)(a[j] >> 16);
+        acc[2 * j] += SRC == 1 ? F16::to_f32(lo) : BF16::to_f32(lo);
+        acc[2 * j + 1] += SRC == 1 ? F16::to_f32(hi) : BF16::to_f32(hi);
+      }
+    }
+  }
+  const float inv = 1.0f / (float)(e - s);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] *= inv;
+    if (scale) acc[j] = acc[j] * scale[(long long)b * C + c + j] + shift[(long long)b * C + c + j];   // affine commutes with the average
+  }
+  const long long o = ((long long)b * Tout + i) * ld_dst + c;
+  if (dst16) {
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack2<T>(acc[2 * j], acc[2 * j + 1]);
+    *reinterpret_cast<u32x4*>(dst16 + o) = w;
+  }
+  if (dst32) {
+    *reinterpret_cast<f32x4*>(dst32 + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(dst32 + o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
+static int pool_time_go(const void* src, int srcfmt, const float* scale, const float* shift, void* dst16, float* dst32, int B,
+                        int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype, void* stream) {
+  if (!src || (!dst16 && !dst32) || ((scale == nullptr) != (shift == nullptr))) return SFM_ERR_ARG;
+  if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int esz = srcfmt == 0 ? 4 : 2;
+  const bool vec = (C % 8 == 0) && C <= 2048 && (256 % (C / 8) == 0) && ((ld_src * esz) % 16 == 0) && (((uintptr_t)src) % 16 == 0) &&
+                   (!dst16 || ((ld_dst * 2) % 16 == 0 && ((uintptr_t)dst16) % 16 == 0)) &&
+                   (!dst32 || ((ld_dst * 4) % 16 == 0 && ((uintptr_t)dst32) % 16 == 0));
+  if (vec) {
+    const int fpb = 256 / (C / 8);
+    dim3 grid((Tout + fpb - 1) / fpb, B), block(256);
+#define POOL_GO(TT, S) SFM_LAUNCH((pool_time_vec_kernel<TT, S>), grid, block, 0, st, src, (u16*)dst16, dst32, Tin, Tout, C, ld_src, ld_dst, scale, shift)
+#define POOL_SRC(TT) { if (srcfmt == 0) POOL_GO(TT, 0); else if (srcfmt == 1) POOL_GO(TT, 1); else POOL_GO(TT, 2); }
+    if (dtype == SFM_DT_F16) POOL_SRC(F16) else POOL_SRC(BF16)
+#undef POOL_SRC
+#undef POOL_GO
+    return SFM_OK;
+  }
+  dim3 grid((C + 255) / 256, Tout, B), block(256);
+#define POOL_GO(TT, S) SFM_LAUNCH((pool_time_kernel<TT, S>), grid, block, 0, st, src, (u16*)dst16, dst32, Tin, Tout, C, ld_src, ld_dst, scale, shift)
+#define POOL_SRC(TT) { if (srcfmt == 0) POOL_GO(TT, 0); else if (srcfmt == 1) POOL_GO(TT, 1); else POOL_GO(TT, 2); }
+  if (dtype == SFM_DT_F16) POOL_SRC(F16) else POOL_SRC(BF16)
+#undef POOL_SRC
+#undef POOL_GO
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
 }
 
 // sfm_pool_time_affine: out = scale[b, c] * avg(src) + shift[b, c].  Pooling the RAW output of a GroupNorm'd layer with
@@ -500,17 +585,16 @@ __global__ __launch_bounds__(256) void pool_time_kernel(const float* __restrict_
 extern "C" int sfm_pool_time_affine(const float* src, const float* scale, const float* shift, void* dst16, float* dst32,
                                     int B, int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype,
                                     void* stream) {
-  if (!src || (!dst16 && !dst32) || ((scale == nullptr) != (shift == nullptr))) return SFM_ERR_ARG;
-  if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return SFM_ERR_SHAPE;
-  dim3 grid((C + 255) / 256, Tout, B), block(256);
-  if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((pool_time_kernel<F16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin, Tout,
-                       C, ld_src, ld_dst, scale, shift);
-  else
-    SFM_LAUNCH((pool_time_kernel<BF16>), grid, block, 0, (hipStream_t)stream, src, (u16*)dst16, dst32, Tin,
-                       Tout, C, ld_src, ld_dst, scale, shift);
-  SFM_CHECK_LAUNCH();
-  return SFM_OK;
+  return pool_time_go(src, 0, scale, shift, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, dtype, stream);
+}
+// the same on a 16-bit source (the raw latent heads written in the operands' format: half the bytes of the GEMM's output and
+// of this pass; the 16-bit rounding of a raw value is below the rounding of the pooled operand it ends up in)
+extern "C" int sfm_pool_time_affine16(const void* src16, int src_dtype, const float* scale, const float* shift, void* dst16,
+                                      float* dst32, int B, int Tin, int Tout, int C, long long ld_src, long long ld_dst, int dtype,
+                                      void* stream) {
+  if (src_dtype != SFM_DT_F16 && src_dtype != SFM_DT_BF16) return SFM_ERR_ARG;
+  return pool_time_go(src16, src_dtype == SFM_DT_F16 ? 1 : 2, scale, shift, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, dtype,
+                      stream);
 }
 
 extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B, int Tin, int Tout, int C,

@@ -460,7 +460,9 @@ def _perception_forward(wave, pk, keep_sinc, latents):
     xd = torch.empty(B, Tpa, D, device=dev, dtype=dt)
     ops.gn_apply(rd, sd_, hd_, xd, B, Tpa, D, act=1)
     # complex latent heads: one GEMM for (real | imag), GroupNorm(16) per half = 32 groups over 2D channels
-    rz, pz, Pz, _ = _conv_gn(xd, pk["zproj"], B, Tpa, 1, 0, 32, torch.float32)
+    # (raw output fp32 when the full-rate latents are returned; otherwise in the operands' format: it is only pooled, and the
+    #  GroupNorm statistics come from the fp32 accumulators either way)
+    rz, pz, Pz, _ = _conv_gn(xd, pk["zproj"], B, Tpa, 1, 0, 32, torch.float32 if latents else dt)
     sz, hz = ops.gn_finalize(pz, pk["z_w"], pk["z_b"], B, Pz, 32, 2 * D, Tpa)
     if latents:
         zcat = torch.empty(B, Tpa, 2 * D, device=dev, dtype=torch.float32)

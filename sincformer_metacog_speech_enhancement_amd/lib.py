@@ -47,6 +47,7 @@ SIGNATURES = {
     "sfm_mean_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_vp],
     "sfm_pool_time_bwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_vp],
     "sfm_pool_time_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
+    "sfm_pool_time_affine16": [c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_stft_lognorm_pack": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_i, c_vp],
     "sfm_polar_mask": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_f, c_ll, c_ll,
                        c_vp],

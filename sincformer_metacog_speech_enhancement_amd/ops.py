@@ -247,7 +247,7 @@ def _cost_of(name, v):
             B, T, H = v["B"], v["T"], v["H"]
             return 2.0 * B * T * 2 * 4 * H * H, B * T * (8 * H + 2 * H) * 4
         if name == "pool_time":
-            return 0.0, v["B"] * (v["Tin"] + v["Tout"]) * v["C"] * 4
+            return 0.0, v["B"] * (v["Tin"] * v["src_bytes"] + v["Tout"] * 4) * v["C"]
         if name == "polar_mask":
             n = v["B"] * v["rows"] * v["F"]
             return 20.0 * n, n * 4 * 8
@@ -576,11 +576,18 @@ def pool_time_bwd(dout32, B, Tin, Tout, C):
 
 
 def pool_time(src32, dst16, dst32, B, Tin, Tout, C, ld_src, ld_dst, scale=None, shift=None):
-    """adaptive average pooling over time; scale / shift [B, C]: out = scale * avg + shift (pooled GroupNorm output)"""
+    """adaptive average pooling over time; scale / shift [B, C]: out = scale * avg + shift (pooled GroupNorm output).
+    src32: fp32, or 16-bit in the current operand format (the fused path's raw latent heads)."""
     L = _lib.load()
-    _call("pool_time", L.sfm_pool_time_affine, (_p(src32), _p(scale), _p(shift), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src,
-                                                ld_dst, _dt(), _stream()),
-          *_cost_of("pool_time", locals()))
+    src_bytes = src32.element_size()
+    if src_bytes == 4:
+        args = (_p(src32), _p(scale), _p(shift), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src, ld_dst, _dt(), _stream())
+        fn = L.sfm_pool_time_affine
+    else:
+        args = (_p(src32), _DT_ID[src32.dtype], _p(scale), _p(shift), _p(dst16), _p(dst32), B, Tin, Tout, C, ld_src, ld_dst,
+                _dt(), _stream())
+        fn = L.sfm_pool_time_affine16
+    _call("pool_time", fn, args, *_cost_of("pool_time", locals()))
 
 
 def stft_lognorm_pack(re, im, dst16, M, F, zpad, ld_dst):

@@ -470,6 +470,15 @@ def test_layout_kernels(ops):
     refp = orc.pool_latents(zz.transpose(1, 2), 21).transpose(1, 2)
     report("pool_time", p32.cpu(), refp, 1e-6)
     report("pool_time 16", p16.float().cpu(), refp, 2e-3)
+    # 16-bit source in EITHER format, whatever the destination's (a policy may run the PerceptionAgent in one format and the
+    # front-end in the other), with the per-(utterance, channel) affine of a pooled GroupNorm
+    sc, sh = arr("psc", (B, 512), 75, 0.2) + 1.0, arr("psh", (B, 512), 76, 0.2)
+    for sdt in (torch.float16, torch.bfloat16):
+        zq = zz.to(sdt)
+        q32 = torch.empty(B, 21, 512, device="cuda")
+        ops.pool_time(dev(zq), None, q32, B, 100, 21, 512, 512, 512, scale=dev(sc), shift=dev(sh))
+        refq = orc.pool_latents(zq.float().transpose(1, 2), 21).transpose(1, 2) * sc[:, None, :] + sh[:, None, :]
+        report("pool_time from %s + affine" % sdt, q32.cpu(), refq, 2e-6)
     re, im = arr("nr", (40, 129), 73, 0.5), arr("ni", (40, 129), 74, 0.5)
     pk = torch.full((40, 300), 3.0, device="cuda", dtype=torch.float16)
     ops.stft_lognorm_pack(dev(re), dev(im), pk, 40, 129, 30, 300)
