@@ -12,6 +12,10 @@
 // workgroup barrier per time step.
 #include "sfm_common.h"
 
+#ifndef SFM_LSTM_LPU
+#define SFM_LSTM_LPU 4                       // lanes per hidden unit of the forward recurrence (8 = round 1's mapping)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {          // v + v[permuted lane] (within a row of 16 lanes)
   const int x = __builtin_bit_cast(int, v);
@@ -37,15 +41,18 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 }
 
 // save (training): [B, T, 2, 5, H] fp32 = the activated gates i, f, g, o and the cell state c of every step
-template <int H>
-__global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __restrict__ xg,
-                                                             const float* __restrict__ whh,
-                                                             float* __restrict__ out, int T, float* __restrict__ save) {
-  constexpr int KS = H / 8;                                  // k-slice length per lane
-  constexpr int SL = KS + 4;                                 // slice stride in LDS: slices ks and ks+4 on different banks
-  __shared__ __attribute__((aligned(16))) float hs[2][8 * SL];
+// LPU lanes per hidden unit: thread = (unit j, k-slice ks of H / LPU).  8 lanes per unit (16 waves at H 128) is 4 waves per
+// SIMD x ~100 instructions per step = issue bound at ~1600 cycles; 4 lanes per unit (8 waves, 128 multiply-adds per lane in four
+// independent chains, one DPP stage fewer) issues ~1330 (tools/lstm_bench.py: 0.60 -> see profiles/README.md).
+template <int H, int LPU>
+__global__ __launch_bounds__(LPU * H) void bilstm_layer_kernel(const float* __restrict__ xg,
+                                                               const float* __restrict__ whh,
+                                                               float* __restrict__ out, int T, float* __restrict__ save) {
+  constexpr int KS = H / LPU;                                // k-slice length per lane
+  constexpr int SL = KS + 4;                                 // slice stride in LDS: the slices of a unit's lanes on different banks
+  __shared__ __attribute__((aligned(16))) float hs[2][LPU * SL];
   const int tid = threadIdx.x;
-  const int j = tid >> 3, ks = tid & 7;
+  const int j = tid / LPU, ks = tid % LPU;
   const int dir = blockIdx.x, b = blockIdx.y;
   float w[4][KS];
 #pragma unroll
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < KS; ++i) w[g][i] = wr[i];
   }
-  if (tid < 8 * SL) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; }
+  if (tid < LPU * SL) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; }
   __syncthreads();
   float c = 0.f;
   const int mygate = ks & 3;                                  // lanes 0-3 (and 4-7) carry gate i,f,g,o
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
     for (int g = 0; g < 4; ++g) {
       a[g] = dpp_add<DPP_XOR1>(a[g]);
       a[g] = dpp_add<DPP_XOR2>(a[g]);
-      a[g] = dpp_add<DPP_HALF_MIRROR>(a[g]);
+      if (LPU == 8) a[g] = dpp_add<DPP_HALF_MIRROR>(a[g]);
     }
     // every lane now holds the 4 complete pre-activations of its unit; lane q of each quad activates gate q
     const float pre = ((mygate == 0) ? a[0] : (mygate == 1) ? a[1] : (mygate == 2) ? a[2] : a[3]) + xcur;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_kernel(const float* __rest
     if (save) {
       float* sv = save + ((((long long)b * T + t) * 2 + dir) * 5) * H + j;
       if (ks < 4) sv[mygate * H] = act;
-      if (ks == 4) sv[4 * H] = c;
+      if (ks == LPU - 4) sv[4 * H] = c;                      // (8 lanes: lane 4; 4 lanes: lane 0)
     }
     // LDS-only barrier (__syncthreads() would also drain vmcnt: the global store of h and the x prefetch)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_bwd_kernel(const float* __
 
 template <int H>
 static int bilstm_fwd_go(const float* xg, const float* whh, float* out, float* save, int B, int T, hipStream_t st) {
-  SFM_LAUNCH((bilstm_layer_kernel<H>), dim3(2, B), dim3(8 * H), 0, st, xg, whh, out, T, save);
+  constexpr int LPU = H >= 64 ? SFM_LSTM_LPU : 8;           // H 32: 4 x H / 4 = 8-float slices, too short for the float4 reads
+  SFM_LAUNCH((bilstm_layer_kernel<H, LPU>), dim3(2, B), dim3(LPU * H), 0, st, xg, whh, out, T, save);
   return SFM_OK;
 }
 

@@ -58,7 +58,18 @@ for name, cin, cout, k, s, p, two, skip, L in [("b0.c1+cs", 64, 128, 7, 2, 3, Fa
                 j = ids[b_]
                 o += max(0.0, min(hi, st[j, 2]) - max(lo, st[j, 1]))
             ov.append(o / max(hi - lo, 1.0))
-    coloc = {"cus": len(by), "workgroups_per_cu_p50": float(np.median([len(v) for v in by.values()])), "tg_ids": sorted(set(int(x) for x in tg))[:8],
+    # turnaround of a thread-group slot: end of one workgroup -> start of the next one the dispatcher puts there
+    slot = cu * 16 + tg
+    gaps, busy = [], []
+    for k in set(int(x) for x in slot):
+        ids = [i for i in np.nonzero(slot == k)[0]]
+        ids.sort(key=lambda i: st[i, 0])
+        for a_, b_ in zip(ids[:-1], ids[1:]):
+            gaps.append(st[b_, 0] - st[a_, 3])
+        if len(ids) > 1:
+            busy.append(sum(st[i, 3] - st[i, 0] for i in ids) / max(st[ids[-1], 3] - st[ids[0], 0], 1.0))
+    coloc = {"slot_turnaround_cycles_p50": float(np.median(gaps)) if gaps else None, "slot_turnaround_cycles_p90": float(np.percentile(gaps, 90)) if gaps else None,
+             "slot_busy_fraction_p50": float(np.median(busy)) if busy else None,"cus": len(by), "workgroups_per_cu_p50": float(np.median([len(v) for v in by.values()])), "tg_ids": sorted(set(int(x) for x in tg))[:8],
              "kloop_overlap_with_neighbour_kloop_p50": float(np.median(ov)), "mean": float(np.mean(ov))}
     fine = {"dma_issue+scale_loads": float(np.median(st[:, 4] - st[:, 0])), "raw_rows_wait": float(np.median(st[:, 5] - st[:, 4])),
             "transform": float(np.median(st[:, 1] - st[:, 5]))}
