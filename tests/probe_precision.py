@@ -40,7 +40,7 @@ def policies():
         p["block%d" % i] = FP
         p["attn%d" % i] = FP
         out.append(("only_block%d_fp16" % i, p))
-    out.append(("mixed(pa,attn bf16)", dict(ops.POLICIES["mixed"])))
+    out.append(("mixed = the default policy (attn bf16, rest fp16)", dict(ops.POLICIES["mixed"])))
     out.append(("mixed2(pa bf16)", {"pa": BF, "front": FP, "block": FP, "attn": FP, "tail": FP}))
     out.append(("mixed3(attn bf16)", {"pa": FP, "front": FP, "block": FP, "attn": BF, "tail": FP}))
     out.append(("mixed4(pa,attn,front bf16)", {"pa": BF, "front": BF, "block": FP, "attn": BF, "tail": FP}))
