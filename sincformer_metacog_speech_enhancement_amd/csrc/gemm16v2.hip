@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma(fb[j], fa[i], acc[i][j]);   // W as the A operand: the TRANSPOSED tile
     }
     if (++stage == STAGES) stage = 0;
   }
@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) img[(i * 32 + mfma_row(r, lane)) * IMG_LD + j * 32 + l31] = acc[2 * hp + i][j][r];
+      for (int q = 0; q < 4; ++q)                        // transposed accumulators: a register quad = 4 consecutive columns of
+        *reinterpret_cast<f32x4*>(&img[(i * 32 + l31) * IMG_LD + j * 32 + 8 * q + 4 * hl]) =   // output row l31: 16 ds_write_b128
+            f32x4{acc[2 * hp + i][j][4 * q], acc[2 * hp + i][j][4 * q + 1], acc[2 * hp + i][j][4 * q + 2],     // per tile instead
+                  acc[2 * hp + i][j][4 * q + 3]};                                                              // of 64 ds_write_b32
   __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the wave's own image is complete
   __builtin_amdgcn_wave_barrier();
   const int row_base = l0 + wm * (BM / 2) + hp * 64;   // first output row of this pass
@@ -179,6 +182,55 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
   }
   const long long obase = (long long)b * p.o_batch_stride;
+  // Residual epilogue (out = resid + alpha * (acc + bias), no dropout, no statistics: attention out_proj, pointwise2 and the
+  // unfused FFN of the inference path): all of the tile's residual rows are requested BEFORE the first one is used.  In the
+  // general loop below each pass loads its 32 bytes and waits for them (a global round trip per 8 rows: the epilogue of these
+  // GEMMs took 23 us of their 37 at M 51 264).
+  if (p.epi == EPI_RESID && !glu && p.vec_ok && p.p_drop == 0.f && !p.gn_partial && ncol0 + 8 <= p.N) {
+    constexpr int CPR = WN >> 3, RPP = 64 / CPR;
+    const int c8s = (lane % CPR) * 8, rs = lane / CPR;
+    const int nc = colb + c8s;
+    f32x4 rr[CPR][2];
+#pragma unroll
+    for (int it = 0; it < CPR; ++it) {
+      int m = row_base + it * RPP + rs;
+      m = m < p.Lout ? m : p.Lout - 1;                 // clamped: loaded, not used
+      const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + nc;
+      rr[it][0] = *reinterpret_cast<const f32x4*>(rp);
+      rr[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+    }
+    f32x4 bb0 = {0.f, 0.f, 0.f, 0.f}, bb1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      bb0 = *reinterpret_cast<const f32x4*>(p.bias + nc);
+      bb1 = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < CPR; ++it) {
+      const int row = it * RPP + rs;
+      const int m = row_base + row;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8s]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8s + 4]);
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = rr[it][0][e] + p.alpha * (x0[e] + bb0[e]);
+        y[4 + e] = rr[it][1][e] + p.alpha * (x1[e] + bb1[e]);
+      }
+      if (m >= p.Lout) continue;
+      const long long orow = obase + (long long)m * p.ldo + nc;
+      if (p.out_f32 == 1) {
+        float* op = reinterpret_cast<float*>(p.out) + orow;
+        *reinterpret_cast<f32x4*>(op) = f32x4{y[0], y[1], y[2], y[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{y[4], y[5], y[6], y[7]};
+      } else {
+        u32x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(y[2 * e], y[2 * e + 1], p.out_f32 == 2);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
+      }
+    }
+    continue;                                          // next 64-row pass of the wave tile
+  }
   float gsum = 0.f, gsq = 0.f;
   for (int r0 = 0; r0 < 64; r0 += rpp) {
     const int row = r0 + rsub;
@@ -197,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + 32 + c8 + 4]);
       const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= sigmoid_f(g[e] + big[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= __builtin_amdgcn_rcpf(1.0f + __expf(-(g[e] + big[e])));   // v_rcp (1 ulp), not the division sequence
     }
     const bool mok = m < p.Lout;
     if (p.gn_partial && mok) {
