@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     big[e] = (glu && p.bias) ? p.bias[colb + 32 + c8 + e] : 0.f;
   }
   const long long obase = (long long)b * p.o_batch_stride;
-  // Residual epilogue (out = resid + alpha * (acc + bias), no dropout, no statistics: attention out_proj, pointwise2 and the
-  // unfused FFN of the inference path): all of the tile's residual rows are requested BEFORE the first one is used.  In the
+  // Residual epilogue (out = resid + alpha * drop(acc + bias), no statistics: attention out_proj, pointwise2, the second FFN
+  // Linear of the unfused / training path): all of the tile's residual rows are requested BEFORE the first one is used.  In the
   // general loop below each pass loads its 32 bytes and waits for them (a global round trip per 8 rows: the epilogue of these
   // GEMMs took 23 us of their 37 at M 51 264).
-  if (p.epi == EPI_RESID && !glu && p.vec_ok && p.p_drop == 0.f && !p.gn_partial && ncol0 + 8 <= p.N) {
+  if (p.epi == EPI_RESID && !glu && p.vec_ok && !p.gn_partial && ncol0 + 8 <= p.N) {
     constexpr int CPR = WN >> 3, RPP = 64 / CPR;
     const int c8s = (lane % CPR) * 8, rs = lane / CPR;
     const int nc = colb + c8s;
@@ -213,8 +213,19 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
       float y[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        y[e] = rr[it][0][e] + p.alpha * (x0[e] + bb0[e]);
-        y[4 + e] = rr[it][1][e] + p.alpha * (x1[e] + bb1[e]);
+        y[e] = x0[e] + bb0[e];
+        y[4 + e] = x1[e] + bb1[e];
+      }
+      if (p.p_drop > 0.f) {                              // residual-branch dropout, same counters as sfm_ew_train mode 4
+        float kp[8];
+        sfm_keep_scale8(p.seed, ((unsigned long long)b * p.Lout + (m < p.Lout ? m : 0)) * p.N + nc, p.p_drop, 1.0f / (1.0f - p.p_drop), kp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] *= kp[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = rr[it][0][e] + p.alpha * y[e];
+        y[4 + e] = rr[it][1][e] + p.alpha * y[4 + e];
       }
       if (m >= p.Lout) continue;
       const long long orow = obase + (long long)m * p.ldo + nc;
