@@ -514,21 +514,41 @@ __global__ __launch_bounds__(256) void pool_time_vec_kernel(const void* __restri
   const long long s = ((long long)i * Tin) / Tout;
   const long long e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long t = s; t < e; ++t) {
-    const long long o = ((long long)b * Tin + t) * ld_src + c;
+  // window rows in groups of 8 with ALL of a group's loads issued before the first add (a rolled `for t` loop waits out one
+  // memory round trip per row; the windows of the path are 5-6 rows)
+  for (long long t0 = s; t0 < e; t0 += 8) {
     if (SRC == 0) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o + 4);
+      f32x4 a0[8], a1[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
-    } else {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(src_) + o);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u16 lo = (u16)(a[j] & 0xffffu), hi = (u16)(a[j] >> 16);
-        acc[2 * j] += SRC == 1 ? F16::to_f32(lo) : BF16::to_f32(lo);
-        acc[2 * j + 1] += SRC == 1 ? F16::to_f32(hi) : BF16::to_f32(hi);
+      for (int k = 0; k < 8; ++k) {
+        const long long t = t0 + k < e ? t0 + k : e - 1;     // clamped: loaded, not added
+        const long long o = ((long long)b * Tin + t) * ld_src + c;
+        a0[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o);
+        a1[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o + 4);
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (t0 + k < e) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += a0[k][j]; acc[4 + j] += a1[k][j]; }
+        }
+    } else {
+      u32x4 a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long long t = t0 + k < e ? t0 + k : e - 1;
+        a[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(src_) + ((long long)b * Tin + t) * ld_src + c);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (t0 + k < e) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const u16 lo = (u16)(a[k][j] & 0xffffu), hi = (u16)(a[k][j] >> 16);
+            acc[2 * j] += SRC == 1 ? F16::to_f32(lo) : BF16::to_f32(lo);
+            acc[2 * j + 1] += SRC == 1 ? F16::to_f32(hi) : BF16::to_f32(hi);
+          }
+        }
     }
   }
   const float inv = 1.0f / (float)(e - s);
