@@ -45,10 +45,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// D = 256 (every LayerNorm of the Conformer blocks): a wave takes TWO rows per trip, a lane 4 consecutive columns of each
+// (16-byte loads, 8- or 16-byte stores), row sums by DPP adds.  The general kernel above moves 4 bytes per lane per instruction.
+template <class T>
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bsh, u16* out16, float* out32, int M,
+                                                           int ldx, int ld16, int ld32, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (row0 >= M) return;
+  const bool two = row0 + 1 < M;
+  const f32x4 gw = *reinterpret_cast<const f32x4*>(w + 4 * lane), gb = *reinterpret_cast<const f32x4*>(bsh + 4 * lane);
+  f32x4 v[2];
+  v[0] = *reinterpret_cast<const f32x4*>(x + (long long)row0 * ldx + 4 * lane);
+  v[1] = *reinterpret_cast<const f32x4*>(x + (long long)(two ? row0 + 1 : row0) * ldx + 4 * lane);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && !two) break;
+    const float mean = wave_sum_dpp((v[r][0] + v[r][1]) + (v[r][2] + v[r][3])) * (1.0f / 256.0f);
+    float d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = v[r][j] - mean;
+    const float rstd = rsqrtf(wave_sum_dpp((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f) + eps);
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      y[j] = d[j] * rstd * gw[j] + gb[j];
+      if (act == 1) y[j] = gelu_erf(y[j]);
+    }
+    const long long row = row0 + r;
+    if (out16) {
+      u32x2 pk;
+      pk[0] = pack2<T>(y[0], y[1]);
+      pk[1] = pack2<T>(y[2], y[3]);
+      *reinterpret_cast<u32x2*>(out16 + row * ld16 + 4 * lane) = pk;
+    }
+    if (out32) *reinterpret_cast<f32x4*>(out32 + row * ld32 + 4 * lane) = f32x4{y[0], y[1], y[2], y[3]};
+  }
+}
+
 extern "C" int sfm_layernorm(const float* x, const float* w, const float* b, void* out16, float* out32, int M, int D,
                              int ldx, int ld16, int ld32, float eps, int act, int dtype, void* stream) {
   if (!x || !w || !b || (!out16 && !out32)) return SFM_ERR_ARG;
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
+  const bool vec = D == 256 && (ldx % 4 == 0) && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)b) % 16 == 0) &&
+                   (!out16 || ((ld16 % 4 == 0) && ((uintptr_t)out16 % 8 == 0))) &&
+                   (!out32 || ((ld32 % 4 == 0) && ((uintptr_t)out32 % 16 == 0)));
+  if (vec) {
+    dim3 grid2((M + 7) / 8), block2(256);
+    if (dtype == SFM_DT_F16)
+      SFM_LAUNCH((layernorm256_kernel<F16>), grid2, block2, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M, ldx, ld16, ld32,
+                 eps, act);
+    else
+      SFM_LAUNCH((layernorm256_kernel<BF16>), grid2, block2, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M, ldx, ld16, ld32,
+                 eps, act);
+    return SFM_OK;
+  }
   dim3 grid((M + 3) / 4), block(256);
   if (dtype == SFM_DT_F16)
     SFM_LAUNCH((layernorm_kernel<F16>), grid, block, 0, (hipStream_t)stream, x, w, b, (u16*)out16, out32, M, D,
