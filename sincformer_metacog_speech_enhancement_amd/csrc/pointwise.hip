@@ -123,10 +123,21 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
                                                          int P, int G, int C, double count, float eps) {
   const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int i = lane; i < P; i += 64) {
-    const float* pp = partial + (((long long)b * P + i) * G + g) * 2;
-    s += (double)pp[0];
-    q += (double)pp[1];
+  // eight partial slots per lane per trip, loaded together (a rolled one-slot loop pays a memory round trip per slot: 8 in a
+  // row at P = 500, which was this kernel's whole 8 us); same summation order
+  for (int i0 = lane; i0 < P; i0 += 64 * 8) {
+    f32x2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + 64 * k < P ? i0 + 64 * k : P - 1;
+      v[k] = *reinterpret_cast<const f32x2*>(partial + (((long long)b * P + i) * G + g) * 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + 64 * k < P) {
+        s += (double)v[k][0];
+        q += (double)v[k][1];
+      }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
