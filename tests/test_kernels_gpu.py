@@ -418,7 +418,7 @@ def test_attention_online_softmax_rescale(ops, variant):
 
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,D", [(100, 256), (33, 64), (17, 258)])
+@pytest.mark.parametrize("M,D", [(100, 256), (101, 256), (7, 256), (33, 64), (17, 258)])   # D 256: the two-rows-per-wave kernel, odd M = its tail
 def test_layernorm(ops, dt, M, D):
     ops.set_compute_dtype(dt)
     x, w, b = arr("lx", (M, D), 50, 2.0) + 0.3, arr("lw", (D,), 51) * 0.1 + 1, arr("lb", (D,), 52) * 0.1
