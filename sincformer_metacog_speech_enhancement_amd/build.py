@@ -20,7 +20,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # per-source extras: keep the attention accumulators in VGPRs (the softmax works on them with
 # VALU instructions; the default AGPR placement costs ~220 v_accvgpr moves per key tile)
 # -fno-honor-nans: row maxima of the online softmax compile to bare v_max3_f32 (see attention.hip)
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+         "attention_pipe.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def _newer(src, dst, deps):

@@ -758,12 +758,16 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
 // kernel selection for the head_dim 64 no-dropout path: 0 = by shape (persistent ring kernel for 256 < T <= 512 and
 // T >= 1024, 32 query rows per wave otherwise), 1 = always 32 rows per wave (attn_fwd_hd64), 3 = always the persistent ring
 // kernel (attn_fwd_hd64r); 2 (the former 64-rows-per-wave kernel, superseded by the ring kernel) is accepted as 3
+// 4 = the pipelined persistent kernel attn_fwd_hd64p (attention_pipe.hip), which auto now picks wherever it picked the ring kernel
 static int sfm_attn_variant = 0;
 extern "C" int sfm_attention_set_variant(int v) {
-  if (v < 0 || v > 3) return SFM_ERR_ARG;
+  if (v < 0 || v > 4) return SFM_ERR_ARG;
   sfm_attn_variant = (v == 2) ? 3 : v;
   return SFM_OK;
 }
+int sfm_attn_pipe_launch(const void* qkv, void* out, float* lse, int B, int T, int H, int ldqkv, int ldo, int koff, int voff,
+                         long long qkv_batch_stride, long long o_batch_stride, float sl2, int dtype, int out_other,
+                         hipStream_t st);
 
 // qkv: [B, T, ldqkv] 16-bit with q at column h*hd, k at koff + h*hd, v at voff + h*hd.
 static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv, int ldo, int koff,
@@ -786,7 +790,10 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
     const int nqt5 = (T + 511) / 512;
     const bool ring_auto = ((T > 256 && T <= 512) || T >= 1024) && (long long)B * H * nqt5 >= 128;
     if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) &&
-        (sfm_attn_variant == 3 || (sfm_attn_variant == 0 && ring_auto))) {
+        (sfm_attn_variant == 4 || (sfm_attn_variant == 0 && ring_auto)))
+      return sfm_attn_pipe_launch(qkv, out, lse, B, T, H, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, sl2, dtype,
+                                  out_other, st);
+    if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) && sfm_attn_variant == 3) {
       const int n_items = nqt5 * H * B;
       static int ncu = 0;
       if (ncu == 0) {

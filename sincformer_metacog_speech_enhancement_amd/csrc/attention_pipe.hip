@@ -1,0 +1,473 @@
+// attn_fwd_hd64p: the head_dim-64 attention core (models/conformer.py:66-71 -> nn.MultiheadAttention's softmax(QK^T/sqrt(hd)) V)
+// as a persistent, three-stage software pipeline.  Same data movement as the ring kernel it replaces (one 512-thread
+// workgroup per CU walks (batch, head, 512-query tile) items; K/V by LDS-DMA into a ring of 2 x 3 key tiles, one barrier per
+// 3 key tiles, the next item's Q rows prefetched; O transposed through LDS and stored as whole rows), new arithmetic:
+//
+//   * a wave owns 64 query rows = two 32-row sub-blocks U = 0, 1 and walks the keys in 32-key steps; one "ritem" per
+//     (step, sub-block).  Ritem r issues, in ONE basic block,
+//        S^T(r)   = K Q^T - m           4 x v_mfma_f32_32x32x16 + one augmented k-step (K side [1, 1, pad, 0..], Q side
+//                                       [-m_hi, -m_lo, -BIG, 0..]): the matrix core subtracts the running maximum and pushes
+//                                       padding keys (>= T) to -BIG.  (The alternative - -m as the C operand of the first
+//                                       MFMA - needs a 16-register block per sub-block; the kernel has no registers to spare.)
+//        P(r-1)   = exp2(S^T(r-1))      16 v_exp_f32 + 8 packing converts on the VALU, other sub-block
+//        O^T(r-2) += V^T P^T(r-2)       4 x v_mfma_f32_32x32x16 + the row sums l += 1^T P as 2 x v_mfma_f32_16x16x32 against
+//                                       a lane-patterned ones operand (each lane gets the sum of ITS query over both lane
+//                                       halves: 4 accumulator registers instead of 16, half the matrix-pipe time)
+//     so every MFMA has independent VALU work beside it and nothing in the block waits for a result produced in it.
+//   * overflow check instead of a row maximum per block: P is packed 16-bit and >= 0, so "some P >= 2" is bit 14 of either
+//     half (top exponent bit in bf16 and in fp16): OR of the 8 packed registers, one AND, one compare.  Only then - a rare,
+//     wave-uniform branch, also forced on the first block of a sub-block - the true row maxima are computed, m is raised to
+//     max + 3 (log2 units: P <= 1/8 afterwards, so the branch fires when a score exceeds the running maximum by 4), O and l
+//     are rescaled and P(r-1) is recomputed.  P(r-2) entered O at the old scale before the rescale: consistent.
+//   * steps made of padding keys only (T mod 64 in 1..32) are skipped.
+//   * K fragments of step s+1 and V^T fragments of step s are read from LDS under the second ritem of step s (inline asm,
+//     counted lgkmcnt): no LDS latency in front of an MFMA chain.
+#include "sfm_common.h"
+
+#ifndef SFM_ATTNP_ABL
+#define SFM_ATTNP_ABL 0
+#endif
+
+typedef __attribute__((address_space(3))) void* attnp_lds_ptr_t;
+
+__device__ __forceinline__ float attnp_xhalf_max(float v) {
+  // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of the second (s_nop: VALU write -> swap)
+  uint32_t a = __builtin_bit_cast(uint32_t, v), c = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, c));
+}
+
+template <class T>
+__device__ __forceinline__ uint32_t attnp_pack2_o(float lo, float hi, bool other) {
+  if (T::id == SFM_DT_BF16) return other ? F16::pack(lo, hi) : BF16::pack(lo, hi);
+  return other ? BF16::pack(lo, hi) : F16::pack(lo, hi);
+}
+
+#define ATTNP_HEADROOM 3.0f
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen,
+                                                                int ldqkv, int ldo, int koff, int voff,
+                                                                long long qkv_batch_stride, long long o_batch_stride,
+                                                                float scale_log2e, int nqt, int nheads, int n_items,
+                                                                float* __restrict__ lse_out, int out_other) {
+  constexpr int SLOT = 16384;                                       // one key tile: K 64 x 128 B, then V 64 x 128 B
+  constexpr int GT = 3;                                             // key tiles per group (ring = 2 groups)
+  constexpr int QBASE = 2 * GT * SLOT;                              // Q prefetch region: 8 waves x 64 rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l31 = lane & 31;
+  const int nkt = (Tlen + 63) >> 6, ngrp = (nkt + GT - 1) / GT, nsteps = (Tlen + 31) >> 5;
+  const int rec_bytes = Tlen * ldqkv * 2;                          // keys / queries >= Tlen are out of range: read as zero
+  const int orec_bytes = Tlen * ldo * 2;
+
+  // ---- LDS-DMA lane constants: an instruction moves 8 rows x 128 B; this wave owns rows 8*wave .. 8*wave+7 of every tile ----
+  const int prow = wave * 8 + (lane >> 3);
+  const int kconst = prow * ldqkv * 2 + koff * 2 + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+  const int vconst = prow * ldqkv * 2 + voff * 2 + (((lane & 7) ^ (((prow >> 1) & 1) << 2)) << 4);
+  auto issue_group = [&](int item, int g, int half) {              // K/V tiles GT g .. GT g + GT-1 of `item` -> ring half `half`
+    const int bh = item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (long long)b * qkv_batch_stride), 0, rec_bytes, 0x00020000);
+#pragma unroll
+    for (int tl = 0; tl < GT; ++tl) {
+      const int kt = g * GT + tl;
+      if (kt < nkt) {
+        const int off = kt * 64 * ldqkv * 2 + h * 128;
+        unsigned char* dst = rsm + (half * GT + tl) * SLOT + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)dst, 16, kconst + off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)(dst + 8192), 16, vconst + off, 0, 0, 0);
+      }
+    }
+  };
+  // Q rows of `item` for this wave (64 rows x 128 B, same chunk swizzle as a K tile) -> the wave's 8 KB of the Q region
+  auto issue_q = [&](int item) {
+    const int qt = item % nqt, bh = item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (long long)b * qkv_batch_stride), 0, rec_bytes, 0x00020000);
+    const int off = (qt * 512 + wave * 64) * ldqkv * 2 + h * 128;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 4;
+      const int vo = off + (8 * j + (lane >> 3)) * ldqkv * 2 + c;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)(rsm + QBASE + wave * 8192 + j * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment read lane constants (byte offsets inside a 32-key step: K rows at +0, V rows at +8192) ----
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(attnp_lds_ptr_t)rsm;
+  uint32_t klane[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) klane[ks] = lds0 + l31 * 128 + (((2 * ks + hl) ^ ((l31 >> 1) & 7)) << 4);
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int vrow0 = 4 * (g16 >> 1) + (i16 >> 2);
+  uint32_t vlane[2];
+#pragma unroll
+  for (int dj = 0; dj < 2; ++dj) {
+    const int chunk = dj * 4 + (g16 & 1) * 2 + ((i16 & 3) >> 1);
+    vlane[dj] = lds0 + 8192 + vrow0 * 128 + ((chunk ^ (((vrow0 >> 1) & 1) << 2)) << 4) + (i16 & 1) * 8;
+  }
+
+  // ones operand of the row-sum MFMA (16x16x32, A side): row i of the result sums the lane groups G with G&1 == (i>>2)&1, so
+  // that lane l (result rows 4*(l>>4)..+3, column l&15) receives the sum over both lane halves of query l&31
+  const uint32_t one16 = T::from_f32(1.0f);
+  const uint32_t ones2 = (((lane >> 4) & 1) == ((lane >> 2) & 1)) ? (one16 | (one16 << 16)) : 0u;
+  const u32x4 onesA = {ones2, ones2, ones2, ones2};
+  const uint32_t ones2k = one16 | (one16 << 16);                    // augmented k-step, K side
+  const uint32_t negbig = (uint32_t)T::from_f32(T::id == SFM_DT_F16 ? -60000.0f : -3.0e38f);
+
+  // All LDS fragment reads are inline asm with hand-counted lgkmcnt waits: behind an LDS-DMA the compiler guards its own LDS
+  // reads with vmcnt(0) (it cannot prove they do not alias the DMA destination) and it sinks early reads down to their use.
+  // The ring protocol (vmcnt + barrier at the group boundary) is what orders reads against fills.
+  u32x4 kf[4];
+  u32x2 vt[2][2][2];                                                // V^T fragment halves [s2][dj][first / second 4 keys]
+  auto load_kf = [&](int sbase) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks]) : "v"(klane[ks] + sbase) : "memory");
+  };
+  auto load_vf = [&](int sbase) {
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj) {
+      const uint32_t a = vlane[dj] + sbase;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[0][dj][0]) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vt[0][dj][1]) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vt[1][dj][0]) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(vt[1][dj][1]) : "v"(a) : "memory");
+    }
+  };
+#define ATTNP_KF_WAIT(N)                                                                                               \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) : : "memory")
+#define ATTNP_VT_WAIT()                                                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
+               : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[1][0][0]),        \
+                 "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1])                                               \
+               :                                                                                                       \
+               : "memory")
+#define ATTNP_VF(S2, DJ) (u32x4{vt[S2][DJ][0][0], vt[S2][DJ][0][1], vt[S2][DJ][1][0], vt[S2][DJ][1][1]})
+
+  u32x4 qf[2][4];
+  float m_run[2];
+  uint32_t qaug[2];                                                 // packed (-m_hi, -m_lo) of the lane's query, lanes 0-31
+  f32x16 o[2][2], s[2];
+  f32x4 lacc[2];
+  u32x4 pf[2][2];                                                   // packed P of the pending block of each sub-block [U][s2]
+
+  // P = exp2(S) of sub-block X, packed; FLAG |= "some P >= 2"
+#define ATTNP_EXP_PACK(X, FLAGW)                                                                                       \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                                 \
+      float e_[8];                                                                                                     \
+      _Pragma("unroll") for (int r = 0; r < 8; ++r) e_[r] = __builtin_amdgcn_exp2f(s[X][8 * s2 + r]);                  \
+      pf[X][s2][0] = pack2<T>(e_[0], e_[1]);                                                                           \
+      pf[X][s2][1] = pack2<T>(e_[2], e_[3]);                                                                           \
+      pf[X][s2][2] = pack2<T>(e_[4], e_[5]);                                                                           \
+      pf[X][s2][3] = pack2<T>(e_[6], e_[7]);                                                                           \
+    }                                                                                                                  \
+    FLAGW = (pf[X][0][0] | pf[X][0][1] | pf[X][0][2]) | (pf[X][0][3] | pf[X][1][0] | pf[X][1][1]) |                    \
+            (pf[X][1][2] | pf[X][1][3]);                                                                               \
+  }
+  // O^T(U) += V^T P^T(U), l(U) += 1^T P(U)
+#define ATTNP_PV(U)                                                                                                    \
+  {                                                                                                                    \
+    lacc[U] = T::mfma16(onesA, pf[U][0], lacc[U]);                                                                     \
+    o[U][0] = T::mfma(ATTNP_VF(0, 0), pf[U][0], o[U][0]);                                                              \
+    o[U][1] = T::mfma(ATTNP_VF(0, 1), pf[U][0], o[U][1]);                                                              \
+    lacc[U] = T::mfma16(onesA, pf[U][1], lacc[U]);                                                                     \
+    o[U][0] = T::mfma(ATTNP_VF(1, 0), pf[U][1], o[U][0]);                                                              \
+    o[U][1] = T::mfma(ATTNP_VF(1, 1), pf[U][1], o[U][1]);                                                              \
+  }
+  // rare path: raise the running maximum of sub-block X from the block whose scores are in s[X], rescale O and l, redo P
+#define ATTNP_RESCALE(X, FORCE)                                                                                        \
+  {                                                                                                                    \
+    float mx = fmaxf(s[X][0], s[X][1]);                                                                                \
+    _Pragma("unroll") for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[X][r]), s[X][r + 1]);                     \
+    mx = attnp_xhalf_max(mx);                                                                                          \
+    /* new subtracted value, split in two 16-bit terms so that the MFMA subtracts it to ~2^-17 */                      \
+    const float want_ = m_run[X] + ((FORCE) ? mx + ATTNP_HEADROOM : fmaxf(mx + ATTNP_HEADROOM, 0.f));                  \
+    const float hi_ = T::to_f32(T::from_f32(want_));                                                                   \
+    const float lo_ = T::to_f32(T::from_f32(want_ - hi_));                                                             \
+    const float m_new_ = hi_ + lo_;                                                                                    \
+    const float delta = m_new_ - m_run[X];                                                                             \
+    const float alpha = (FORCE) ? 0.f : __builtin_amdgcn_exp2f(-delta);                                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                   \
+      o[X][0][r] *= alpha;                                                                                             \
+      o[X][1][r] *= alpha;                                                                                             \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) lacc[X][r] *= alpha;                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) s[X][r] -= delta;                                                   \
+    m_run[X] = m_new_;                                                                                                 \
+    qaug[X] = (hl == 0) ? pack2<T>(-hi_, -lo_) : 0u;                                                                   \
+    uint32_t fl_;                                                                                                      \
+    ATTNP_EXP_PACK(X, fl_)                                                                                             \
+    (void)fl_;                                                                                                         \
+  }
+
+  // One ritem: S chain of (STEP, U); exponentials of the previous ritem's block (sub-block 1-U); PV of sub-block U's pending
+  // block.  AFIRST: first ritem of a step (fragment waits).  KPRE / VLOAD (second ritem of a step): read the next step's K
+  // fragments / this step's V^T fragments.
+#define ATTNP_RITEM(U, STEP, AFIRST, KPRE, KSB, VLOAD, VSB, FORCE)                                                     \
+  {                                                                                                                    \
+    constexpr int V_ = 1 - (U);                                                                                        \
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
+    const bool pad_ = (STEP) * 32 + l31 >= Tlen;                                                                       \
+    const u32x4 ka = {hl == 0 ? ones2k : 0u, (hl == 0 && pad_) ? one16 : 0u, 0u, 0u};                                  \
+    const u32x4 qa = {qaug[U], hl == 0 ? negbig : 0u, 0u, 0u};                                                         \
+    /* ---- region 1: the S chain, with the first 12 exponentials beside it ---- */                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    f32x16 sn = T::mfma(ka, qa, zero);                                                                                 \
+    if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
+    sn = T::mfma(kf[0], qf[U][0], sn);                                                                                 \
+    sn = T::mfma(kf[1], qf[U][1], sn);                                                                                 \
+    sn = T::mfma(kf[2], qf[U][2], sn);                                                                                 \
+    sn = T::mfma(kf[3], qf[U][3], sn);                                                                                 \
+    float e_[16];                                                                                                      \
+    _Pragma("unroll") for (int r = 0; r < 12; ++r) e_[r] = __builtin_amdgcn_exp2f(s[V_][r]);                           \
+    pf[V_][0][0] = pack2<T>(e_[0], e_[1]);                                                                             \
+    pf[V_][0][1] = pack2<T>(e_[2], e_[3]);                                                                             \
+    pf[V_][0][2] = pack2<T>(e_[4], e_[5]);                                                                             \
+    pf[V_][0][3] = pack2<T>(e_[6], e_[7]);                                                                             \
+    ATTNP_SCHED1                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    /* ---- region 2: PV of the pending block, the remaining exponentials, the overflow test ---- */                   \
+    if (KPRE) load_kf(KSB);                                                                                            \
+    if (AFIRST) ATTNP_VT_WAIT();                                                                                       \
+    ATTNP_PV(U)                                                                                                        \
+    _Pragma("unroll") for (int r = 12; r < 16; ++r) e_[r] = __builtin_amdgcn_exp2f(s[V_][r]);                          \
+    pf[V_][1][0] = pack2<T>(e_[8], e_[9]);                                                                             \
+    pf[V_][1][1] = pack2<T>(e_[10], e_[11]);                                                                           \
+    pf[V_][1][2] = pack2<T>(e_[12], e_[13]);                                                                           \
+    pf[V_][1][3] = pack2<T>(e_[14], e_[15]);                                                                           \
+    uint32_t flag_ = (pf[V_][0][0] | pf[V_][0][1] | pf[V_][0][2]) | (pf[V_][0][3] | pf[V_][1][0] | pf[V_][1][1]) |     \
+                     (pf[V_][1][2] | pf[V_][1][3]);                                                                    \
+    ATTNP_SCHED2                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (VLOAD) load_vf(VSB);                                                                                           \
+    s[U] = sn;                                                                                                         \
+    /* the forced case enters through the same data-dependent test (a short-circuit on FORCE lets the compiler sink the   \
+       exponentials out of this block, behind the branch) */                                                           \
+    if (__any(((flag_ | ((FORCE) ? 0x4000u : 0u)) & 0x40004000u) != 0u)) ATTNP_RESCALE(V_, FORCE)                      \
+  }
+
+#if SFM_ATTNP_ABL == 4
+#define ATTNP_SCHED1
+#define ATTNP_SCHED2
+#else
+  // Per 32-cycle MFMA ~24 cycles of VALU issue fit beside it (v_exp_f32 8, the rest 4 each), 8 beside a 16-cycle one.
+  // region 1: A S0 S1 S2 S3 with 12 exponentials (TRANS) and 4 converts
+#define ATTNP_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define ATTNP_SCHED1                                                                                                   \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)                                                                                \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)                                                                                \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 2) ATTNP_SG(0x002, 2)                                                             \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 2) ATTNP_SG(0x002, 2)                                                             \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 2)
+  // region 2: L P P L P P with 4 exponentials, 4 converts, the OR / test
+#define ATTNP_SCHED2                                                                                                   \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 1)                                                                                \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)                                                                                \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x002, 4)                                                                                \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x002, 2)                                                                                \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x002, 6)                                                                                \
+  ATTNP_SG(0x008, 1)
+#endif
+
+  // ---- O of the finished item, held in registers until the next item's first barrier has been passed; then transposed
+  //      through the wave's own 8 KB of the Q region (free between the Q fragment reads and the next Q prefetch) so that
+  //      every store instruction writes 8 whole 128-byte rows ----
+  uint32_t ow[2][2][4][2];                                          // [sub-block][dj][rq][2 dwords] = 4 consecutive d, 16-bit
+  int st_item = -1;
+  auto store_o = [&]() {
+    if (st_item < 0) return;
+    const int qt = st_item % nqt, bh = st_item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    auto ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * o_batch_stride), 0, orec_bytes, 0x00020000);
+    unsigned char* ob = rsm + QBASE + wave * 8192;
+    // the lane id is made opaque so that the per-lane addresses below are computed HERE, once per item (hoisted to kernel
+    // entry they live across the whole tile loop and get spilled)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int l31o = ln & 31, hlo = ln >> 5;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 32 * u + l31o;
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<u32x2*>(ob + row * 128 + (((dj * 4 + rq) ^ ((row >> 1) & 7)) << 4) + 8 * hlo) =
+              u32x2{ow[u][dj][rq][0], ow[u][dj][rq][1]};
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): the wave's own image is complete
+    __builtin_amdgcn_wave_barrier();
+    const int qbase = qt * 512 + wave * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ln + 64 * i;
+      const int row = c >> 3, ch = c & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, (qbase + row) * ldo * 2 + h * 128 + ch * 16, 0, 0);
+    }
+    st_item = -1;
+  };
+
+  // the second-dispatched half of the workgroup loses the VALU arbitration against its SIMD partner (priority, then age)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  int gcount = 0;                                                   // groups consumed so far by this workgroup (ring parity)
+  if ((int)blockIdx.x < n_items) {
+    issue_q(blockIdx.x);
+    issue_group(blockIdx.x, 0, 0);
+  }
+  // ---- group boundary: this wave's pieces of group g have landed (vmcnt), everyone's have and everyone is done with group
+  //      g-1 (barrier; the lgkmcnt(0) covers the V^T reads of the last step, issued before it): refill that half with the
+  //      next group of this item or group 0 of the next item; then read the K fragments of the group's first step ----
+#define ATTNP_BOUNDARY(G)                                                                                              \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+  __syncthreads();                                                                                                     \
+  const int half = gcount & 1;                                                                                         \
+  if ((G) + 1 < ngrp) issue_group(item, (G) + 1, half ^ 1);                                                            \
+  else if (item + (int)gridDim.x < n_items) issue_group(item + gridDim.x, 0, half ^ 1);                                \
+  ++gcount;                                                                                                            \
+  load_kf(half * GT * SLOT);
+  // the steps of group G (the K prefetch of a step beyond the group reads stale ring / Q-region bytes that are never used:
+  // the next group's first fragments are read after its barrier)
+#define ATTNP_STEPS(G)                                                                                                 \
+  ATTNP_KF_WAIT(0);                                                                                                    \
+  {                                                                                                                    \
+    const int step_end = min(nsteps, ((G) + 1) * 2 * GT);                                                              \
+    for (int step = (G) * 2 * GT; step < step_end; ++step) {                                                           \
+      const int sbk = half * GT * SLOT + ((step >> 1) - (G) * GT) * SLOT + (step & 1) * 4096;   /* K rows; V at +8192 */ \
+      const int sbn = half * GT * SLOT + (((step + 1) >> 1) - (G) * GT) * SLOT + ((step + 1) & 1) * 4096;              \
+      ATTNP_RITEM(0, step, true, false, 0, false, 0, step == 1)                                                        \
+      ATTNP_RITEM(1, step, false, true, sbn, true, sbk, step == 0)                                                     \
+    }                                                                                                                  \
+  }
+
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int qt = item % nqt, bh = item / nqt;
+    const int h = bh % nheads, b = bh / nheads;
+    const int q0 = qt * 512 + wave * 64;
+    {
+      // ---- group 0 (peeled: the packed O of the previous item must not stay live across the group loop) ----
+      ATTNP_BOUNDARY(0)
+      // Q fragments (B operand: col = query, k = d) from the prefetched LDS rows (rows >= Tlen were zero-filled; the vmcnt
+      // wait above covered this wave's own Q pieces, issued an item ago)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          qf[u][ks] = *reinterpret_cast<const u32x4*>(rsm + QBASE + wave * 8192 + u * 4096 + (klane[ks] - lds0));
+      if (scale_log2e != 1.0f) {                                   // callers normally fold the scale into W_q (scale_log2e == 1)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t w = qf[u][ks][e];
+              qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
+            }
+      }
+      // lgkmcnt(0) as a BUILTIN: the compiler must know that its Q loads have landed (behind an asm wait they stay "pending"
+      // in its model and it then waits in every ritem).  The Q region may be reused from here on.
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      asm volatile("" ::: "memory");
+      store_o();                                                    // the previous item's O: drains under this item's math
+      // pipeline start: nothing pending -> P = 0 (s = -1e30 exponentiates to 0), V^T fragments zero (0 x stale data)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        m_run[u] = 0.f;
+        qaug[u] = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o[u][0][r] = 0.f;
+          o[u][1][r] = 0.f;
+          s[u][r] = -1.0e30f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lacc[u][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) pf[u][s2] = u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+          vt[s2][dj][0] = u32x2{0u, 0u};
+          vt[s2][dj][1] = u32x2{0u, 0u};
+        }
+      // the next item's Q rows -> this wave's own region (its last LDS accesses, the O read-back, have completed)
+      if (ngrp == 1 && item + (int)gridDim.x < n_items) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_q(item + gridDim.x);
+      }
+      ATTNP_STEPS(0)
+    }
+    for (int g = 1; g < ngrp; ++g) {
+      ATTNP_BOUNDARY(g)
+      if (g == 1 && item + (int)gridDim.x < n_items) issue_q(item + gridDim.x);
+      ATTNP_STEPS(g)
+    }
+    // ---- drain: exponentials of the last block of sub-block 1, then the two pending PV products ----
+    {
+      uint32_t flag_;
+      ATTNP_EXP_PACK(1, flag_)
+      const bool force1 = nsteps == 1;
+      if (__any(((flag_ | (force1 ? 0x4000u : 0u)) & 0x40004000u) != 0u)) ATTNP_RESCALE(1, force1)
+      ATTNP_VT_WAIT();
+      ATTNP_PV(0)
+      ATTNP_PV(1)
+    }
+    // ---- normalise and pack; the stores themselves are issued after the next barrier (store_o) ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float l = lacc[u][0];
+      const float inv = 1.0f / l;
+      const int q = q0 + 32 * u + l31;
+      if (lse_out && hl == 0 && q < Tlen)
+        lse_out[((long long)b * nheads + h) * Tlen + q] = m_run[u] + __builtin_amdgcn_logf(l);
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          ow[u][dj][rq][0] = attnp_pack2_o<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv, out_other != 0);
+          ow[u][dj][rq][1] = attnp_pack2_o<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv, out_other != 0);
+        }
+    }
+    st_item = item;
+  }
+  store_o();
+}
+
+// launch (called by attention.hip's dispatcher): head_dim 64, no dropout, operands below 2 GiB per batch element
+int sfm_attn_pipe_launch(const void* qkv, void* out, float* lse, int B, int T, int H, int ldqkv, int ldo, int koff, int voff,
+                         long long qkv_batch_stride, long long o_batch_stride, float sl2, int dtype, int out_other,
+                         hipStream_t st) {
+  const int nqt5 = (T + 511) / 512;
+  const int n_items = nqt5 * H * B;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
+  static int ncu[64] = {0};
+  static bool attr_set[64][2] = {{false, false}};
+  if (ncu[dev] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SFM_ERR_LAUNCH;
+    ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  constexpr int lds = 6 * 16384 + 65536;                            // K/V ring + Q prefetch region = 160 KB
+  const int ti = dtype == SFM_DT_F16 ? 1 : 0;
+  if (!attr_set[dev][ti]) {
+    const void* fn = ti ? (const void*)attn_fwd_hd64p_kernel<F16> : (const void*)attn_fwd_hd64p_kernel<BF16>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SFM_ERR_LAUNCH;
+    attr_set[dev][ti] = true;
+  }
+  dim3 gridr(n_items < ncu[dev] ? n_items : ncu[dev]), blockr(512);
+  if (dtype == SFM_DT_F16)
+    SFM_LAUNCH((attn_fwd_hd64p_kernel<F16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
+               qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
+  else
+    SFM_LAUNCH((attn_fwd_hd64p_kernel<BF16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
+               qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
+  return SFM_OK;
+}

@@ -45,6 +45,11 @@ struct BF16 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
+  // v_mfma_f32_16x16x32: A lane l -> row l&15, k = 8*(l>>4)+j; B lane l -> col l&15, same k; C/D col = l&15, row = 4*(l>>4)+r
+  static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
 };
 
 struct F16 {
@@ -62,6 +67,10 @@ struct F16 {
   }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                   __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };

@@ -350,7 +350,7 @@ def _attn_ref(qkv, B, T, H, hd):
     return (p @ v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("variant", [1, 3])          # both head_dim-64 kernels: 32 query rows per wave / persistent ring
+@pytest.mark.parametrize("variant", [1, 3, 4])       # the head_dim-64 kernels: 32 query rows per wave / persistent ring / pipelined persistent
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,T,H,hd", [(2, 200, 4, 64), (1, 64, 4, 64), (3, 1, 2, 64), (1, 801, 4, 64), (2, 129, 1, 64),
                                       (1, 1100, 2, 64), (2, 20, 4, 16), (1, 37, 2, 32)])
@@ -366,23 +366,24 @@ def test_attention(ops, dt, B, T, H, hd, variant):
     report("attention v%d %s B%d T%d H%d hd%d" % (variant, dt, B, T, H, hd), out.float().cpu(), ref, 6 * EPS[dt])
 
 
-def test_attention_persistent_kernel_walks_several_items_per_workgroup(ops):
+@pytest.mark.parametrize("variant", [3, 4])
+def test_attention_persistent_kernel_walks_several_items_per_workgroup(ops, variant):
     """more (batch, head, query tile) items than CUs: every workgroup of the ring kernel handles two items, the second one's
     Q / first K,V group prefetched under the first; ragged T (keys and query rows beyond T are zero-filled / dropped by the
     buffer descriptors), two query tiles per (batch, head)"""
     ops.set_compute_dtype(torch.bfloat16)
     B, T, H, hd = 40, 700, 4, 64                      # 2 query tiles x 4 heads x 40 = 320 items > 256 CUs
     qkv = arr("aq3", (B * T, 3 * H * hd), 91, 1.0)
-    ops.set_attention_variant(3)
+    ops.set_attention_variant(variant)
     try:
         out = ops.attention(dev(qkv).to(torch.bfloat16).contiguous(), B, T, H, hd)
     finally:
         ops.set_attention_variant(0)
     ref = _attn_ref(q16(qkv, torch.bfloat16), B, T, H, hd)
-    report("attention ring, 320 items", out.float().cpu(), ref, 6 * EPS[torch.bfloat16])
+    report("attention persistent v%d, 320 items" % variant, out.float().cpu(), ref, 6 * EPS[torch.bfloat16])
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 def test_attention_result_in_the_other_16bit_format(ops, variant):
     """precision policy: bf16 attention core, O written as fp16 (and the reverse)"""
     B, T, H, hd = 2, 300, 4, 64
@@ -399,7 +400,7 @@ def test_attention_result_in_the_other_16bit_format(ops, variant):
         report("attention v%d %s -> %s" % (variant, dt, odt), out.float().cpu(), ref, 6 * max(EPS[dt], EPS[odt]))
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 def test_attention_online_softmax_rescale(ops, variant):
     """a spiked key late in the sequence forces the running-max rescale branch"""
     ops.set_compute_dtype(torch.float16)
