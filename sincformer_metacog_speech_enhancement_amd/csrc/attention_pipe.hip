@@ -149,7 +149,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
 
   u32x4 qf[2][4];
   float m_run[2];
-  uint32_t qaug[2];                                                 // packed (-m_hi, -m_lo) of the lane's query, lanes 0-31
+  // augmented k-step operands, kept as whole 4-register tuples (assembling them per ritem costs two moves and a hazard nop):
+  // Q side (-m_hi, -m_lo | -BIG, 0 | 0...) per sub-block, [0] rewritten by a rescale; K side (1, 1 | pad, 0 | 0...), [1]
+  // rewritten per step (nonzero only in a last step that contains padding keys)
+  u32x4 qa[2], ka;
   f32x16 o[2][2], s[2];
   f32x4 lacc[2];
   u32x4 pf[2][2];                                                   // packed P of the pending block of each sub-block [U][s2]
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     _Pragma("unroll") for (int r = 0; r < 4; ++r) lacc[X][r] *= alpha;                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) s[X][r] -= delta;                                                   \
     m_run[X] = m_new_;                                                                                                 \
-    qaug[X] = (hl == 0) ? pack2<T>(-hi_, -lo_) : 0u;                                                                   \
+    qa[X][0] = (hl == 0) ? pack2<T>(-hi_, -lo_) : 0u;                                                                  \
     uint32_t fl_;                                                                                                      \
     ATTNP_EXP_PACK(X, fl_)                                                                                             \
     (void)fl_;                                                                                                         \
@@ -211,12 +214,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   {                                                                                                                    \
     constexpr int V_ = 1 - (U);                                                                                        \
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
-    const bool pad_ = (STEP) * 32 + l31 >= Tlen;                                                                       \
-    const u32x4 ka = {hl == 0 ? ones2k : 0u, (hl == 0 && pad_) ? one16 : 0u, 0u, 0u};                                  \
-    const u32x4 qa = {qaug[U], hl == 0 ? negbig : 0u, 0u, 0u};                                                         \
     /* ---- region 1: the S chain, with the first 12 exponentials beside it ---- */                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    f32x16 sn = T::mfma(ka, qa, zero);                                                                                 \
+    f32x16 sn = T::mfma(ka, qa[U], zero);                                                                              \
     if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
     sn = T::mfma(kf[0], qf[U][0], sn);                                                                                 \
     sn = T::mfma(kf[1], qf[U][1], sn);                                                                                 \
@@ -229,6 +229,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     pf[V_][0][2] = pack2<T>(e_[4], e_[5]);                                                                             \
     pf[V_][0][3] = pack2<T>(e_[6], e_[7]);                                                                             \
     ATTNP_SCHED1                                                                                                       \
+    /* order at the IR level too (MFMAs have no side effects: without a data tie the PV chain may be emitted first and   \
+       the sched_barrier then freezes that order): the PV operands pass through an empty asm that also takes sn */        \
+    asm volatile("" : "+v"(sn), "+v"(pf[U][0]), "+v"(pf[U][1]));                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     /* ---- region 2: PV of the pending block, the remaining exponentials, the overflow test ---- */                   \
     if (KPRE) load_kf(KSB);                                                                                            \
@@ -339,11 +342,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     for (int step = (G) * 2 * GT; step < step_end; ++step) {                                                           \
       const int sbk = half * GT * SLOT + ((step >> 1) - (G) * GT) * SLOT + (step & 1) * 4096;   /* K rows; V at +8192 */ \
       const int sbn = half * GT * SLOT + (((step + 1) >> 1) - (G) * GT) * SLOT + ((step + 1) & 1) * 4096;              \
+      ka[1] = (step == pad_step && hl == 0 && step * 32 + l31 >= Tlen) ? one16 : 0u;                                   \
       ATTNP_RITEM(0, step, true, false, 0, false, 0, step == 1)                                                        \
       ATTNP_RITEM(1, step, false, true, sbn, true, sbk, step == 0)                                                     \
     }                                                                                                                  \
   }
 
+  const int pad_step = (Tlen & 31) ? nsteps - 1 : -1;               // the only step that can contain padding keys
+  ka = u32x4{hl == 0 ? ones2k : 0u, 0u, 0u, 0u};
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int qt = item % nqt, bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         m_run[u] = 0.f;
-        qaug[u] = 0u;
+        qa[u] = u32x4{0u, hl == 0 ? negbig : 0u, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           o[u][0][r] = 0.f;
