@@ -45,6 +45,22 @@ __device__ __forceinline__ uint32_t attnp_pack2_o(float lo, float hi, bool other
 
 #define ATTNP_HEADROOM 3.0f
 
+// diagnostic build (-DSFM_ATTNP_STAMPS, tools/attnp_stamps.py): lse_out becomes a stamp buffer, 8 x uint64 per wave:
+// kernel start, kernel end, and the sums of s_memtime differences over [wait + barrier], [group-0 prologue], [step loops],
+// [drain + normalise].  No stamp executes in the real kernel.
+#ifdef SFM_ATTNP_STAMPS
+__device__ __forceinline__ unsigned long long attnp_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define ATTNP_T(...) __VA_ARGS__
+#else
+#define ATTNP_T(...)
+#endif
+
 template <class T>
 __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen,
                                                                 int ldqkv, int ldo, int koff, int voff,
@@ -67,6 +83,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   const int prow = wave * 8 + (lane >> 3);
   const int kconst = prow * ldqkv * 2 + koff * 2 + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
   const int vconst = prow * ldqkv * 2 + voff * 2 + (((lane & 7) ^ (((prow >> 1) & 1) << 2)) << 4);
+  // (issuing these pieces one tile per step from inside the step loop instead of as a burst behind the barrier was tried:
+  //  6 % slower - a piece issued between ritems costs the in-order wave more than the same piece in a burst)
   auto issue_group = [&](int item, int g, int half) {              // K/V tiles GT g .. GT g + GT-1 of `item` -> ring half `half`
     const int bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
@@ -215,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     constexpr int V_ = 1 - (U);                                                                                        \
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
     /* ---- region 1: the S chain, with the first 12 exponentials beside it ---- */                                    \
+    ATTNP_PRIO(U)                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     f32x16 sn = T::mfma(ka, qa[U], zero);                                                                              \
     if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
@@ -253,6 +272,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     if (__any(((flag_ | ((FORCE) ? 0x4000u : 0u)) & 0x40004000u) != 0u)) ATTNP_RESCALE(V_, FORCE)                      \
   }
 
+#if SFM_ATTNP_ABL == 2
+  // experiment: the two waves of a SIMD take turns at priority 1, one ritem each
+#define ATTNP_PRIO(U) if ((wave >= 4) == ((U) == 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+#define ATTNP_PRIO(U)
+#endif
 #if SFM_ATTNP_ABL == 4
 #define ATTNP_SCHED1
 #define ATTNP_SCHED2
@@ -316,7 +341,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   };
 
   // the second-dispatched half of the workgroup loses the VALU arbitration against its SIMD partner (priority, then age)
+#if SFM_ATTNP_ABL != 1 && SFM_ATTNP_ABL != 2
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   int gcount = 0;                                                   // groups consumed so far by this workgroup (ring parity)
   if ((int)blockIdx.x < n_items) {
     issue_q(blockIdx.x);
@@ -326,8 +353,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   //      g-1 (barrier; the lgkmcnt(0) covers the V^T reads of the last step, issued before it): refill that half with the
   //      next group of this item or group 0 of the next item; then read the K fragments of the group's first step ----
 #define ATTNP_BOUNDARY(G)                                                                                              \
+  ATTNP_T(const unsigned long long tb0_ = attnp_stamp();)                                                              \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
   __syncthreads();                                                                                                     \
+  ATTNP_T(const unsigned long long tb1_ = attnp_stamp(); t_bar += tb1_ - tb0_;)                                        \
   const int half = gcount & 1;                                                                                         \
   if ((G) + 1 < ngrp) issue_group(item, (G) + 1, half ^ 1);                                                            \
   else if (item + (int)gridDim.x < n_items) issue_group(item + gridDim.x, 0, half ^ 1);                                \
@@ -337,6 +366,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   // the next group's first fragments are read after its barrier)
 #define ATTNP_STEPS(G)                                                                                                 \
   ATTNP_KF_WAIT(0);                                                                                                    \
+  ATTNP_T(const unsigned long long ts0_ = attnp_stamp(); if ((G) == 0) t_pre += ts0_ - tb1_;)                          \
   {                                                                                                                    \
     const int step_end = min(nsteps, ((G) + 1) * 2 * GT);                                                              \
     for (int step = (G) * 2 * GT; step < step_end; ++step) {                                                           \
@@ -346,8 +376,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
       ATTNP_RITEM(0, step, true, false, 0, false, 0, step == 1)                                                        \
       ATTNP_RITEM(1, step, false, true, sbn, true, sbk, step == 0)                                                     \
     }                                                                                                                  \
-  }
+  }                                                                                                                    \
+  ATTNP_T(t_last = attnp_stamp(); t_steps += t_last - ts0_;)
 
+  ATTNP_T(unsigned long long t_bar = 0, t_pre = 0, t_steps = 0, t_post = 0, t_last = 0, t_q = 0, t_so = 0, t_dr = 0; const unsigned long long t_start = attnp_stamp();
+          unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lse_out) + ((size_t)blockIdx.x * 8 + wave) * 8; lse_out = nullptr;)
   const int pad_step = (Tlen & 31) ? nsteps - 1 : -1;               // the only step that can contain padding keys
   ka = u32x4{hl == 0 ? ones2k : 0u, 0u, 0u, 0u};
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -379,7 +412,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
       // in its model and it then waits in every ritem).  The Q region may be reused from here on.
       __builtin_amdgcn_s_waitcnt(0xC07F);
       asm volatile("" ::: "memory");
+      ATTNP_T(const unsigned long long tq_ = attnp_stamp(); t_q += tq_ - tb1_;)
       store_o();                                                    // the previous item's O: drains under this item's math
+      ATTNP_T(t_so += attnp_stamp() - tq_;)
       // pipeline start: nothing pending -> P = 0 (s = -1e30 exponentiates to 0), V^T fragments zero (0 x stale data)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -425,11 +460,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
       ATTNP_PV(0)
       ATTNP_PV(1)
     }
+    ATTNP_T(t_dr += attnp_stamp() - t_last;)
     // ---- normalise and pack; the stores themselves are issued after the next barrier (store_o) ----
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float l = lacc[u][0];
-      const float inv = 1.0f / l;
+      const float inv = __builtin_amdgcn_rcpf(l);                  // 1 ulp; O is rounded to 16 bits
       const int q = q0 + 32 * u + l31;
       if (lse_out && hl == 0 && q < Tlen)
         lse_out[((long long)b * nheads + h) * Tlen + q] = m_run[u] + __builtin_amdgcn_logf(l);
@@ -442,8 +478,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
         }
     }
     st_item = item;
+    ATTNP_T(t_post += attnp_stamp() - t_last;)
   }
   store_o();
+  ATTNP_T(if (lane == 0) { dbg[0] = t_start; dbg[1] = attnp_stamp(); dbg[2] = t_bar; dbg[3] = t_pre; dbg[4] = t_steps; dbg[5] = t_post; dbg[6] = (t_q << 32) | t_so; dbg[7] = t_dr; })
 }
 
 // launch (called by attention.hip's dispatcher): head_dim 64, no dropout, operands below 2 GiB per batch element

@@ -8,7 +8,7 @@ mkdir -p $OUT
 CS=$ROOT/sincformer_metacog_speech_enhancement_amd/csrc
 src=$1; tag=$2; shift 2
 extra=""
-[ "$src" = attention ] && extra="-fno-honor-nans"
+case "$src" in attention|attention_pipe) extra="-fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form";; esac
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -I $CS $extra "$@" -c $CS/$src.hip -o $OUT/${src}_$tag.o
 objs=$(ls $CS/_obj/*.o | grep -v "/$src.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_${src}_$tag.so $objs $OUT/${src}_$tag.o
