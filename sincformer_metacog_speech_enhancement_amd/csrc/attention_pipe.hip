@@ -1,7 +1,11 @@
 // attn_fwd_hd64p: the head_dim-64 attention core (models/conformer.py:66-71 -> nn.MultiheadAttention's softmax(QK^T/sqrt(hd)) V)
-// as a persistent, three-stage software pipeline.  Same data movement as the ring kernel it replaces (one 512-thread
-// workgroup per CU walks (batch, head, 512-query tile) items; K/V by LDS-DMA into a ring of 2 x 3 key tiles, one barrier per
-// 3 key tiles, the next item's Q rows prefetched; O transposed through LDS and stored as whole rows), new arithmetic:
+// as a persistent, three-stage software pipeline.  One 512-thread workgroup per CU walks (batch, head, 512-query tile) items;
+// K/V by LDS-DMA into a ring of 3 groups x 2 key tiles, one barrier per group; the next item's Q rows prefetched; O transposed
+// through LDS and stored as whole rows.  Everything a wave does between two groups - the refill of the ring (the slot it
+// refills was consumed TWO groups ago, so no barrier is needed first), and at the end of an item the next Q fragments, the
+// pipeline drain, normalisation, the O stores and the re-initialisation - comes BEFORE the barrier: the wave of a SIMD that
+// finishes its steps first (static priority) does this work under its partner's MFMA steps instead of idling at the barrier
+// and then doing it in lockstep with the partner (in-kernel stamps: 18 % of a wave's time was such lockstep work).
 //
 //   * a wave owns 64 query rows = two 32-row sub-blocks U = 0, 1 and walks the keys in 32-key steps; one "ritem" per
 //     (step, sub-block).  Ritem r issues, in ONE basic block,
@@ -68,8 +72,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
                                                                 float scale_log2e, int nqt, int nheads, int n_items,
                                                                 float* __restrict__ lse_out, int out_other) {
   constexpr int SLOT = 16384;                                       // one key tile: K 64 x 128 B, then V 64 x 128 B
-  constexpr int GT = 3;                                             // key tiles per group (ring = 2 groups)
-  constexpr int QBASE = 2 * GT * SLOT;                              // Q prefetch region: 8 waves x 64 rows x 128 B
+  constexpr int GT = 2;                                             // key tiles per group
+  constexpr int NSLOT = 3;                                          // group slots of the ring
+  constexpr int QBASE = NSLOT * GT * SLOT;                          // Q prefetch region: 8 waves x 64 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   const int vconst = prow * ldqkv * 2 + voff * 2 + (((lane & 7) ^ (((prow >> 1) & 1) << 2)) << 4);
   // (issuing these pieces one tile per step from inside the step loop instead of as a burst behind the barrier was tried:
   //  6 % slower - a piece issued between ritems costs the in-order wave more than the same piece in a burst)
-  auto issue_group = [&](int item, int g, int half) {              // K/V tiles GT g .. GT g + GT-1 of `item` -> ring half `half`
+  auto issue_group = [&](int item, int g, int half) -> int {       // K/V tiles GT g .. GT g + GT-1 of `item` -> ring slot `half`; returns the DMA pieces issued
+    int np = 0;
     const int bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (long long)b * qkv_batch_stride), 0, rec_bytes, 0x00020000);
@@ -97,8 +103,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
         unsigned char* dst = rsm + (half * GT + tl) * SLOT + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)dst, 16, kconst + off, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)(dst + 8192), 16, vconst + off, 0, 0, 0);
+        np += 2;
       }
     }
+    return np;
   };
   // Q rows of `item` for this wave (64 rows x 128 B, same chunk swizzle as a K tile) -> the wave's 8 KB of the Q region
   auto issue_q = [&](int item) {
@@ -301,13 +309,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   ATTNP_SG(0x008, 1)
 #endif
 
-  // ---- O of the finished item, held in registers until the next item's first barrier has been passed; then transposed
-  //      through the wave's own 8 KB of the Q region (free between the Q fragment reads and the next Q prefetch) so that
-  //      every store instruction writes 8 whole 128-byte rows ----
+  // ---- O of the finished item: transposed through the wave's own 8 KB of the Q region (the next item's Q fragments have
+  //      been read out of it) so that every store instruction writes 8 whole 128-byte rows ----
   uint32_t ow[2][2][4][2];                                          // [sub-block][dj][rq][2 dwords] = 4 consecutive d, 16-bit
-  int st_item = -1;
-  auto store_o = [&]() {
-    if (st_item < 0) return;
+  auto store_o = [&](int st_item) {
     const int qt = st_item % nqt, bh = st_item / nqt;
     const int h = bh % nheads, b = bh / nheads;
     auto ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * o_batch_stride), 0, orec_bytes, 0x00020000);
@@ -337,41 +342,108 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
       const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
       __builtin_amdgcn_raw_buffer_store_b128(v, ors, (qbase + row) * ldo * 2 + h * 128 + ch * 16, 0, 0);
     }
-    st_item = -1;
+  };
+  // Q fragments (B operand: col = query, k = d) of the item whose rows are in the wave's Q region (rows >= Tlen zero-filled)
+  auto load_qf = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        qf[u][ks] = *reinterpret_cast<const u32x4*>(rsm + QBASE + wave * 8192 + u * 4096 + (klane[ks] - lds0));
+    if (scale_log2e != 1.0f) {                                     // callers normally fold the scale into W_q (scale_log2e == 1)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t w = qf[u][ks][e];
+            qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
+          }
+    }
+    // lgkmcnt(0) as a BUILTIN: the compiler must know that its Q loads have landed (behind an asm wait they stay "pending"
+    // in its model and it then waits in every ritem).  The Q region may be reused from here on.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+  };
+  // pipeline start: nothing pending -> P = 0 (s = -1e30 exponentiates to 0), V^T fragments zero (0 x stale data)
+  auto init_state = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      m_run[u] = 0.f;
+      qa[u] = u32x4{0u, hl == 0 ? negbig : 0u, 0u, 0u};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[u][0][r] = 0.f;
+        o[u][1][r] = 0.f;
+        s[u][r] = -1.0e30f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lacc[u][r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) pf[u][s2] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        vt[s2][dj][0] = u32x2{0u, 0u};
+        vt[s2][dj][1] = u32x2{0u, 0u};
+      }
   };
 
   // the second-dispatched half of the workgroup loses the VALU arbitration against its SIMD partner (priority, then age)
 #if SFM_ATTNP_ABL != 1 && SFM_ATTNP_ABL != 2
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
-  int gcount = 0;                                                   // groups consumed so far by this workgroup (ring parity)
+  // ring bookkeeping: `cslot` = slot of the group being consumed; the prefetch cursor (p_item, p_g, pslot) names the next
+  // group to fetch; it runs two groups ahead of the consumer
+  int cslot = 0, pslot = 0;
+  int p_item = blockIdx.x, p_g = 0;
+  auto issue_next_group = [&]() -> int {
+    if (p_item >= n_items) return 0;
+    const int np = issue_group(p_item, p_g, pslot);
+    pslot = (pslot == NSLOT - 1) ? 0 : pslot + 1;
+    if (++p_g == ngrp) { p_g = 0; p_item += gridDim.x; }
+    return np;
+  };
   if ((int)blockIdx.x < n_items) {
     issue_q(blockIdx.x);
-    issue_group(blockIdx.x, 0, 0);
+    issue_next_group();
+    issue_next_group();
   }
-  // ---- group boundary: this wave's pieces of group g have landed (vmcnt), everyone's have and everyone is done with group
-  //      g-1 (barrier; the lgkmcnt(0) covers the V^T reads of the last step, issued before it): refill that half with the
-  //      next group of this item or group 0 of the next item; then read the K fragments of the group's first step ----
-#define ATTNP_BOUNDARY(G)                                                                                              \
+  bool qf_ready = false;                                            // Q fragments of the coming item already in registers
+  int inflight = 0;                                                 // vector-memory operations issued since the pieces the next barrier waits for
+  const int pad_step = (Tlen & 31) ? nsteps - 1 : -1;               // the only step that can contain padding keys
+  ka = u32x4{hl == 0 ? ones2k : 0u, 0u, 0u, 0u};
+  ATTNP_T(unsigned long long t_bar = 0, t_pre = 0, t_steps = 0, t_post = 0, t_last = 0, t_q = 0, t_so = 0, t_dr = 0; const unsigned long long t_start = attnp_stamp();
+          unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lse_out) + ((size_t)blockIdx.x * 8 + wave) * 8; lse_out = nullptr;)
+
+  // ---- group boundary: this wave's pieces of the group to consume have landed - counted vmcnt: the `inflight` youngest
+  //      operations (this wave's refill of another slot, Q prefetch, O stores; all issued after those pieces) may stay in
+  //      flight - then everyone's have (barrier; its lgkmcnt(0) also covers the V^T reads of the last step, issued before).
+  //      Then the K fragments of the group's first step. ----
+#define ATTNP_BOUNDARY()                                                                                               \
   ATTNP_T(const unsigned long long tb0_ = attnp_stamp();)                                                              \
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
-  __syncthreads();                                                                                                     \
+  if (inflight >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                                     \
+  else if (inflight >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                  \
+  else if (inflight >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                  \
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                     \
+  __builtin_amdgcn_s_barrier();            /* raw: __syncthreads() would drain vmcnt to 0 (refill and O stores in flight) */ \
+  asm volatile("" ::: "memory");                                                                                       \
+  inflight = 0;                                                                                                        \
   ATTNP_T(const unsigned long long tb1_ = attnp_stamp(); t_bar += tb1_ - tb0_;)                                        \
-  const int half = gcount & 1;                                                                                         \
-  if ((G) + 1 < ngrp) issue_group(item, (G) + 1, half ^ 1);                                                            \
-  else if (item + (int)gridDim.x < n_items) issue_group(item + gridDim.x, 0, half ^ 1);                                \
-  ++gcount;                                                                                                            \
-  load_kf(half * GT * SLOT);
-  // the steps of group G (the K prefetch of a step beyond the group reads stale ring / Q-region bytes that are never used:
-  // the next group's first fragments are read after its barrier)
-#define ATTNP_STEPS(G)                                                                                                 \
+  load_kf(cslot * GT * SLOT);
+  // the steps of group `g` (the K prefetch of a step beyond the group reads stale ring / Q-region bytes that are never
+  // used: the next group's first fragments are read after its barrier)
+#define ATTNP_STEPS()                                                                                                  \
   ATTNP_KF_WAIT(0);                                                                                                    \
-  ATTNP_T(const unsigned long long ts0_ = attnp_stamp(); if ((G) == 0) t_pre += ts0_ - tb1_;)                          \
+  ATTNP_T(const unsigned long long ts0_ = attnp_stamp();)                                                              \
   {                                                                                                                    \
-    const int step_end = min(nsteps, ((G) + 1) * 2 * GT);                                                              \
-    for (int step = (G) * 2 * GT; step < step_end; ++step) {                                                           \
-      const int sbk = half * GT * SLOT + ((step >> 1) - (G) * GT) * SLOT + (step & 1) * 4096;   /* K rows; V at +8192 */ \
-      const int sbn = half * GT * SLOT + (((step + 1) >> 1) - (G) * GT) * SLOT + ((step + 1) & 1) * 4096;              \
+    const int step_end = min(nsteps, (g + 1) * 2 * GT);                                                                \
+    for (int step = g * 2 * GT; step < step_end; ++step) {                                                             \
+      const int sbk = cslot * GT * SLOT + ((step >> 1) - g * GT) * SLOT + (step & 1) * 4096;   /* K rows; V at +8192 */  \
+      const int sbn = cslot * GT * SLOT + (((step + 1) >> 1) - g * GT) * SLOT + ((step + 1) & 1) * 4096;               \
       ka[1] = (step == pad_step && hl == 0 && step * 32 + l31 >= Tlen) ? one16 : 0u;                                   \
       ATTNP_RITEM(0, step, true, false, 0, false, 0, step == 1)                                                        \
       ATTNP_RITEM(1, step, false, true, sbn, true, sbk, step == 0)                                                     \
@@ -379,76 +451,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   }                                                                                                                    \
   ATTNP_T(t_last = attnp_stamp(); t_steps += t_last - ts0_;)
 
-  ATTNP_T(unsigned long long t_bar = 0, t_pre = 0, t_steps = 0, t_post = 0, t_last = 0, t_q = 0, t_so = 0, t_dr = 0; const unsigned long long t_start = attnp_stamp();
-          unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lse_out) + ((size_t)blockIdx.x * 8 + wave) * 8; lse_out = nullptr;)
-  const int pad_step = (Tlen & 31) ? nsteps - 1 : -1;               // the only step that can contain padding keys
-  ka = u32x4{hl == 0 ? ones2k : 0u, 0u, 0u, 0u};
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int qt = item % nqt, bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
     const int q0 = qt * 512 + wave * 64;
-    {
-      // ---- group 0 (peeled: the packed O of the previous item must not stay live across the group loop) ----
-      ATTNP_BOUNDARY(0)
-      // Q fragments (B operand: col = query, k = d) from the prefetched LDS rows (rows >= Tlen were zero-filled; the vmcnt
-      // wait above covered this wave's own Q pieces, issued an item ago)
+    const bool has_next = item + (int)gridDim.x < n_items;
+    if (!qf_ready) {
+      // first item of the workgroup (or single-group items, below): this wave's own Q pieces have landed -> fragments
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      load_qf();
+      init_state();
+    }
+    for (int g = 0; g < ngrp; ++g) {
+      ATTNP_BOUNDARY()
+      ATTNP_STEPS()
+      // ---- between groups, BEFORE the barrier: refill the slot that was consumed two groups ago; after the first group
+      //      of an item also fetch the next item's Q rows (the wave's Q region is free: the O read-back finished long ago) ----
+      if (g == 0 && ngrp > 1 && has_next) {
+        issue_q(item + gridDim.x);
+        inflight += 8;
+      }
+      if (g + 1 < ngrp) inflight += issue_next_group();
+      cslot = (cslot == NSLOT - 1) ? 0 : cslot + 1;
+    }
+    // ---- end of the item ----
+    qf_ready = false;
+    if (ngrp > 1 && has_next) {
+      // the next item's Q fragments: its rows were fetched a group or more ago (operations issued after them: >= one refill)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");             // (a refill is 2 or 4 pieces)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           qf[u][ks] = *reinterpret_cast<const u32x4*>(rsm + QBASE + wave * 8192 + u * 4096 + (klane[ks] - lds0));
-      if (scale_log2e != 1.0f) {                                   // callers normally fold the scale into W_q (scale_log2e == 1)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const uint32_t w = qf[u][ks][e];
-              qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
-            }
-      }
-      // lgkmcnt(0) as a BUILTIN: the compiler must know that its Q loads have landed (behind an asm wait they stay "pending"
-      // in its model and it then waits in every ritem).  The Q region may be reused from here on.
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      asm volatile("" ::: "memory");
-      ATTNP_T(const unsigned long long tq_ = attnp_stamp(); t_q += tq_ - tb1_;)
-      store_o();                                                    // the previous item's O: drains under this item's math
-      ATTNP_T(t_so += attnp_stamp() - tq_;)
-      // pipeline start: nothing pending -> P = 0 (s = -1e30 exponentiates to 0), V^T fragments zero (0 x stale data)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        m_run[u] = 0.f;
-        qa[u] = u32x4{0u, hl == 0 ? negbig : 0u, 0u, 0u};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          o[u][0][r] = 0.f;
-          o[u][1][r] = 0.f;
-          s[u][r] = -1.0e30f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lacc[u][r] = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) pf[u][s2] = u32x4{0u, 0u, 0u, 0u};
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-          vt[s2][dj][0] = u32x2{0u, 0u};
-          vt[s2][dj][1] = u32x2{0u, 0u};
-        }
-      // the next item's Q rows -> this wave's own region (its last LDS accesses, the O read-back, have completed)
-      if (ngrp == 1 && item + (int)gridDim.x < n_items) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_q(item + gridDim.x);
-      }
-      ATTNP_STEPS(0)
-    }
-    for (int g = 1; g < ngrp; ++g) {
-      ATTNP_BOUNDARY(g)
-      if (g == 1 && item + (int)gridDim.x < n_items) issue_q(item + gridDim.x);
-      ATTNP_STEPS(g)
+      qf_ready = true;
     }
     // ---- drain: exponentials of the last block of sub-block 1, then the two pending PV products ----
     {
@@ -472,15 +508,50 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
 #pragma unroll
       for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          ow[u][dj][rq][0] = attnp_pack2_o<T>(o[u][dj][4 * rq + 0] * inv, o[u][dj][4 * rq + 1] * inv, out_other != 0);
-          ow[u][dj][rq][1] = attnp_pack2_o<T>(o[u][dj][4 * rq + 2] * inv, o[u][dj][4 * rq + 3] * inv, out_other != 0);
-        }
+        for (int r = 0; r < 16; ++r) o[u][dj][r] *= inv;
     }
-    st_item = item;
+    // ONE branch on the output format around the 32 packing converts (a select per convert compiles to a branch per convert)
+#define ATTNP_PACK_O(PK)                                                                                               \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                        \
+  _Pragma("unroll") for (int dj = 0; dj < 2; ++dj)                                                                     \
+  _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                                                                   \
+    ow[u][dj][rq][0] = PK(o[u][dj][4 * rq + 0], o[u][dj][4 * rq + 1]);                                                 \
+    ow[u][dj][rq][1] = PK(o[u][dj][4 * rq + 2], o[u][dj][4 * rq + 3]);                                                 \
+  }
+    if ((out_other != 0) == (T::id == SFM_DT_BF16)) { ATTNP_PACK_O(F16::pack) } else { ATTNP_PACK_O(BF16::pack) }
+    ATTNP_T(const unsigned long long tso_ = attnp_stamp();)
+    if (qf_ready) {
+      if (scale_log2e != 1.0f) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t w = qf[u][ks][e];
+              qf[u][ks][e] = pack2<T>(T::to_f32((u16)(w & 0xffffu)) * scale_log2e, T::to_f32((u16)(w >> 16)) * scale_log2e);
+            }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);                           // (builtin: see load_qf) the Q region is free now
+      asm volatile("" ::: "memory");
+    }
+    store_o(item);                                                  // 8 stores, left in flight across the next barrier
+    inflight += 8;
+    ATTNP_T(t_so += attnp_stamp() - tso_;)
+    if (has_next) {
+      if (ngrp == 1) {                                              // single-group items: no room for the Q prefetch earlier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_q(item + gridDim.x);
+        inflight = 0;                                               // (conservative: the next boundary waits for everything)
+      }
+      if (qf_ready) init_state();
+    }
+    {
+      const int np = issue_next_group();                            // the refill that belongs to the item's last group
+      inflight = (ngrp == 1) ? 0 : inflight + np;
+    }
     ATTNP_T(t_post += attnp_stamp() - t_last;)
   }
-  store_o();
   ATTNP_T(if (lane == 0) { dbg[0] = t_start; dbg[1] = attnp_stamp(); dbg[2] = t_bar; dbg[3] = t_pre; dbg[4] = t_steps; dbg[5] = t_post; dbg[6] = (t_q << 32) | t_so; dbg[7] = t_dr; })
 }
 
@@ -499,7 +570,7 @@ int sfm_attn_pipe_launch(const void* qkv, void* out, float* lse, int B, int T, i
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SFM_ERR_LAUNCH;
     ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  constexpr int lds = 6 * 16384 + 65536;                            // K/V ring + Q prefetch region = 160 KB
+  constexpr int lds = 6 * 16384 + 65536;                            // K/V ring (3 x 2 tiles) + Q prefetch region = 160 KB
   const int ti = dtype == SFM_DT_F16 ? 1 : 0;
   if (!attr_set[dev][ti]) {
     const void* fn = ti ? (const void*)attn_fwd_hd64p_kernel<F16> : (const void*)attn_fwd_hd64p_kernel<BF16>;
