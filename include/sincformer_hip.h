@@ -115,18 +115,18 @@ int sfm_framed_gemm_f32(const float* sig, const float* Wt, const float* bias, vo
  * nn.MultiheadAttention (models/conformer.py:69).  qkv [B,T,ldqkv] 16-bit with
  * q at column h*hd, k at koff+h*hd, v at voff+h*hd; out [B,T,ldo] 16-bit at h*hd.
  * scale <= 0 means Q is pre-multiplied by softmax_scale*log2(e) (folded into W_q/b_q). */
-/* head_dim-64 kernel selection (diagnostics / A-B measurements): 0 = by shape (default: the persistent ring kernel
- * attn_fwd_hd64r for 256 < T <= 512 and T >= 1024, 32 query rows per wave otherwise), 1 = always 32 query rows per wave,
- * 3 (or 2) = always the persistent ring kernel. */
-int sfm_attention_set_variant(int v);
 int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                       int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
                       float scale, int dtype, void* stream);
 /* Same, with the result written in `out_dtype` (SFM_DT_BF16 / SFM_DT_F16) when it differs from the operands' `dtype`
- * (precision policy: a bf16 attention core behind fp16 projections; head_dim 64 kernels only). */
+ * (precision policy: a bf16 attention core behind fp16 projections; head_dim 64 kernels only), and with the head_dim-64
+ * kernel chosen per call by `variant` (A/B measurements; the library keeps no selection state): 0 = by shape (the pipelined
+ * persistent kernel attn_fwd_hd64p for T 400..512, 800..1024 and >= 1024 with 512-row query tiles, for T 231..256 with 256-row
+ * tiles; 32 query rows per wave otherwise), 1 = always 32 query rows per wave, 3 (or 2) = the persistent ring kernel of
+ * round 2, 4 / 5 = the pipelined persistent kernel with one 8-wave / two 4-wave workgroups per CU. */
 int sfm_attention_fwd_ex(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                          int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
-                         float scale, int dtype, int out_dtype, void* stream);
+                         float scale, int dtype, int out_dtype, int variant, void* stream);
 
 /* nn.LayerNorm (+ optional erf GELU when act==1): models/conformer.py:43,68,107,150;
  * agents/msa.py:44-47; training/conformer_pipeline.py:274,282. */

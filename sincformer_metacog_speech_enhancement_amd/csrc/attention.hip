@@ -755,25 +755,21 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const u16* __rest
   }
 }
 
-// kernel selection for the head_dim 64 no-dropout path: 0 = by shape (persistent ring kernel for 256 < T <= 512 and
-// T >= 1024, 32 query rows per wave otherwise), 1 = always 32 rows per wave (attn_fwd_hd64), 3 = always the persistent ring
-// kernel (attn_fwd_hd64r); 2 (the former 64-rows-per-wave kernel, superseded by the ring kernel) is accepted as 3
-// 4 = the pipelined persistent kernel attn_fwd_hd64p (attention_pipe.hip), which auto now picks wherever it picked the ring kernel
-static int sfm_attn_variant = 0;
-extern "C" int sfm_attention_set_variant(int v) {
-  if (v < 0 || v > 4) return SFM_ERR_ARG;
-  sfm_attn_variant = (v == 2) ? 3 : v;
-  return SFM_OK;
-}
+// kernel selection for the head_dim 64 no-dropout path, the `variant` argument of sfm_attention_fwd_ex (a per-call argument: the
+// library keeps no state): 0 = by shape (below), 1 = always 32 query rows per wave (attn_fwd_hd64), 3 = the persistent ring
+// kernel of round 2 (attn_fwd_hd64r; 2 is accepted as 3), 4 / 5 = the pipelined persistent kernel attn_fwd_hd64p
+// (attention_pipe.hip) with one 8-wave / two 4-wave workgroups per CU
 int sfm_attn_pipe_launch(const void* qkv, void* out, float* lse, int B, int T, int H, int ldqkv, int ldo, int koff, int voff,
-                         long long qkv_batch_stride, long long o_batch_stride, float sl2, int dtype, int out_other,
+                         long long qkv_batch_stride, long long o_batch_stride, float sl2, int dtype, int out_other, int nw,
                          hipStream_t st);
 
 // qkv: [B, T, ldqkv] 16-bit with q at column h*hd, k at koff + h*hd, v at voff + h*hd.
 static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int T, int H, int hd, int ldqkv, int ldo, int koff,
                               int voff, long long qkv_batch_stride, long long o_batch_stride, float scale, float p_drop,
-                              unsigned int seed, int dtype, int out_dtype, void* stream) {
+                              unsigned int seed, int dtype, int out_dtype, int variant, void* stream) {
   if (!qkv || !out) return SFM_ERR_ARG;
+  if (variant < 0 || variant > 5) return SFM_ERR_ARG;
+  const int sfm_attn_variant = (variant == 2) ? 3 : variant;
   if (p_drop < 0.f || p_drop >= 1.f) return SFM_ERR_SHAPE;
   if ((lse || p_drop > 0.f) && (qkv_batch_stride != (long long)T * ldqkv)) return SFM_ERR_SHAPE;
   if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 256) return SFM_ERR_SHAPE;
@@ -784,31 +780,39 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
       (qkv_batch_stride % 8) == 0 && (o_batch_stride % 8) == 0) {
     // scale <= 0: Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
     float sl2 = (scale > 0.f) ? scale * 1.44269504088896340736f : 1.0f;
-    // persistent ring kernel (512-row query tiles): auto for 256 < T <= 512 and for T >= 1024 when there is at least half an
-    // item per CU (in between, the second query tile of a (batch, head) would be mostly padding); variant 3 forces it
+    // pipelined persistent kernel (attention_pipe.hip): by measured shape window (tools/attn_ab.py, profiles/README.md) - query
+    // tiles of 512 rows (one 8-wave workgroup per CU) when at least 78 % of the tile rows are real (T 400..512, 800..1024) and
+    // for every T >= 1024 (its step loop is 15-20 % faster than the 32-rows-per-wave kernel's: 1.0 PFLOP/s at T 6001); tiles
+    // of 256 rows (two 4-wave workgroups per CU) for T 231..256; the 32-rows-per-wave kernel otherwise and for short launches
     const long long bytes_q = (long long)T * ldqkv * 2, bytes_o = (long long)T * ldo * 2;
     const int nqt5 = (T + 511) / 512;
-    const bool ring_auto = ((T > 256 && T <= 512) || T >= 1024) && (long long)B * H * nqt5 >= 128;
+    const bool enough = (long long)B * H * nqt5 >= 128;
+    const bool pipe8_auto = enough && (T >= 1024 || 100 * T >= 78 * 512 * nqt5);
+    const bool pipe4_auto = enough && !pipe8_auto && T <= 256 && 100 * T >= 90 * 256;
+    const bool ring_auto = pipe8_auto || pipe4_auto;
     if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) &&
-        (sfm_attn_variant == 4 || (sfm_attn_variant == 0 && ring_auto)))
+        (sfm_attn_variant == 4 || sfm_attn_variant == 5 || (sfm_attn_variant == 0 && ring_auto)))
       return sfm_attn_pipe_launch(qkv, out, lse, B, T, H, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, sl2, dtype,
-                                  out_other, st);
+                                  out_other, (sfm_attn_variant == 5 || (sfm_attn_variant == 0 && pipe4_auto)) ? 4 : 8, st);
     if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) && sfm_attn_variant == 3) {
       const int n_items = nqt5 * H * B;
-      static int ncu = 0;
-      if (ncu == 0) {
-        int dev = 0;
+      // (CU count and the dynamic-LDS attribute are per device: caches keyed by hipGetDevice())
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
+      static int ncus[64] = {0};
+      if (ncus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SFM_ERR_LAUNCH;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SFM_ERR_LAUNCH;
+        ncus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       }
+      const int ncu = ncus[dev];
       constexpr int lds = 6 * 16384 + 65536;                        // K/V ring + Q prefetch region = 160 KB
-      static bool attr_set[2] = {false, false};
+      static bool attr_set[64][2] = {{false, false}};
       const int ti = dtype == SFM_DT_F16 ? 1 : 0;
-      if (!attr_set[ti]) {
+      if (!attr_set[dev][ti]) {
         const void* fn = ti ? (const void*)attn_fwd_hd64r_kernel<F16> : (const void*)attn_fwd_hd64r_kernel<BF16>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SFM_ERR_LAUNCH;
-        attr_set[ti] = true;
+        attr_set[dev][ti] = true;
       }
       dim3 gridr(n_items < ncu ? n_items : ncu), blockr(512);
       if (dtype == SFM_DT_F16)
@@ -846,15 +850,16 @@ extern "C" int sfm_attention_fwd(const void* qkv, void* out, int B, int T, int H
                                  int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
                                  float scale, int dtype, void* stream) {
   return attention_fwd_impl(qkv, out, nullptr, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride,
-                            scale, 0.f, 0u, dtype, dtype, stream);
+                            scale, 0.f, 0u, dtype, dtype, 0, stream);
 }
 
-// sfm_attention_fwd with the result written in `out_dtype` (SFM_DT_BF16 / SFM_DT_F16), which may differ from the operands' `dtype`
+// sfm_attention_fwd with the result written in `out_dtype` (SFM_DT_BF16 / SFM_DT_F16), which may differ from the operands' `dtype`,
+// and with the kernel chosen by `variant` (0 = by shape)
 extern "C" int sfm_attention_fwd_ex(const void* qkv, void* out, int B, int T, int H, int hd, int ldqkv, int ldo,
                                     int koff, int voff, long long qkv_batch_stride, long long o_batch_stride,
-                                    float scale, int dtype, int out_dtype, void* stream) {
+                                    float scale, int dtype, int out_dtype, int variant, void* stream) {
   return attention_fwd_impl(qkv, out, nullptr, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride,
-                            scale, 0.f, 0u, dtype, out_dtype, stream);
+                            scale, 0.f, 0u, dtype, out_dtype, variant, stream);
 }
 
 // training-mode forward: also writes lse [B,H,T] (log2 domain) and applies attention dropout
@@ -863,5 +868,5 @@ extern "C" int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, i
                                        long long o_batch_stride, float scale, float p_drop, unsigned int seed,
                                        int dtype, void* stream) {
   return attention_fwd_impl(qkv, out, lse, B, T, H, hd, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale,
-                            p_drop, seed, dtype, dtype, stream);
+                            p_drop, seed, dtype, dtype, 0, stream);
 }

@@ -65,16 +65,19 @@ __device__ __forceinline__ unsigned long long attnp_stamp() {
 #define ATTNP_T(...)
 #endif
 
-template <class T>
-__global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen,
-                                                                int ldqkv, int ldo, int koff, int voff,
-                                                                long long qkv_batch_stride, long long o_batch_stride,
-                                                                float scale_log2e, int nqt, int nheads, int n_items,
-                                                                float* __restrict__ lse_out, int out_other) {
+// NW = waves per workgroup (8: one workgroup per CU, items of 512 query rows, ring of 3 x 2 key tiles; 4: TWO workgroups per
+// CU, items of 256 query rows, ring of 3 x 1 key tile, 80 KB of LDS each - the two waves of a SIMD then belong to different
+// workgroups and never wait for each other at a barrier; K/V are streamed twice per 512 query rows instead of once)
+template <class T, int NW>
+__device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen, int ldqkv, int ldo, int koff,
+                                           int voff, long long qkv_batch_stride, long long o_batch_stride, float scale_log2e,
+                                           int nqt, int nheads, int n_items, float* __restrict__ lse_out, int out_other) {
   constexpr int SLOT = 16384;                                       // one key tile: K 64 x 128 B, then V 64 x 128 B
-  constexpr int GT = 2;                                             // key tiles per group
+  constexpr int GT = NW / 4;                                        // key tiles per group
   constexpr int NSLOT = 3;                                          // group slots of the ring
-  constexpr int QBASE = NSLOT * GT * SLOT;                          // Q prefetch region: 8 waves x 64 rows x 128 B
+  constexpr int QBASE = NSLOT * GT * SLOT;                          // Q prefetch region: NW waves x 64 rows x 128 B
+  constexpr int QROWS = 64 * NW;                                    // query rows of an item
+  constexpr int RPW = 64 / NW;                                      // rows of a key tile this wave fetches (8 per DMA instruction)
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,8 +88,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   const int orec_bytes = Tlen * ldo * 2;
 
   // ---- LDS-DMA lane constants: an instruction moves 8 rows x 128 B; this wave owns rows 8*wave .. 8*wave+7 of every tile ----
-  const int prow = wave * 8 + (lane >> 3);
-  const int kconst = prow * ldqkv * 2 + koff * 2 + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+  // (K chunk swizzle = (row >> 1) & 7: period 16 rows, so each of the wave's 8-row pieces has its own lane constant; the V
+  //  swizzle ((row >> 1) & 1) << 2 has period 4: one constant, the piece enters through the row offset)
+  const int prow = wave * RPW + (lane >> 3);
+  int kconst[RPW / 8];
+#pragma unroll
+  for (int pc = 0; pc < RPW / 8; ++pc)
+    kconst[pc] = (prow + 8 * pc) * ldqkv * 2 + koff * 2 + (((lane & 7) ^ (((prow + 8 * pc) >> 1) & 7)) << 4);
   const int vconst = prow * ldqkv * 2 + voff * 2 + (((lane & 7) ^ (((prow >> 1) & 1) << 2)) << 4);
   // (issuing these pieces one tile per step from inside the step loop instead of as a burst behind the barrier was tried:
   //  6 % slower - a piece issued between ritems costs the in-order wave more than the same piece in a burst)
@@ -100,10 +108,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
       const int kt = g * GT + tl;
       if (kt < nkt) {
         const int off = kt * 64 * ldqkv * 2 + h * 128;
-        unsigned char* dst = rsm + (half * GT + tl) * SLOT + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)dst, 16, kconst + off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)(dst + 8192), 16, vconst + off, 0, 0, 0);
-        np += 2;
+        unsigned char* dst = rsm + (half * GT + tl) * SLOT + wave * (RPW * 128);
+#pragma unroll
+        for (int pc = 0; pc < RPW / 8; ++pc) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)(dst + pc * 1024), 16, kconst[pc] + off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attnp_lds_ptr_t)(dst + pc * 1024 + 8192), 16, vconst + off + pc * 8 * ldqkv * 2, 0, 0, 0);
+        }
+        np += 2 * (RPW / 8);
       }
     }
     return np;
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     const int qt = item % nqt, bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (long long)b * qkv_batch_stride), 0, rec_bytes, 0x00020000);
-    const int off = (qt * 512 + wave * 64) * ldqkv * 2 + h * 128;
+    const int off = (qt * QROWS + wave * 64) * ldqkv * 2 + h * 128;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = ((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 4;
@@ -334,13 +345,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): the wave's own image is complete
     __builtin_amdgcn_wave_barrier();
-    const int qbase = qt * 512 + wave * 64;
+    const int qbase = qt * QROWS + wave * 64;
+    // all eight row reads first (one LDS round trip; the compiler otherwise pairs read, read, store, store: four round trips)
+    u32x4 rv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = ln + 64 * i;
       const int row = c >> 3, ch = c & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-      __builtin_amdgcn_raw_buffer_store_b128(v, ors, (qbase + row) * ldo * 2 + h * 128 + ch * 16, 0, 0);
+      rv[i] = *reinterpret_cast<const u32x4*>(ob + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ln + 64 * i;
+      const int row = c >> 3, ch = c & 7;
+      __builtin_amdgcn_raw_buffer_store_b128(rv[i], ors, (qbase + row) * ldo * 2 + h * 128 + ch * 16, 0, 0);
     }
   };
   // Q fragments (B operand: col = query, k = d) of the item whose rows are in the wave's Q region (rows >= Tlen zero-filled)
@@ -394,12 +413,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
 
   // the second-dispatched half of the workgroup loses the VALU arbitration against its SIMD partner (priority, then age)
 #if SFM_ATTNP_ABL != 1 && SFM_ATTNP_ABL != 2
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   // ring bookkeeping: `cslot` = slot of the group being consumed; the prefetch cursor (p_item, p_g, pslot) names the next
   // group to fetch; it runs two groups ahead of the consumer
+  // XCD-aware item order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of virtual ids so
+  // that the query tiles of one (batch, head) - consecutive items - share an L2 (placement is a speed matter only)
+  const int nwg = gridDim.x;
+  const int vid = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   int cslot = 0, pslot = 0;
-  int p_item = blockIdx.x, p_g = 0;
+  int p_item = vid, p_g = 0;
   auto issue_next_group = [&]() -> int {
     if (p_item >= n_items) return 0;
     const int np = issue_group(p_item, p_g, pslot);
@@ -407,8 +430,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
     if (++p_g == ngrp) { p_g = 0; p_item += gridDim.x; }
     return np;
   };
-  if ((int)blockIdx.x < n_items) {
-    issue_q(blockIdx.x);
+  if (vid < n_items) {
+    issue_q(vid);
     issue_next_group();
     issue_next_group();
   }
@@ -417,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   const int pad_step = (Tlen & 31) ? nsteps - 1 : -1;               // the only step that can contain padding keys
   ka = u32x4{hl == 0 ? ones2k : 0u, 0u, 0u, 0u};
   ATTNP_T(unsigned long long t_bar = 0, t_pre = 0, t_steps = 0, t_post = 0, t_last = 0, t_q = 0, t_so = 0, t_dr = 0; const unsigned long long t_start = attnp_stamp();
-          unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lse_out) + ((size_t)blockIdx.x * 8 + wave) * 8; lse_out = nullptr;)
+          unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lse_out) + ((size_t)blockIdx.x * NW + wave) * 8; lse_out = nullptr;)
 
   // ---- group boundary: this wave's pieces of the group to consume have landed - counted vmcnt: the `inflight` youngest
   //      operations (this wave's refill of another slot, Q prefetch, O stores; all issued after those pieces) may stay in
@@ -451,10 +474,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   }                                                                                                                    \
   ATTNP_T(t_last = attnp_stamp(); t_steps += t_last - ts0_;)
 
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  for (int item = vid; item < n_items; item += gridDim.x) {
     const int qt = item % nqt, bh = item / nqt;
     const int h = bh % nheads, b = bh / nheads;
-    const int q0 = qt * 512 + wave * 64;
+    const int q0 = qt * QROWS + wave * 64;
     const bool has_next = item + (int)gridDim.x < n_items;
     if (!qf_ready) {
       // first item of the workgroup (or single-group items, below): this wave's own Q pieces have landed -> fragments
@@ -555,34 +578,63 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd64p_kernel(const u16* __res
   ATTNP_T(if (lane == 0) { dbg[0] = t_start; dbg[1] = attnp_stamp(); dbg[2] = t_bar; dbg[3] = t_pre; dbg[4] = t_steps; dbg[5] = t_post; dbg[6] = (t_q << 32) | t_so; dbg[7] = t_dr; })
 }
 
-// launch (called by attention.hip's dispatcher): head_dim 64, no dropout, operands below 2 GiB per batch element
-int sfm_attn_pipe_launch(const void* qkv, void* out, float* lse, int B, int T, int H, int ldqkv, int ldo, int koff, int voff,
-                         long long qkv_batch_stride, long long o_batch_stride, float sl2, int dtype, int out_other,
-                         hipStream_t st) {
-  const int nqt5 = (T + 511) / 512;
-  const int n_items = nqt5 * H * B;
+// (the launch bounds cannot depend on a template parameter with this hipcc: two thin kernels around the body)
+template <class T>
+__global__ __launch_bounds__(512, 2) void attn_fwd_hd64p8_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen, int ldqkv,
+                                                                 int ldo, int koff, int voff, long long qkv_batch_stride,
+                                                                 long long o_batch_stride, float scale_log2e, int nqt, int nheads,
+                                                                 int n_items, float* __restrict__ lse_out, int out_other) {
+  attnp_body<T, 8>(qkv, out, Tlen, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale_log2e, nqt, nheads, n_items, lse_out,
+                   out_other);
+}
+template <class T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_hd64p4_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int Tlen, int ldqkv,
+                                                                 int ldo, int koff, int voff, long long qkv_batch_stride,
+                                                                 long long o_batch_stride, float scale_log2e, int nqt, int nheads,
+                                                                 int n_items, float* __restrict__ lse_out, int out_other) {
+  attnp_body<T, 4>(qkv, out, Tlen, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, scale_log2e, nqt, nheads, n_items, lse_out,
+                   out_other);
+}
+
+// launch (called by attention.hip's dispatcher): head_dim 64, no dropout, operands below 2 GiB per batch element.
+// nw = 8: one 512-thread workgroup per CU; nw = 4: two 256-thread workgroups per CU
+template <class T, int NW>
+static int attnp_launch(const void* qkv, void* out, float* lse, int B, int Tlen, int H, int ldqkv, int ldo, int koff, int voff,
+                        long long qkv_batch_stride, long long o_batch_stride, float sl2, int out_other, hipStream_t st) {
+  const int nqt = (Tlen + 64 * NW - 1) / (64 * NW);
+  const int n_items = nqt * H * B;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
   static int ncu[64] = {0};
-  static bool attr_set[64][2] = {{false, false}};
+  static bool attr_set[64] = {false};
   if (ncu[dev] == 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SFM_ERR_LAUNCH;
     ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  constexpr int lds = 6 * 16384 + 65536;                            // K/V ring (3 x 2 tiles) + Q prefetch region = 160 KB
-  const int ti = dtype == SFM_DT_F16 ? 1 : 0;
-  if (!attr_set[dev][ti]) {
-    const void* fn = ti ? (const void*)attn_fwd_hd64p_kernel<F16> : (const void*)attn_fwd_hd64p_kernel<BF16>;
+  constexpr int lds = 3 * (NW / 4) * 16384 + NW * 8192;             // K/V ring + Q prefetch region: 160 KB (NW 8) / 80 KB (NW 4)
+  const void* fn = NW == 8 ? (const void*)attn_fwd_hd64p8_kernel<T> : (const void*)attn_fwd_hd64p4_kernel<T>;
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SFM_ERR_LAUNCH;
-    attr_set[dev][ti] = true;
+    attr_set[dev] = true;
   }
-  dim3 gridr(n_items < ncu[dev] ? n_items : ncu[dev]), blockr(512);
-  if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((attn_fwd_hd64p_kernel<F16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
-               qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
+  const int resident = ncu[dev] * (8 / NW);
+  dim3 gridr(n_items < resident ? n_items : resident), blockr(64 * NW);
+  if (NW == 8)
+    SFM_LAUNCH((attn_fwd_hd64p8_kernel<T>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, Tlen, ldqkv, ldo, koff, voff,
+               qkv_batch_stride, o_batch_stride, sl2, nqt, H, n_items, lse, out_other);
   else
-    SFM_LAUNCH((attn_fwd_hd64p_kernel<BF16>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, T, ldqkv, ldo, koff, voff,
-               qkv_batch_stride, o_batch_stride, sl2, nqt5, H, n_items, lse, out_other);
+    SFM_LAUNCH((attn_fwd_hd64p4_kernel<T>), gridr, blockr, lds, st, (const u16*)qkv, (u16*)out, Tlen, ldqkv, ldo, koff, voff,
+               qkv_batch_stride, o_batch_stride, sl2, nqt, H, n_items, lse, out_other);
   return SFM_OK;
 }
+
+int sfm_attn_pipe_launch(const void* qkv, void* out, float* lse, int B, int T, int H, int ldqkv, int ldo, int koff, int voff,
+                         long long qkv_batch_stride, long long o_batch_stride, float sl2, int dtype, int out_other, int nw,
+                         hipStream_t st) {
+#define ATTNP_GO(TT, NW_) return attnp_launch<TT, NW_>(qkv, out, lse, B, T, H, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, sl2, out_other, st)
+  if (dtype == SFM_DT_F16) { if (nw == 4) ATTNP_GO(F16, 4); else ATTNP_GO(F16, 8); }
+  else { if (nw == 4) ATTNP_GO(BF16, 4); else ATTNP_GO(BF16, 8); }
+#undef ATTNP_GO
+}
+

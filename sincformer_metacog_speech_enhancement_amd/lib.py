@@ -34,7 +34,7 @@ SIGNATURES = {
     "sfm_framed_gemm_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i,
                             c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_vp],
     "sfm_attention_fwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_vp],
-    "sfm_attention_fwd_ex": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_i, c_vp],
+    "sfm_attention_fwd_ex": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_i, c_i, c_i, c_vp],
     "sfm_layernorm": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_vp],
     "sfm_gn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_f, c_vp],
     "sfm_gn_apply": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp],
@@ -69,7 +69,6 @@ SIGNATURES = {
     "sfm_spec_loss_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_ll, c_i, c_i, c_f, c_vp],
     "sfm_stft_adjoint_ola": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_polar_mask_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_f, c_ll, c_ll, c_vp],
-    "sfm_attention_set_variant": [c_i],
     "sfm_attention_bwd_generic": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_i,
                                   c_vp],
     "sfm_ssnr_frames": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp],

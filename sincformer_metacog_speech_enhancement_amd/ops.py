@@ -466,8 +466,16 @@ ATTN_QSCALE_LOG2E = 1.4426950408889634
 
 
 def set_attention_variant(v):
-    """0: chosen by shape (default), 1: 32 query rows per wave, 3: persistent ring kernel (A/B measurements)."""
-    _lib.check(_lib.load().sfm_attention_set_variant(int(v)), "attention_set_variant")
+    """0: chosen by shape (default), 1: 32 query rows per wave, 3: persistent ring kernel, 4 / 5: pipelined persistent kernel
+    with one 8-wave / two 4-wave workgroups per CU (A/B measurements).  Host-side state only: the value is passed to
+    sfm_attention_fwd_ex with every call (the library keeps no selection state)."""
+    v = int(v)
+    if not 0 <= v <= 5:
+        raise ValueError("attention variant %d" % v)
+    _ATTN_VARIANT[0] = v
+
+
+_ATTN_VARIANT = [0]
 
 
 def attention(qkv16, B, T, H, hd, out=None, prescaled=False, out_dtype=None):
@@ -483,7 +491,7 @@ def attention(qkv16, B, T, H, hd, out=None, prescaled=False, out_dtype=None):
         out = torch.empty(B * T, D, device=qkv16.device, dtype=out_dtype or qkv16.dtype)
     _call("attention_fwd", L.sfm_attention_fwd_ex, (_p(qkv16), _p(out), B, T, H, hd, ld, out.stride(0), D, 2 * D, T * ld,
                                                     T * out.stride(0), (-1.0 if prescaled else 1.0 / math.sqrt(hd)), _dt(),
-                                                    _DT_ID[out.dtype], _stream()),
+                                                    _DT_ID[out.dtype], _ATTN_VARIANT[0], _stream()),
           *_cost_of("attention_fwd", locals()))
     return out
 

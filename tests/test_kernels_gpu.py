@@ -350,7 +350,7 @@ def _attn_ref(qkv, B, T, H, hd):
     return (p @ v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])       # the head_dim-64 kernels: 32 query rows per wave / persistent ring / pipelined persistent
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])       # the head_dim-64 kernels: 32 query rows per wave / persistent ring / pipelined persistent
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,T,H,hd", [(2, 200, 4, 64), (1, 64, 4, 64), (3, 1, 2, 64), (1, 801, 4, 64), (2, 129, 1, 64),
                                       (1, 1100, 2, 64), (2, 20, 4, 16), (1, 37, 2, 32)])
@@ -366,7 +366,7 @@ def test_attention(ops, dt, B, T, H, hd, variant):
     report("attention v%d %s B%d T%d H%d hd%d" % (variant, dt, B, T, H, hd), out.float().cpu(), ref, 6 * EPS[dt])
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_attention_persistent_kernel_walks_several_items_per_workgroup(ops, variant):
     """more (batch, head, query tile) items than CUs: every workgroup of the ring kernel handles two items, the second one's
     Q / first K,V group prefetched under the first; ragged T (keys and query rows beyond T are zero-filled / dropped by the
@@ -383,7 +383,7 @@ def test_attention_persistent_kernel_walks_several_items_per_workgroup(ops, vari
     report("attention persistent v%d, 320 items" % variant, out.float().cpu(), ref, 6 * EPS[torch.bfloat16])
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 def test_attention_result_in_the_other_16bit_format(ops, variant):
     """precision policy: bf16 attention core, O written as fp16 (and the reverse)"""
     B, T, H, hd = 2, 300, 4, 64
@@ -400,7 +400,7 @@ def test_attention_result_in_the_other_16bit_format(ops, variant):
         report("attention v%d %s -> %s" % (variant, dt, odt), out.float().cpu(), ref, 6 * max(EPS[dt], EPS[odt]))
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 def test_attention_online_softmax_rescale(ops, variant):
     """a spiked key late in the sequence forces the running-max rescale branch"""
     ops.set_compute_dtype(torch.float16)

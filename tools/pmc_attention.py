@@ -11,7 +11,7 @@ for path in sys.argv[2:]:
         k = r["Kernel_Name"]
         if "attn_fwd" not in k:
             continue
-        name = "attn_fwd_hd64p" if "hd64p" in k else "attn_fwd_hd64r" if "hd64r" in k else ("attn_fwd_hd64x2" if "x2" in k else "attn_fwd_hd64")
+        name = "attn_fwd_hd64p4" if "hd64p4" in k else "attn_fwd_hd64p8" if "hd64p8" in k else "attn_fwd_hd64r" if "hd64r" in k else ("attn_fwd_hd64x2" if "x2" in k else "attn_fwd_hd64")
         a = acc[name][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
