@@ -69,6 +69,10 @@ class FlatGradSynchronizer:
             off += p.numel()
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
+        # optional measurement (bench.py): HIP events around the wait in finish() = the time the compute stream is held up by
+        # the exchange, i.e. the part of the all-reduce that did NOT overlap the backward pass
+        self.time_exposed = False
+        self._exposed_events = []
 
     # -- overlap machinery ---------------------------------------------------------------------------------------
     def _launch(self, b):
@@ -109,12 +113,33 @@ class FlatGradSynchronizer:
         their unscale factor, see optim.FlatAdamW)."""
         self.set_flag(loss)
         if self.world > 1:
+            ev = None
+            if self.time_exposed and self.buf.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
             for w in self._works:
                 w.wait()
+            if ev is not None:
+                ev[1].record()
+                self._exposed_events.append(ev)
         self._works = []
+
+    def exposed_ms(self, reset=True):
+        """average milliseconds per step the compute stream waited for the exchange (time_exposed must be set; host sync)."""
+        if not self._exposed_events:
+            return None
+        torch.cuda.synchronize()
+        v = sum(a.elapsed_time(b) for a, b in self._exposed_events) / len(self._exposed_events)
+        if reset:
+            self._exposed_events = []
+        return v
+
+    def bytes_per_step(self):
+        """payload of the per-step all-reduce (flat fp32 gradient + the 64-float header that carries the NaN/Inf flag)."""
+        return 4 * int(self.buf.numel())
 
     # -- host-synchronising convenience (tests, simple loops) --------------------------------------------------------
     def sync(self, loss=None, max_norm=None):

@@ -31,6 +31,7 @@ def _run(cmd, env=None):
 
 def test_bench_single_gpu_line():
     d = _json_line(_run([sys.executable, "bench.py", "--workload", "c1", "--steps", "6", "--warmup", "2"]))
+    assert d["sustained"]["steps"] >= 250 and d["sustained"]["seconds"] >= 2.0 and 0.5 < d["sustained"]["vs_timed_region"] < 2.0
     assert all(k in d for k in REQUIRED + ["cpu_baseline"])
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 201 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
@@ -87,3 +88,24 @@ def test_bench_two_ranks_rehearsal(workload, extra):
     per_rank = (1 if workload == "c1" else 4) * (201 if workload == "c1" else 801)
     assert abs(d["value"] - 2 * per_rank / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]      # whole job = both ranks
     assert "cpu_baseline" not in d                                                         # N = 1 only
+
+
+def test_bench_default_two_ranks_carry_the_dp_train_record():
+    """the driver's N > 1 command (no --workload): the line must carry BOTH the forward shard (no data-path collective) and the
+    `dp_train` sub-record - the training step of training/conformer_pipeline.py:496-532 with the bucketed gradient all-reduce
+    (north_star: "RCCL all-reduce of gradients"; here over gloo, two ranks on the one card) - and the sustained figure"""
+    env = {"SFM_SINGLE_DEVICE": "1", "SFM_DIST_BACKEND": "gloo"}
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-headline",
+                "--dp-batch", "4", "--dp-steps", "2", "--dp-warmup", "1"], env)
+    d = _json_line(out)
+    assert all(k in d for k in REQUIRED) and d["n_gpus"] == 2 and "B64 x 4 s" in d["config"]["workload"]
+    assert "no data-path collective" in d["config"]["sharding"]
+    s = d["sustained"]
+    assert s["steps"] >= 250 and s["seconds"] >= 2.0 and s["ms_per_step"] > 0 and 0.5 < s["vs_timed_region"] < 2.0
+    t = d["dp_train"]
+    assert t["rccl_ranks"] == 2 and t["backend"] == "gloo" and t["batch_per_gpu"] == 4 and t["steps"] == 2 and t["overlap"] is True
+    assert t["allreduce_bytes_per_step"] > 20e6 and t["allreduce_buckets"] >= 2          # SpeechEnhancer: 24.9 MB of fp32 gradients
+    assert t["ms_per_step"] > 0 and abs(t["frames_per_s"] - 2 * 4 * 801 / (t["ms_per_step"] * 1e-3)) < 1e-3 * t["frames_per_s"]
+    assert t["exposed_allreduce_ms_per_step"] is not None and 0 <= t["exposed_allreduce_ms_per_step"] <= t["ms_per_step"]
+    assert t["optimizer_state"]["step"] == 3 and not t["optimizer_state"]["skipped"]
