@@ -31,6 +31,12 @@
 #ifndef SFM_ATTNP_ABL
 #define SFM_ATTNP_ABL 0
 #endif
+// SFM_ATTNP_CINIT=1: -m as the C operand of the first S MFMA instead of the augmented k-step (one MFMA fewer per block).  Correct
+// (tests pass) but needs a 16-register block per sub-block: 256 VGPRs + 19 spills, whose scratch reloads make the compiler
+// drain vmcnt at every group boundary - 517 against 672 TFLOP/s on the same box.  Kept for a future, leaner register budget.
+#ifndef SFM_ATTNP_CINIT
+#define SFM_ATTNP_CINIT 0
+#endif
 
 typedef __attribute__((address_space(3))) void* attnp_lds_ptr_t;
 
@@ -190,6 +196,9 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
   // Q side (-m_hi, -m_lo | -BIG, 0 | 0...) per sub-block, [0] rewritten by a rescale; K side (1, 1 | pad, 0 | 0...), [1]
   // rewritten per step (nonzero only in a last step that contains padding keys)
   u32x4 qa[2], ka;
+#if SFM_ATTNP_CINIT
+  f32x16 negm[2];                                                   // -m of the lane's query in all 16 registers: C operand of the first S MFMA
+#endif
   f32x16 o[2][2], s[2];
   f32x4 lacc[2];
   u32x4 pf[2][2];                                                   // packed P of the pending block of each sub-block [U][s2]
@@ -218,6 +227,29 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     o[U][0] = T::mfma(ATTNP_VF(1, 0), pf[U][1], o[U][0]);                                                              \
     o[U][1] = T::mfma(ATTNP_VF(1, 1), pf[U][1], o[U][1]);                                                              \
   }
+#if SFM_ATTNP_CINIT
+  // -m enters the S chain as the C operand of its first MFMA (exact fp32, no fifth MFMA per block); padding keys (last step of
+  // an item whose T is not a multiple of 32) are pushed to -1e30 behind the chain, in a wave-uniform branch at the boundary of
+  // the two scheduling regions
+#define ATTNP_SET_NEGM(X, HI, LO, MNEW) { const float nm_ = -(MNEW); _Pragma("unroll") for (int r = 0; r < 16; ++r) negm[X][r] = nm_; }
+#define ATTNP_S_FIRST(U, AFIRST)                                                                                       \
+    if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
+    f32x16 sn = T::mfma(kf[0], qf[U][0], negm[U]);
+#define ATTNP_PAD_FIX(STEP)                                                                                            \
+    if ((STEP) == pad_step) {                                                                                          \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                   \
+        sn[r] = ((STEP) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl >= Tlen) ? -1.0e30f : sn[r];                            \
+    }
+#define ATTNP_SCHED_AUG
+#else
+#define ATTNP_SET_NEGM(X, HI, LO, MNEW) qa[X][0] = (hl == 0) ? pack2<T>(-(HI), -(LO)) : 0u;
+#define ATTNP_S_FIRST(U, AFIRST)                                                                                       \
+    f32x16 sn = T::mfma(ka, qa[U], zero);                                                                              \
+    if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
+    sn = T::mfma(kf[0], qf[U][0], sn);
+#define ATTNP_PAD_FIX(STEP)
+#define ATTNP_SCHED_AUG ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)
+#endif
   // rare path: raise the running maximum of sub-block X from the block whose scores are in s[X], rescale O and l, redo P
 #define ATTNP_RESCALE(X, FORCE)                                                                                        \
   {                                                                                                                    \
@@ -238,7 +270,7 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     _Pragma("unroll") for (int r = 0; r < 4; ++r) lacc[X][r] *= alpha;                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) s[X][r] -= delta;                                                   \
     m_run[X] = m_new_;                                                                                                 \
-    qa[X][0] = (hl == 0) ? pack2<T>(-hi_, -lo_) : 0u;                                                                  \
+    ATTNP_SET_NEGM(X, hi_, lo_, m_new_)                                                                                \
     uint32_t fl_;                                                                                                      \
     ATTNP_EXP_PACK(X, fl_)                                                                                             \
     (void)fl_;                                                                                                         \
@@ -254,9 +286,7 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     /* ---- region 1: the S chain, with the first 12 exponentials beside it ---- */                                    \
     ATTNP_PRIO(U)                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    f32x16 sn = T::mfma(ka, qa[U], zero);                                                                              \
-    if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
-    sn = T::mfma(kf[0], qf[U][0], sn);                                                                                 \
+    ATTNP_S_FIRST(U, AFIRST)                                                                                           \
     sn = T::mfma(kf[1], qf[U][1], sn);                                                                                 \
     sn = T::mfma(kf[2], qf[U][2], sn);                                                                                 \
     sn = T::mfma(kf[3], qf[U][3], sn);                                                                                 \
@@ -267,6 +297,7 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     pf[V_][0][2] = pack2<T>(e_[4], e_[5]);                                                                             \
     pf[V_][0][3] = pack2<T>(e_[6], e_[7]);                                                                             \
     ATTNP_SCHED1                                                                                                       \
+    ATTNP_PAD_FIX(STEP)                                                                                                \
     /* order at the IR level too (MFMAs have no side effects: without a data tie the PV chain may be emitted first and   \
        the sched_barrier then freezes that order): the PV operands pass through an empty asm that also takes sn */        \
     asm volatile("" : "+v"(sn), "+v"(pf[U][0]), "+v"(pf[U][1]));                                                       \
@@ -305,11 +336,11 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
   // region 1: A S0 S1 S2 S3 with 12 exponentials (TRANS) and 4 converts
 #define ATTNP_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 #define ATTNP_SCHED1                                                                                                   \
+  ATTNP_SCHED_AUG                                                                                                      \
   ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)                                                                                \
   ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)                                                                                \
-  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 2) ATTNP_SG(0x002, 2)                                                             \
-  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 2) ATTNP_SG(0x002, 2)                                                             \
-  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 2)
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3) ATTNP_SG(0x002, 2)                                                             \
+  ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3) ATTNP_SG(0x002, 2)
   // region 2: L P P L P P with 4 exponentials, 4 converts, the OR / test
 #define ATTNP_SCHED2                                                                                                   \
   ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 1)                                                                                \
@@ -391,6 +422,10 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     for (int u = 0; u < 2; ++u) {
       m_run[u] = 0.f;
       qa[u] = u32x4{0u, hl == 0 ? negbig : 0u, 0u, 0u};
+#if SFM_ATTNP_CINIT
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[u][r] = 0.f;
+#endif
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         o[u][0][r] = 0.f;
@@ -430,13 +465,17 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     if (++p_g == ngrp) { p_g = 0; p_item += gridDim.x; }
     return np;
   };
-  if (vid < n_items) {
-    issue_q(vid);
-    issue_next_group();
-    issue_next_group();
-  }
   bool qf_ready = false;                                            // Q fragments of the coming item already in registers
   int inflight = 0;                                                 // vector-memory operations issued since the pieces the next barrier waits for
+  bool first_q_pending = false;
+  if (vid < n_items) {
+    // cold start: the first MFMA needs Q and the first group only - the second group's pieces stay in flight across the
+    // first barrier (every CU fetches at once here: 96 KB instead of 128 KB before the first instruction of work)
+    issue_q(vid);
+    const int n0 = issue_next_group();
+    inflight = issue_next_group();
+    first_q_pending = (n0 + inflight == 8);                         // both groups whole: the counted wait below is exact
+  }
   const int pad_step = (Tlen & 31) ? nsteps - 1 : -1;               // the only step that can contain padding keys
   ka = u32x4{hl == 0 ? ones2k : 0u, 0u, 0u, 0u};
   ATTNP_T(unsigned long long t_bar = 0, t_pre = 0, t_steps = 0, t_post = 0, t_last = 0, t_q = 0, t_so = 0, t_dr = 0; const unsigned long long t_start = attnp_stamp();
@@ -481,7 +520,9 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     const bool has_next = item + (int)gridDim.x < n_items;
     if (!qf_ready) {
       // first item of the workgroup (or single-group items, below): this wave's own Q pieces have landed -> fragments
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first_q_pending) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 youngest = the two K/V groups
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); inflight = 0; }
+      first_q_pending = false;
       load_qf();
       init_state();
     }
