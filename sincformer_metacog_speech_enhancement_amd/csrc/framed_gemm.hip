@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void framed_gemm_kernel(FramedParams p) {
       if (nok && m < p.M) {
         float v = acc[j][r] + bv;
         gsum += v;
-        gsq += v * v;
+        gsq = __builtin_fmaf(v, v, gsq);               // (fmaf, not mul + add: see profiles/README.md, "the lost sums of squares")
         long long off = (long long)b * p.o_batch_stride + (long long)m * p.ldm + (long long)nn * p.ldn;
         if (p.out_f32) reinterpret_cast<float*>(dst)[off] = v;
         else reinterpret_cast<u16*>(dst)[off] = T::from_f32(v);

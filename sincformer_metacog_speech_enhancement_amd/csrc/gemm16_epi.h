@@ -127,7 +127,7 @@ __device__ __forceinline__ void gemm16_epilogue_strips(const Gemm2Params& p, f32
       if (p.gn_partial && mok) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
+          if (ncol0 + e < p.N) { gsum += v[e]; gsq = __builtin_fmaf(v[e], v[e], gsq); }   // (fmaf: see profiles/README.md, "the lost sums of squares")
       }
       switch (p.epi) {
         case EPI_SWISH:

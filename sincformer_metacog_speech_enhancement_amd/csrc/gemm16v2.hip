@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
     if (p.gn_partial && mok) {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (ncol0 + e < p.N) { gsum += v[e]; gsq += v[e] * v[e]; }
+        if (ncol0 + e < p.N) { gsum += v[e]; gsq = __builtin_fmaf(v[e], v[e], gsq); }     // (fmaf: see profiles/README.md, "the lost sums of squares")
     }
     switch (p.epi) {
       case EPI_SWISH:

@@ -233,3 +233,102 @@ def test_long_utterances_with_memory_vs_oracle_and_batch_independence():
           (r, rmse(out["enhanced"][1:2].cpu(), ref["enhanced"]), int(out["mem_top"][1]), int(ref["memory"]["top_indices"][0])))
     assert r <= 1e-3
     assert int(out["mem_top"][1]) == int(ref["memory"]["top_indices"][0])
+
+
+def test_full_size_objective_training_steps_on_the_north_star_composition():
+    """BASELINE configs[2] on the north-star composition WITH the real objective (compute_path_loss = the objective of
+    training/conformer_pipeline.py:539-572) at B 256 x 4 s, dropout off so that a step is a deterministic function of the
+    state: finite loss and gradients, the same loss (to 1e-3 relative) and the same gradient norm from a second run started
+    from the same state, and the objective going down over a few FlatAdamW steps.  (The oracle's autograd is out of reach at
+    this size; the objective's backward is pinned on identical inputs in tests/test_train_gpu.py.)"""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath, compute_path_loss
+    ops.set_compute_dtype("bf16")         # training runs in one base format, as bench.py --workload c3t does
+    Bt = 256
+    noisy, clean = syn.synth_wave(Bt, L, 779)
+    noisy, clean = torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda()
+
+    def build():
+        path = EnhancementPath(sample_rate=16000)
+        path.perception.load_state_dict(synth_sd("PerceptionAgent", 291, sinc_scale=2000.0))
+        path.cpea.load_state_dict(synth_sd("CorrelationPhaseEstimationAgent", 292))
+        path.msa.load_state_dict(synth_sd("MaskSynthesisAgent", 293))
+        for mod in path.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        path.cpea.lstm.dropout = 0.0
+        path = path.cuda().train()
+        params = [p_ for n, p_ in path.named_parameters() if "uncertainty_head" not in n]
+        return path, FlatAdamW(params, lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0)
+
+    def run(steps):
+        path, opt = build()
+        hist, norms = [], []
+        for _ in range(steps):
+            opt.zero_grad()
+            total, neg = compute_path_loss(path, noisy, clean)
+            total.backward()
+            opt.step(loss=total)
+            st = opt.stats()
+            assert not st["skipped"] and math.isfinite(st["grad_norm"]) and st["grad_norm"] > 0
+            hist.append(float(total.detach()))
+            norms.append(st["grad_norm"])
+        assert all(math.isfinite(h) for h in hist)
+        del path, opt
+        torch.cuda.empty_cache()
+        return hist, norms
+
+    try:
+        h1, n1 = run(5)
+        h2, n2 = run(2)
+    finally:
+        ops.reset_precision()
+    print("full-size objective (B 256 x 4 s): losses %s, gradient norms %s; second run %s / %s" %
+          (["%.4f" % h for h in h1], ["%.3f" % n for n in n1], ["%.4f" % h for h in h2], ["%.3f" % n for n in n2]))
+    # same state, same data, no dropout: the first step of the two runs sees identical inputs (fp32 atomics in the weight
+    # gradients and 16-bit operand noise behind them: DESIGN.md section 5)
+    assert abs(h1[0] - h2[0]) <= 1e-3 * abs(h1[0]), (h1[0], h2[0])
+    assert abs(h1[1] - h2[1]) <= 1e-2 * abs(h1[1]), (h1[1], h2[1])
+    assert abs(n1[0] - n2[0]) <= 0.1 * n1[0], (n1[0], n2[0])
+    assert h1[-1] < h1[0], h1
+
+
+def test_configs4_batch_of_32_thirty_second_utterances_with_memory():
+    """BASELINE configs[4] AT ITS BATCH (B 32 x 30 s, T 6001, episodic memory on): shapes, mask bounds, finiteness, and
+    independence of the batch - utterance 7 of the 32 equals the same utterance run inside a batch of 3 (the size
+    test_long_utterances_with_memory_vs_oracle_and_batch_independence compares with the oracle) and in a permuted batch."""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import EnhancementPath
+    ops.reset_precision()
+    Bl, Ll = 32, 480000
+    path = EnhancementPath(sample_rate=16000, use_memory=True)
+    path.perception.load_state_dict(synth_sd("PerceptionAgent", 391, sinc_scale=2000.0))
+    path.cpea.load_state_dict(synth_sd("CorrelationPhaseEstimationAgent", 392))
+    path.msa.load_state_dict(synth_sd("MaskSynthesisAgent", 393))
+    path.memory.load_state_dict(synth_sd("EpisodicMemory", 394))
+    path = path.cuda().eval()
+    noisy, _ = syn.synth_wave(Bl, Ll, 397)
+    wave = torch.from_numpy(noisy).cuda()
+    T = 1 + Ll // 80
+    ops.set_attention_variant(4)          # one attention kernel for every batch size below (the default picks it at B 32)
+    try:
+        with torch.no_grad():
+            out = path(wave)
+            keep = {k: out[k][[7, 20, 31]].clone() for k in ("mask_real", "mask_imag", "enhanced")}
+            top = out["mem_top"].clone()
+            shape_mask, shape_enh = tuple(out["mask_real"].shape), tuple(out["enhanced"].shape)
+            mag_max = float(torch.sqrt(out["mask_real"] ** 2 + out["mask_imag"] ** 2).max())
+            ph_max = float(torch.atan2(out["mask_imag"], out["mask_real"]).abs().max())
+            finite = all(bool(torch.isfinite(v).all()) for v in out.values() if isinstance(v, torch.Tensor) and v.dtype.is_floating_point)
+            del out
+            sub = path(wave[[7, 20, 31]].contiguous())
+    finally:
+        ops.set_attention_variant(0)
+    assert shape_mask == (Bl, T, 129) and shape_enh == (Bl, Ll) and finite
+    assert mag_max <= 1.0 + 1e-5 and ph_max <= 3.14159 / 8 + 1e-4
+    for k in ("mask_real", "mask_imag", "enhanced"):
+        assert rmse(sub[k].cpu(), keep[k].cpu()) < 2e-5, k
+    assert torch.equal(sub["mem_top"].cpu(), top[[7, 20, 31]].cpu())

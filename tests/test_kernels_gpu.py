@@ -272,6 +272,58 @@ def test_conv16p_statistics_and_determinism_at_scale(ops, cin, cout, k, s, p, tw
         assert float(err.max()) < 1e-4, float(err.max())
 
 
+@pytest.mark.parametrize("cin,cout,k,s,p,L", [(64, 128, 7, 2, 3, 64000), (256, 256, 1, 1, 0, 8000)])
+def test_gemm16_statistics_and_determinism_at_scale(ops, cin, cout, k, s, p, L):
+    """the same at-scale check for sfm_gemm16's GroupNorm partial sums (the training-mode convs and the latent heads use
+    them): exact against the fp32 rows of the same launch in every slot, bitwise equal between two launches"""
+    ops.set_compute_dtype(torch.float16)
+    dt, B, G = torch.float16, 8, 16
+    g = torch.Generator(device="cuda").manual_seed(6)
+    R = lambda *shape: torch.randn(*shape, device="cuda", generator=g)
+    x = R(B, L, cin).to(dt)
+    pw = ops.pack_linear(R(cout, cin, k) / (cin * k) ** 0.5, R(cout))
+    Lout = (L + 2 * p - k) // s + 1
+    P = 2 * ((Lout + 127) // 128)
+
+    def run():
+        out = torch.empty(B, Lout, cout, device="cuda", dtype=torch.float32)
+        part = torch.zeros(B, P, G, 2, device="cuda")
+        ops.gemm16(x, pw, out, B=B, Lout=Lout, Lin=L, a_batch_stride=L * cin, ldo=cout, o_batch_stride=Lout * cout, stride=s, pad=p,
+                   gn_partial=part, gn_group=cout // G)
+        return out, part
+    (o1, p1), (o2, p2) = run(), run()
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    rows = torch.cat([o1.double(), torch.zeros(B, P * 64 - Lout, cout, device="cuda", dtype=torch.float64)], dim=1)
+    rows = rows.reshape(B, P, 64, G, cout // G)
+    want = torch.stack([rows.sum(dim=(2, 4)), (rows ** 2).sum(dim=(2, 4))], dim=-1)
+    err = (p1.double() - want).abs() / (1.0 + want.abs())
+    assert float(err.max()) < 1e-4, float(err.max())
+
+
+def test_framed_gemm_statistics_and_determinism_at_scale(ops):
+    """and for sfm_framed_gemm_f32 (the SincConv1d front-end of the module API and of training): B 8 x 4 s, 64 filters x 251
+    taps, GroupNorm(8) partial sums per 32-row slot"""
+    B, L, N, K = 8, 64000, 64, 251
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(B, L, device="cuda", generator=g) * 0.3
+    Wt = torch.zeros(256, N, device="cuda")
+    Wt[:K] = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
+    P = 4 * ((L + 127) // 128)
+
+    def run():
+        out = torch.empty(B, L, N, device="cuda", dtype=torch.float32)
+        part = torch.zeros(B, P, 8, 2, device="cuda")
+        ops.framed_gemm(x, Wt, out, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=125, K=K, N=N, o_batch_stride=L * N, ldm=N, ldn=1,
+                        mode=0, gn_partial=part, gn_group=8)
+        return out, part
+    (o1, p1), (o2, p2) = run(), run()
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    rows = torch.cat([o1.double(), torch.zeros(B, P * 32 - L, N, device="cuda", dtype=torch.float64)], dim=1).reshape(B, P, 32, 8, 8)
+    want = torch.stack([rows.sum(dim=(2, 4)), (rows ** 2).sum(dim=(2, 4))], dim=-1)
+    err = (p1.double() - want).abs() / (1.0 + want.abs())
+    assert float(err.max()) < 1e-4, float(err.max())
+
+
 def test_conv16p_refuses_shapes_it_is_not_built_for(ops):
     ops.set_compute_dtype(torch.float16)
     x = torch.zeros(1, 64, 64, device="cuda", dtype=torch.float16)

@@ -15,13 +15,13 @@ from sincformer_metacog_speech_enhancement_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 # Operand formats under test: "mixed" = the DEFAULT of inference and what bench.py / smoke() run (ops.POLICIES["mixed"]:
-# PerceptionAgent convs and the attention core bf16, LayerNorm-fed GEMMs fp16), "fp16" / "bf16" = one format everywhere
+# fp16 GEMM / conv operands everywhere, bf16 only in the attention core), "fp16" / "bf16" = one format everywhere
 # (ops.set_compute_dtype).
 PRECISIONS = ["mixed", "fp16", "bf16"]
 MASK_RMSE_BOUND = 1e-3
 # The golden MSA / path vectors use DE-SATURATED heads (mask magnitude ~0.5): the hardest regime for the
 # north-star bound (mask RMSE <= 1e-3 against the reference's CPU output).  Measured per-stage error budget:
-# profiles/r02/precision_probe.json — default policy 3.3e-4 (MaskSynthesisAgent) / 7.3e-4 (whole path) / 4.4e-4
+# profiles/r02/precision_probe.json — default policy 2.2e-4 (MaskSynthesisAgent) / 2.0e-4 (whole path) / 3.3e-4
 # (SpeechEnhancer), fp16 everywhere 1.6-1.8e-4, bf16 everywhere 1.2-1.6e-3.  The default and fp16 must meet 1e-3 in the hard
 # regime; uniform bf16 is a non-default diagnostic mode that must meet it at the reference's own initialisation (masks
 # ~0.993) and stay < 2e-3 in the hard regime.
@@ -316,8 +316,10 @@ def test_loss_mirrors_by_their_reference_names_vs_golden(pkg):
     r_si, = torch.autograd.grad(orc.si_snr_loss(e2, torch.from_numpy(clean)), e2)
     r_mr, = torch.autograd.grad(orc.mr_stft_loss(e2, torch.from_numpy(clean)), e2)
     assert rel(g_si.cpu(), r_si.numpy()) < 1e-4, rel(g_si.cpu(), r_si.numpy())
-    # (sign(log|P| - log|T|) terms: bins whose two magnitudes agree to ~1e-6 flip with the 4e-6 error of the split-bf16 STFT)
-    assert rel(g_mr.cpu(), r_mr.numpy()) < 2e-2, rel(g_mr.cpu(), r_mr.numpy())
+    # (sign(log|P| - log|T|) terms: bins whose two magnitudes agree to ~1e-6 flip with the 4e-6 error of the split-bf16 STFT;
+    #  observed 6.2e-3, bound = 2 x that: profiles/README.md, "tolerances and what is achieved")
+    print("MR-STFT gradient vs oracle autograd: rel rmse %.3e" % rel(g_mr.cpu(), r_mr.numpy()))
+    assert rel(g_mr.cpu(), r_mr.numpy()) < 1.3e-2, rel(g_mr.cpu(), r_mr.numpy())
     # a non-default resolution list runs the exact-fp32 STFT path
     mr2 = pkg.cp.MultiResolutionSTFTLoss([128, 320], [32, 80], [128, 320])
     l2 = mr2(est, tgt)

@@ -239,7 +239,7 @@ def test_speech_enhancer_train_step_matches_autograd(dt):
     # residuals of large cancelling terms: the same rounding noise is twice as large relative to them
     # (2.7e-2 .. 4.5e-2 in fp16, against <= 3e-2 everywhere else), and a change of summation order in one LayerNorm moves
     # them by 10-20 %.  They get twice the bound; everything else keeps it.
-    tol_g = 0.04 if dt is torch.float16 else 0.2
+    tol_g = 0.04 if dt is torch.float16 else 0.2       # observed 2.9e-2 / 1.43e-1; BatchNorm-projected 4.5e-2 / 1.78e-1
     worst, worst_bn = ("", 0.0), ("", 0.0)
     for k, p_ in m.named_parameters():
         assert p_.grad is not None, k
@@ -256,7 +256,10 @@ def test_speech_enhancer_train_step_matches_autograd(dt):
             worst = (k, rel)
     print("  worst parameter-gradient rel rmse: %s %.3e; behind the BatchNorm projection: %s %.3e" % (worst + worst_bn))
     assert worst[1] < tol_g, worst
-    assert worst_bn[1] < 2 * tol_g, worst_bn
+    # (the backward arithmetic of exactly these parameters is pinned independently of the forward's rounding noise by
+    #  test_block_train_forward_backward_matches_autograd: one block, identical inputs, every parameter gradient incl.
+    #  conv.layer_norm / conv.pointwise1 within 1e-2 (fp16) / 5e-2 (bf16) of autograd)
+    assert worst_bn[1] < (2 * tol_g if dt is torch.float16 else 0.36), worst_bn
 
 
 # ---------------------------------------------------------------------------
@@ -649,7 +652,7 @@ def test_cpea_train_mode_bptt(dt, B, T):
     for k in cots:
         e = rmse(out[k].detach().cpu(), out_o[k].detach())
         assert e < (2e-3 if dt is torch.float16 else 1.5e-2), (k, e)
-    tol = 0.02 if dt is torch.float16 else 0.1
+    tol = 2e-3 if dt is torch.float16 else 1.5e-2     # observed 7.4e-4 / 6.1e-3 (profiles/README.md): bound = ~2 x
     r = _rel(zg.grad.cpu(), zr.grad)
     worst = ("input", r)
     for k, p_ in m.named_parameters():
@@ -767,7 +770,7 @@ def test_perception_agent_train_mode(dt, sinc_scale):
     print("PA train-mode latents %s: rmse %.3e (rms %.3e)" % (dt, e, float(zr_o.detach().pow(2).mean().sqrt())))
     assert e < (3e-3 if dt is torch.float16 else 2e-2)
     assert rmse(sg.cpu(), sg_o.detach()) < 2e-2 * float(sg_o.abs().max())
-    tol = 0.02 if dt is torch.float16 else 0.1
+    tol = 7e-3 if dt is torch.float16 else 6e-2       # observed 3.1e-3 / 2.6e-2 (profiles/README.md): bound = ~2 x
     worst = ("", 0.0)
     for k, p_ in m.named_parameters():
         if k.startswith("uncertainty_head"):
