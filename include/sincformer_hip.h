@@ -170,12 +170,17 @@ int sfm_pool_time_affine16(const void* src16, int src_dtype, const float* scale,
  * two-pass sum, scratch: sfm_mean_time_scratch_floats floats */
 long long sfm_mean_time_scratch_floats(int B, int T, int C);
 int sfm_mean_time(const float* src, float* dst, float* scratch, int B, int T, int C, long long ld_src, void* stream);
+/* the same reduction without the 1/T (training: gradient of a per-utterance bias broadcast over the frames) */
+int sfm_sum_time(const float* src, float* dst, float* scratch, int B, int T, int C, long long ld_src, void* stream);
 /* adjoint of sfm_pool_time (training: gradient of the pooled latents back to the full-rate latents), fp32 */
 int sfm_pool_time_bwd(const float* dout, float* dsrc, int B, int Tin, int Tout, int C, long long ld_dout,
                       long long ld_dsrc, void* stream);
 /* agents/msa.py:134-137 */
 int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst, long long M, int F, int zpad,
                           long long ld_dst, int dtype, void* stream);
+/* adjoint of sfm_stft_lognorm_pack: g [M, ld_g] fp32 holds d(real') in columns [0,F) and d(imag') in [F,2F) */
+int sfm_stft_lognorm_bwd(const float* re, const float* im, const float* g, float* dre, float* dim_, long long M, int F,
+                         long long ld_g, void* stream);
 /* agents/msa.py:166-172, training/conformer_pipeline.py:287-296 */
 int sfm_polar_mask(const float* lm, const float* lp, const float* mag_bias, const float* nr, const float* ni,
                    float* mr, float* mi, float* er, float* ei, float* mmag, int B, long long rows_per_batch,
@@ -237,9 +242,11 @@ int sfm_spec_loss_bwd(const float* pr, const float* pi, const float* tr, const f
                       float* di, long long n, int F, long long ld, int mode, int accumulate, float scale, void* stream);
 int sfm_stft_adjoint_ola(const float* frames, float* dwave, const float* post, int B, int T, int L, int n_fft, int hop,
                          int win, int accumulate, void* stream);
-int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* nr, const float* ni, const float* der,
-                       const float* dei, float* dlog, long long M, int F, float phase_scale, long long ld_logits,
-                       long long ld_dlog, void* stream);
+/* mag_bias (or NULL): [M / rows_per_batch, F] added to the magnitude logit as in sfm_polar_mask; nr = ni = NULL: the mask itself
+ * is the output (noisy = 1 + 0j, agents/msa.py:166-172) */
+int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* mag_bias, const float* nr, const float* ni,
+                       const float* der, const float* dei, float* dlog, long long M, long long rows_per_batch, int F,
+                       float phase_scale, long long ld_logits, long long ld_dlog, void* stream);
 /* small-shape attention backward (any head_dim <= 256; the MFMA kernels of sfm_attention_bwd need head_dim 64):
  * dkv32 = zero-filled fp32 scratch [B*T, 2*H*hd]; dqkv gets dQ' | dK | dV like sfm_attention_bwd. */
 int sfm_attention_bwd_generic(const void* qkv, const void* O, const void* dO, const float* lse, float* dkv32, void* dqkv,
@@ -307,6 +314,13 @@ int sfm_vq_backward(const float* x, const long long* idx, const float* centroids
 int sfm_sumsq(const float* g, long long n, double* out, void* stream);
 int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
                    float eps, float wd, float inv_scale, float max_norm, int write_back_grad, void* stream);
+/* Same, leaving alone - p, m and v - the parameters that received no gradient in this step (torch.optim.AdamW skips a
+ * parameter whose grad is None): spans[k] = first flat element of parameter k (n_params + 1 ascending entries, device),
+ * touched[k] > 0 = stepped (device; in data-parallel runs the per-rank 0/1 masks summed by the gradient all-reduce, so
+ * that every replica takes the same decision). */
+int sfm_adamw_step_masked(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
+                          float eps, float wd, float inv_scale, float max_norm, int write_back_grad, const long long* spans,
+                          const float* touched, int n_params, void* stream);
 /* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
 /* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); db (optional):
  * db[n] += sum_m G[m,n] in the same launch; sfm_colsum = the stand-alone bias gradient */
@@ -326,6 +340,11 @@ int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, in
 /* BatchNorm1d training statistics / backward (through the following Swish) */
 int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C,
                   void* stream);
+/* nn.BatchNorm1d training statistics from sfm_col_stats' sums: mean, rstd, folded affine (sc, sh) and the in-place update of the
+ * running statistics (unbiased variance; run_* may be NULL); eval_mode: statistics = run_mean / run_var, nothing updated */
+int sfm_bn_finalize(const float* S, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
+                    float* rstd, float* sc, float* sh, int C, long long M, float eps, float momentum, int eval_mode,
+                    void* stream);
 int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float* S, float* dy, int M, int C, int g_f32, int pass, int dtype,
                      void* stream);
@@ -353,6 +372,11 @@ int sfm_bilstm_layer_bwd(const float* save, const float* whh, const float* dout,
 /* EpisodicMemory.forward eval (agents/memory.py:112-133) in one launch, see memory.hip */
 int sfm_memory_fwd(const float* emb, const float* params, float* bias_out, float* gate_out, int* top_idx,
                    float* sim_out, int B, int key_dim, int value_dim, int slots, float temperature, void* stream);
+/* Backward of sfm_memory_fwd (EpisodicMemory in train() mode): d_out = gradient of the gated bias [B, value_dim], d_gate = of
+ * the gate [B] (or NULL); d_emb [B, key_dim] (or NULL) and dparams = a ZERO-FILLED blob with the layout of `params`
+ * (gradients of key_proj, keys, values, value_proj, gate are accumulated over the rows with fp32 atomics). */
+int sfm_memory_bwd(const float* emb, const float* params, const float* d_out, const float* d_gate, float* d_emb,
+                   float* dparams, int B, int key_dim, int value_dim, int slots, float temperature, void* stream);
 
 #ifdef __cplusplus
 }

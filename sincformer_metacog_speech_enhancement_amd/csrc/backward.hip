@@ -138,6 +138,8 @@ extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float
 //   mode 4  SCALE_DROP: out(fp32|16) = [z fp32 +] alpha * g * drop   (residual-branch dropout, fwd and bwd)
 //   mode 5  GELU_FWD  : out(fp32|16) = gelu(z)                         z fp32 [M, N], exact erf
 //   mode 6  GELU_BWD  : out(fp32|16) = g * gelu'(z)                    z fp32, g fp32 or 16-bit
+//   mode 7  CPEA_BWD  : out fp32 = g * f'(.) from the OUTPUTS z = y fp32 [M, N] of the EPI_CPEA epilogue: columns < N/2 are
+//                       sigmoid outputs (f' = y (1 - y)), the rest alpha * tanh outputs (f' = alpha (1 - (y / alpha)^2))
 // `drop` = counter-based keep/(1-p) with element index m*N+n (p == 0 -> 1).
 // ---------------------------------------------------------------------------
 template <class T>
@@ -174,6 +176,10 @@ __global__ __launch_bounds__(256) void ew_train_kernel(const void* __restrict__ 
       const float r = (mode == 5) ? zv * cdf : gv * (cdf + zv * 0.39894228040143267794f * __expf(-0.5f * zv * zv));
       if (out_f32) reinterpret_cast<float*>(out)[e] = r;
       else reinterpret_cast<u16*>(out)[e] = T::from_f32(r);
+    } else if (mode == 7) {
+      const float y = reinterpret_cast<const float*>(z)[e];
+      const float t = y / alpha;
+      reinterpret_cast<float*>(out)[e] = gv * ((n < N / 2) ? y * (1.0f - y) : alpha * (1.0f - t * t));
     } else {
       float r = alpha * gv * dr;
       if (z) r += reinterpret_cast<const float*>(z)[e];          // mode 4: optional fp32 residual
@@ -301,8 +307,10 @@ static int ew_train_launch(const void* z, const void* g, void* out, long long M,
 
 extern "C" int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                             float alpha, float p, unsigned int seed, int dtype, void* stream) {
-  if (!out || ((mode <= 3 || mode >= 5) && !z) || ((mode == 1 || mode == 3 || mode == 4 || mode == 6) && !g)) return SFM_ERR_ARG;
-  if (M <= 0 || N <= 0 || mode < 0 || mode > 6 || p < 0.f || p >= 1.f) return SFM_ERR_SHAPE;
+  if (!out || ((mode <= 3 || mode >= 5) && !z) || ((mode == 1 || mode == 3 || mode == 4 || mode == 6 || mode == 7) && !g))
+    return SFM_ERR_ARG;
+  if (M <= 0 || N <= 0 || mode < 0 || mode > 7 || p < 0.f || p >= 1.f) return SFM_ERR_SHAPE;
+  if (mode == 7 && (!g_f32 || !out_f32)) return SFM_ERR_SHAPE;
   if (dtype == SFM_DT_F16) return ew_train_launch<F16>(z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed, (hipStream_t)stream);
   return ew_train_launch<BF16>(z, g, out, M, N, mode, g_f32, out_f32, alpha, p, seed, (hipStream_t)stream);
 }
@@ -344,6 +352,48 @@ extern "C" int sfm_col_stats(const float* y, const float* aux, const float* mean
   const int rpb = 256;
   SFM_LAUNCH(col_stats_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, y, aux, mean,
              rstd, S, M, C, rpb);
+  return SFM_OK;
+}
+
+// BatchNorm1d training statistics finalised on the device (models/conformer.py ConvolutionModule's nn.BatchNorm1d, train() mode):
+// S[c] = {sum y, sum y^2} over the M rows ->  mean, rstd = 1/sqrt(biased var + eps), the folded affine
+// sc = gamma rstd, sh = beta - mean sc, and the running statistics (unbiased variance, momentum) updated in place.
+// eval_mode: mean / var come from run_mean / run_var and nothing is updated.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ S, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ sc, float* __restrict__ sh,
+                                                          int C, float M, float eps, float momentum, int eval_mode) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (eval_mode) {
+    mu = run_mean[c];
+    var = run_var[c];
+  } else {
+    mu = S[2 * c] / M;
+    var = fmaxf(S[2 * c + 1] / M - mu * mu, 0.0f);
+    if (run_mean) {
+      run_mean[c] = run_mean[c] * (1.0f - momentum) + momentum * mu;
+      run_var[c] = run_var[c] * (1.0f - momentum) + momentum * (var * (M / fmaxf(M - 1.0f, 1.0f)));
+    }
+  }
+  const float rs = rsqrtf(var + eps);
+  mean[c] = mu;
+  rstd[c] = rs;
+  const float a = gamma[c] * rs;
+  sc[c] = a;
+  sh[c] = beta[c] - mu * a;
+}
+
+extern "C" int sfm_bn_finalize(const float* S, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
+                               float* rstd, float* sc, float* sh, int C, long long M, float eps, float momentum, int eval_mode,
+                               void* stream) {
+  if (!gamma || !beta || !mean || !rstd || !sc || !sh) return SFM_ERR_ARG;
+  if (eval_mode ? (!run_mean || !run_var) : (!S || ((run_mean == nullptr) != (run_var == nullptr)))) return SFM_ERR_ARG;
+  if (C <= 0 || M <= 0) return SFM_ERR_SHAPE;
+  SFM_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, S, gamma, beta, run_mean, run_var, mean,
+             rstd, sc, sh, C, (float)M, eps, momentum, eval_mode);
   return SFM_OK;
 }
 

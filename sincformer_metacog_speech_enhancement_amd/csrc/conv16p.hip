@@ -425,7 +425,10 @@ static int launch_convp(const ConvPParams& p, hipStream_t stream) {
   constexpr int PR = (((STRIDE == 2) ? (R + 1) / 2 : R) + 7) / 8 * 8;
   constexpr int patch = PLANES * PR * 128;
   constexpr int lds = patch + ((TWO_IN && patch > 2 * 128 * 128) ? patch : 2 * 128 * 128) + 384 * 4;   // + the bias copy
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {false};        // hipFuncSetAttribute is per device
+  int attr_dev_ = 0;
+  if (hipGetDevice(&attr_dev_) != hipSuccess || attr_dev_ < 0 || attr_dev_ >= 64) return SFM_ERR_LAUNCH;
+  bool& attr_set = attr_set_dev[attr_dev_];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv16p_kernel<T, KS, STRIDE, NPASS, SKIP, TWO_IN>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)

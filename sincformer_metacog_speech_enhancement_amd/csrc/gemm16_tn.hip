@@ -372,7 +372,10 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
     splits = (M + rows - 1) / rows;
     dim3 grid(N / 256, K / 256, splits), block(1024);
     const size_t lds = 4 * 64 * TN_ROW * sizeof(u16);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};        // hipFuncSetAttribute is per device
+  int attr_dev_ = 0;
+  if (hipGetDevice(&attr_dev_) != hipSuccess || attr_dev_ < 0 || attr_dev_ >= 64) return SFM_ERR_LAUNCH;
+  bool& attr_set = attr_set_dev[attr_dev_];
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)gemm16_tn_wide_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)gemm16_tn_wide_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

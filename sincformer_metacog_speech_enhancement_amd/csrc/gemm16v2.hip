@@ -500,7 +500,10 @@ __global__ __launch_bounds__(256) void gemm16p_kernel(Gemm2Params p, int total_t
 template <class T, int BN>
 static int launch_p(const Gemm2Params& p, hipStream_t stream) {
   constexpr int lds = 2 * (128 + BN) * 128 + 4 * 8 * (BN / 2 + 4) * 4;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {false};        // hipFuncSetAttribute is per device
+  int attr_dev_ = 0;
+  if (hipGetDevice(&attr_dev_) != hipSuccess || attr_dev_ < 0 || attr_dev_ >= 64) return SFM_ERR_LAUNCH;
+  bool& attr_set = attr_set_dev[attr_dev_];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm16p_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SFM_ERR_LAUNCH;
@@ -635,7 +638,10 @@ __global__ __launch_bounds__(NW * 64) void gemm16w_kernel(Gemm2Params p) {
 template <class T, int BM, int BN, int NW>
 static int launch_w(const Gemm2Params& p, hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {false};        // hipFuncSetAttribute is per device
+  int attr_dev_ = 0;
+  if (hipGetDevice(&attr_dev_) != hipSuccess || attr_dev_ < 0 || attr_dev_ >= 64) return SFM_ERR_LAUNCH;
+  bool& attr_set = attr_set_dev[attr_dev_];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm16w_kernel<T, BM, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SFM_ERR_LAUNCH;
@@ -650,7 +656,10 @@ template <class T, int BN, int STAGES, int BM>
 static int launch_v2(const Gemm2Params& p, hipStream_t stream) {
   constexpr int ring = STAGES * (BM + BN) * 128, image = 4 * 64 * (BN / 2 + 4) * 4;
   constexpr int lds = ring > image ? ring : image;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {false};        // hipFuncSetAttribute is per device
+  int attr_dev_ = 0;
+  if (hipGetDevice(&attr_dev_) != hipSuccess || attr_dev_ < 0 || attr_dev_ >= 64) return SFM_ERR_LAUNCH;
+  bool& attr_set = attr_set_dev[attr_dev_];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm16v2_kernel<T, BN, STAGES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SFM_ERR_LAUNCH;
@@ -692,14 +701,16 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
     return SFM_ERR_SHAPE;
   if (a_rec >= (1LL << 31) || (long long)Lout * stride * lda * 2 >= (1LL << 31)) {
     // the A operand does not fit one 32-bit buffer descriptor: plain GEMMs (one batch entry, 1 tap) are cut into row chunks
-    if (B != 1 || ksize != 1 || stride != 1 || pad != 0 || gn_partial || swish) return SFM_ERR_SHAPE;
+    // (no dropout on this path: the backward rebuilds the keep mask from the seed and the GLOBAL (row, column) index, a
+    //  per-chunk re-seed with row indices restarting at 0 would give it another mask)
+    if (B != 1 || ksize != 1 || stride != 1 || pad != 0 || gn_partial || swish || p_drop > 0.f) return SFM_ERR_SHAPE;
     const long long rows_max = ((1LL << 30) / ((long long)lda * 2)) & ~255LL;
     const int osz_ = out_f32 == 1 ? 4 : 2;
     for (long long r0 = 0; r0 < Lout; r0 += rows_max) {
       const int rows = (int)((Lout - r0 < rows_max) ? (Lout - r0) : rows_max);
       const int rc = gemm16_impl((const u16*)A + r0 * lda, W, bias, (char*)out + r0 * ldo * osz_, resid ? resid + r0 * ldr : nullptr,
                                  nullptr, 1, rows, rows, Cin, lda, 1, 1, 0, 0, Kpad, N, Npad, ldo, 0, ldr, 0, alpha, epi, out_f32,
-                                 gn_group, nsplit, dtype, variant, p_drop, seed + (unsigned)(r0 * 0x9E3779B1ull), nullptr, nullptr, stream);
+                                 gn_group, nsplit, dtype, variant, 0.f, seed, nullptr, nullptr, stream);
       if (rc != SFM_OK) return rc;
     }
     return SFM_OK;

@@ -121,20 +121,24 @@ __global__ __launch_bounds__(256) void stft_adjoint_ola_kernel(const float* __re
 
 // backward of  mg = sigmoid(a), ph = tanh(p) * phase_scale, mask = mg (cos ph, sin ph), enh = mask (x) noisy
 // dlog[m, f] = d/da, dlog[m, F + f] = d/dp      (row stride ld_d; the columns >= 2F are left untouched)
+// mag_bias (optional, [M / rows_per_batch, F]): a = lm + bias as in the forward kernel; nr == NULL: noisy = 1 + 0j (the mask
+// itself is the output, agents/msa.py:166-172)
 __global__ __launch_bounds__(256) void polar_mask_bwd_kernel(const float* __restrict__ lm, const float* __restrict__ lp,
-                                                             const float* __restrict__ nr, const float* __restrict__ ni,
-                                                             const float* __restrict__ der, const float* __restrict__ dei,
-                                                             float* __restrict__ dlog, int F, long long total,
-                                                             float phase_scale, long long ld_l, long long ld_d) {
+                                                             const float* __restrict__ mag_bias, const float* __restrict__ nr,
+                                                             const float* __restrict__ ni, const float* __restrict__ der,
+                                                             const float* __restrict__ dei, float* __restrict__ dlog, int F,
+                                                             long long total, long long rows_per_batch, float phase_scale,
+                                                             long long ld_l, long long ld_d) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const long long m = e / F;
     const int f = (int)(e - m * F);
-    const float a = lm[m * ld_l + f];
+    float a = lm[m * ld_l + f];
+    if (mag_bias) a += mag_bias[(m / rows_per_batch) * F + f];
     const float mg = 1.0f / (1.0f + expf(-a));
     const float th = tanhf(lp[m * ld_l + f]);
     const float ph = th * phase_scale;
     const float c = cosf(ph), s = sinf(ph);
-    const float r = nr[e], i = ni[e], gr = der[e], gi = dei[e];
+    const float r = nr ? nr[e] : 1.0f, i = nr ? ni[e] : 0.0f, gr = der[e], gi = dei[e];
     const float dxr = gr * r + gi * i;
     const float dxi = gi * r - gr * i;
     const float dmg = dxr * c + dxi * s;
@@ -175,15 +179,15 @@ extern "C" int sfm_stft_adjoint_ola(const float* frames, float* dwave, const flo
   return SFM_OK;
 }
 
-extern "C" int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* nr, const float* ni, const float* der,
-                                  const float* dei, float* dlog, long long M, int F, float phase_scale, long long ld_logits,
-                                  long long ld_dlog, void* stream) {
-  if (!lm || !lp || !nr || !ni || !der || !dei || !dlog) return SFM_ERR_ARG;
-  if (M <= 0 || F <= 0 || ld_dlog < 2 * F) return SFM_ERR_SHAPE;
+extern "C" int sfm_polar_mask_bwd(const float* lm, const float* lp, const float* mag_bias, const float* nr, const float* ni,
+                                  const float* der, const float* dei, float* dlog, long long M, long long rows_per_batch, int F,
+                                  float phase_scale, long long ld_logits, long long ld_dlog, void* stream) {
+  if (!lm || !lp || !der || !dei || !dlog || ((nr == nullptr) != (ni == nullptr))) return SFM_ERR_ARG;
+  if (M <= 0 || F <= 0 || ld_dlog < 2 * F || rows_per_batch <= 0 || M % rows_per_batch) return SFM_ERR_SHAPE;
   const long long total = M * F;
   long long nb = (total + 255) / 256;
   if (nb > 16384) nb = 16384;
-  SFM_LAUNCH(polar_mask_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lm, lp, nr, ni, der, dei, dlog, F,
-             total, phase_scale, ld_logits, ld_dlog);
+  SFM_LAUNCH(polar_mask_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lm, lp, mag_bias, nr, ni, der, dei,
+             dlog, F, total, rows_per_batch, phase_scale, ld_logits, ld_dlog);
   return SFM_OK;
 }

@@ -41,16 +41,35 @@ __global__ void adamw_prepare_kernel(double* __restrict__ ctl, double inv_scale,
   ctl[2] = 0.0;
 }
 
+// spans / touched (optional): spans[k] = first element of parameter k in the flat buffers (n_params + 1 entries, ascending),
+// touched[k] > 0 when some rank's backward pass produced a gradient for parameter k in this step.  Elements of parameters
+// with touched == 0 are left alone - p, m AND v - as torch.optim.AdamW leaves a parameter whose grad is None; the decision is
+// made on the device from a mask that was summed over the ranks with the gradients, so every replica takes the same one.
 __global__ __launch_bounds__(256) void adamw_apply_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, long long n, const double* __restrict__ ctl,
                                                           float lr, float beta1, float beta2, float eps, float wd,
-                                                          int write_back_grad) {
+                                                          int write_back_grad, const long long* __restrict__ spans,
+                                                          const float* __restrict__ touched, int n_params) {
   if (ctl[4] > 0.0) return;                                                    // skipped step: nothing changes
   const float gs = (float)ctl[3];
   const float step_size = lr / (float)ctl[5];
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(ctl[6]));
   const float decay = 1.0f - lr * wd;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  for (long long base = (long long)blockIdx.x * 256; base < n; base += (long long)gridDim.x * 256) {
+    const long long i = base + threadIdx.x;
+    if (spans) {
+      // parameter of the chunk's first element (the same binary search in every lane: broadcast loads), then at most a few
+      // steps forward for the lanes behind a parameter boundary inside the chunk
+      int lo = 0, hi = n_params - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (spans[mid] <= base) lo = mid; else hi = mid - 1;
+      }
+      int k = lo;
+      while (k + 1 < n_params && spans[k + 1] <= i) ++k;
+      if (i < n && touched[k] <= 0.f) continue;
+    }
+    if (i >= n) continue;
     const float gi = g[i] * gs;
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
@@ -71,16 +90,32 @@ extern "C" int sfm_sumsq(const float* g, long long n, double* out, void* stream)
   return SFM_OK;
 }
 
-extern "C" int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,
-                              float beta2, float eps, float wd, float inv_scale, float max_norm, int write_back_grad,
-                              void* stream) {
+static int adamw_step_impl(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,
+                           float beta2, float eps, float wd, float inv_scale, float max_norm, int write_back_grad,
+                           const long long* spans, const float* touched, int n_params, void* stream) {
   if (!p || !g || !m || !v || !ctl) return SFM_ERR_ARG;
   if (n <= 0) return SFM_ERR_SHAPE;
+  if ((spans != nullptr) != (touched != nullptr) || (spans && n_params <= 0)) return SFM_ERR_ARG;
   SFM_LAUNCH(adamw_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, (double)inv_scale, (double)max_norm,
              (double)beta1, (double)beta2);
   long long nb = (n + 255) / 256;
   if (nb > 8192) nb = 8192;
   SFM_LAUNCH(adamw_apply_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ctl, lr, beta1, beta2,
-             eps, wd, write_back_grad);
+             eps, wd, write_back_grad, spans, touched, n_params);
   return SFM_OK;
+}
+
+extern "C" int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,
+                              float beta2, float eps, float wd, float inv_scale, float max_norm, int write_back_grad,
+                              void* stream) {
+  return adamw_step_impl(p, g, m, v, n, ctl, lr, beta1, beta2, eps, wd, inv_scale, max_norm, write_back_grad, nullptr, nullptr, 0,
+                         stream);
+}
+
+extern "C" int sfm_adamw_step_masked(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,
+                                     float beta2, float eps, float wd, float inv_scale, float max_norm, int write_back_grad,
+                                     const long long* spans, const float* touched, int n_params, void* stream) {
+  if (!spans || !touched) return SFM_ERR_ARG;
+  return adamw_step_impl(p, g, m, v, n, ctl, lr, beta1, beta2, eps, wd, inv_scale, max_norm, write_back_grad, spans, touched,
+                         n_params, stream);
 }

@@ -726,14 +726,14 @@ __global__ __launch_bounds__(256) void mean_time_partial_kernel(const float* __r
   part[((long long)b * nchunk + k) * C + c] = acc;
 }
 
-__global__ __launch_bounds__(256) void mean_time_final_kernel(const float* __restrict__ part, float* __restrict__ dst, int T, int C,
-                                                              int nchunk) {
+__global__ __launch_bounds__(256) void mean_time_final_kernel(const float* __restrict__ part, float* __restrict__ dst, float scale,
+                                                              int C, int nchunk) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float acc = 0.f;
   for (int k = 0; k < nchunk; ++k) acc += part[((long long)b * nchunk + k) * C + c];
-  dst[(long long)b * C + c] = acc / (float)T;
+  dst[(long long)b * C + c] = acc * scale;
 }
 
 extern "C" long long sfm_mean_time_scratch_floats(int B, int T, int C) { return (long long)B * ((T + 63) / 64) * C; }
@@ -744,7 +744,19 @@ extern "C" int sfm_mean_time(const float* src, float* dst, float* scratch, int B
   const int nchunk = (T + 63) / 64;
   SFM_LAUNCH(mean_time_partial_kernel, dim3((C + 255) / 256, nchunk, B), dim3(256), 0, (hipStream_t)stream, src, scratch, T, C, ld_src,
              nchunk);
-  SFM_LAUNCH(mean_time_final_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scratch, dst, T, C, nchunk);
+  SFM_LAUNCH(mean_time_final_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scratch, dst, 1.0f / (float)T, C,
+             nchunk);
+  return SFM_OK;
+}
+
+// sum over time with the same two passes (training: gradient of a per-utterance bias broadcast over the frames, glue G3)
+extern "C" int sfm_sum_time(const float* src, float* dst, float* scratch, int B, int T, int C, long long ld_src, void* stream) {
+  if (!src || !dst || !scratch) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0 || C <= 0 || B > 65535) return SFM_ERR_SHAPE;
+  const int nchunk = (T + 63) / 64;
+  SFM_LAUNCH(mean_time_partial_kernel, dim3((C + 255) / 256, nchunk, B), dim3(256), 0, (hipStream_t)stream, src, scratch, T, C, ld_src,
+             nchunk);
+  SFM_LAUNCH(mean_time_final_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scratch, dst, 1.0f, C, nchunk);
   return SFM_OK;
 }
 
@@ -783,6 +795,37 @@ extern "C" int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst
   else
     SFM_LAUNCH((stft_lognorm_pack_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
                        (u16*)dst, M, F, zpad, ld_dst);
+  SFM_CHECK_LAUNCH();
+  return SFM_OK;
+}
+
+// adjoint of the normalisation above (training with a noisy STFT that carries a gradient): g[m, 0:F) / g[m, F:2F) are the
+// gradients of the normalised real / imaginary parts (fp32, leading dimension ld_g);  with n(mag) = log1p(mag) / mag,
+//   d re = g_r n + (g_r re + g_i im) n'(mag) re / mag,   n'(mag) = (1 / (1 + mag) - n) / mag      (and the same for im)
+__global__ __launch_bounds__(256) void stft_lognorm_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                               const float* __restrict__ g, float* __restrict__ dre,
+                                                               float* __restrict__ dim_, long long M, int F, long long ld_g) {
+  const long long total = M * F;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long m = e / F;
+    const int f = (int)(e - m * F);
+    const float r = re[e], i = im[e];
+    const float gr = g[m * ld_g + f], gi = g[m * ld_g + F + f];
+    const float mag = sqrtf(r * r + i * i + 1e-8f);
+    const float nf = log1pf(mag) / mag;
+    const float c = (gr * r + gi * i) * (1.0f / (1.0f + mag) - nf) / (mag * mag);
+    dre[e] = gr * nf + c * r;
+    dim_[e] = gi * nf + c * i;
+  }
+}
+
+extern "C" int sfm_stft_lognorm_bwd(const float* re, const float* im, const float* g, float* dre, float* dim_, long long M, int F,
+                                    long long ld_g, void* stream) {
+  if (!re || !im || !g || !dre || !dim_) return SFM_ERR_ARG;
+  if (M <= 0 || F <= 0 || ld_g < 2 * F) return SFM_ERR_SHAPE;
+  long long nb = (M * F + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  SFM_LAUNCH(stft_lognorm_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im, g, dre, dim_, M, F, ld_g);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
 }

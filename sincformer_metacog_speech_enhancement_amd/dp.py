@@ -20,14 +20,16 @@ def shard_range(n_items, rank, world):
 
 
 class FlatGradSynchronizer:
-    """Flat fp32 gradient buffer, preceded by a 64-float header whose first slot is the NaN/Inf flag: the flag rides
-    in bucket 0 (the first parameters, whose gradients are the LAST that backward produces) and costs no collective
-    of its own.  Gradients of the parameters are views of the buffer; buckets are runs of whole
+    """Flat fp32 gradient buffer, preceded by a header of 64 + n_params floats: slot 0 is the NaN/Inf flag, slots 64.. are
+    the per-parameter "received a gradient in this step" mask (0 / 1 per rank; after the all-reduce: the number of ranks whose
+    backward pass reached the parameter).  The header rides in bucket 0 (the first parameters, whose gradients are the LAST
+    that backward produces) and costs no collective of its own; optim.FlatAdamW steps exactly the parameters whose reduced
+    mask is > 0, so replicas whose graphs differ (data-dependent routing) still take the same decision.  Gradients of the parameters are views of the buffer; buckets are runs of whole
     parameters of about `bucket_bytes`.  With overlap=True every bucket is all-reduced (async, RCCL's own stream) as
     soon as autograd has accumulated the gradient of its last parameter, so the exchange overlaps the rest of the
     backward pass; finish() launches what is left and waits."""
 
-    HEADER = 64
+    HEADER = 64                                   # fixed part of the header; the touched mask follows it
 
     def __init__(self, params, bucket_bytes=16 << 20, group=None, overlap=False):
         self.params = [p for p in params if p.requires_grad]
@@ -36,10 +38,14 @@ class FlatGradSynchronizer:
         n = sum(p.numel() for p in self.params)
         self.n = n
         dev = self.params[0].device
-        H = self.HEADER
+        H = self.HEADER + ((len(self.params) + 63) // 64) * 64
+        self.header = H
         self.buf = torch.zeros(H + n, device=dev, dtype=torch.float32)
         self.flat = self.buf[H:]
         self.flag = self.buf[:1]
+        self.touched_dev = self.buf[self.HEADER:self.HEADER + len(self.params)]
+        self._mask_dev = torch.zeros(len(self.params), device=self.buf.device, dtype=torch.float32)
+        self._mask_host = ()                          # nothing uploaded yet
         off = 0
         per = max(1, bucket_bytes // 4)
         self.buckets, self._bucket_of, start = [], {}, 0
@@ -57,6 +63,7 @@ class FlatGradSynchronizer:
             self._members[self._bucket_of[id(p)]] += 1
         self._pending = list(self._members)
         self._launched = [False] * len(self.buckets)
+        self._next = len(self.buckets) - 1
         self._works = []
         self.overlap = overlap and self.world > 1
         # which parameters autograd accumulated into since zero(): a parameter off the loss's graph keeps its (zero) flat
@@ -86,8 +93,13 @@ class FlatGradSynchronizer:
             return
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
-        if self._pending[b] == 0 and b != 0:       # bucket 0 carries the flag: launched by finish()
-            self._launch(b)
+        # Buckets go out in ONE fixed order on every rank - last bucket first, bucket 0 (flag + touched mask) last, from
+        # finish() - whatever the order in which their gradients complete: a rank whose graph never reaches some parameter
+        # (data-dependent routing) simply stops launching from hooks at that bucket and finish() sends the rest, in the same
+        # order.  (Launching "whichever bucket is complete" pairs different buckets across such ranks.)
+        while self._next >= 1 and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next -= 1
 
     def untouched(self):
         """(offset, numel) in the flat buffers of every parameter that received no gradient since zero().  When autograd
@@ -101,6 +113,7 @@ class FlatGradSynchronizer:
         self._touched = [False] * len(self.params)
         self._pending = list(self._members)
         self._launched = [False] * len(self.buckets)
+        self._next = len(self.buckets) - 1
         self._works = []
 
     def set_flag(self, loss):
@@ -108,16 +121,31 @@ class FlatGradSynchronizer:
         if loss is not None:
             self.flag.copy_((~torch.isfinite(loss.detach().float())).float().reshape(1))
 
+    def _publish_touched(self):
+        """this rank's 0 / 1 mask -> header, before bucket 0 goes out.  The mask lives on the device (`_mask_dev`) and is copied
+        into the (zeroed, all-reduced) header with one device-to-device copy per step; it is uploaded again only when it
+        CHANGES, from a fresh pinned tensor (the host never rewrites pinned memory a pending copy may still read).  When autograd
+        accumulated into NO parameter the gradients were written into the flat views by hand: all ones then."""
+        mask = tuple(self._touched) if any(self._touched) else None
+        if mask != self._mask_host:
+            self._mask_host = mask
+            src = torch.tensor(mask if mask is not None else [True] * len(self.params), dtype=torch.float32)
+            if self.buf.is_cuda:
+                src = src.pin_memory()
+            self._mask_dev.copy_(src, non_blocking=True)
+        self.touched_dev.copy_(self._mask_dev)
+
     def finish(self, loss=None):
         """launch the remaining buckets and wait; the buffer then holds the SUM over ranks (callers fold 1/world into
-        their unscale factor, see optim.FlatAdamW)."""
+        their unscale factor, see optim.FlatAdamW), the header the flag and the summed touched mask."""
         self.set_flag(loss)
+        self._publish_touched()
         if self.world > 1:
             ev = None
             if self.time_exposed and self.buf.is_cuda:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            for b in range(len(self.buckets)):
+            for b in range(len(self.buckets) - 1, -1, -1):         # the fixed order: descending, bucket 0 last
                 if not self._launched[b]:
                     self._launch(b)
             for w in self._works:

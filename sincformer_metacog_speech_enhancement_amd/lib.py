@@ -45,10 +45,12 @@ SIGNATURES = {
     "sfm_pool_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_mean_time_scratch_floats": [c_i, c_i, c_i],
     "sfm_mean_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_vp],
+    "sfm_sum_time": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_vp],
     "sfm_pool_time_bwd": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_vp],
     "sfm_pool_time_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_pool_time_affine16": [c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_ll, c_ll, c_i, c_vp],
     "sfm_stft_lognorm_pack": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_i, c_vp],
+    "sfm_stft_lognorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_ll, c_vp],
     "sfm_polar_mask": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_i, c_f, c_ll, c_ll,
                        c_vp],
     "sfm_complex_mul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
@@ -68,7 +70,7 @@ SIGNATURES = {
     "sfm_sisnr_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp],
     "sfm_spec_loss_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_ll, c_i, c_i, c_f, c_vp],
     "sfm_stft_adjoint_ola": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "sfm_polar_mask_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_f, c_ll, c_ll, c_vp],
+    "sfm_polar_mask_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_i, c_f, c_ll, c_ll, c_vp],
     "sfm_attention_bwd_generic": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_i,
                                   c_vp],
     "sfm_ssnr_frames": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp],
@@ -91,12 +93,14 @@ SIGNATURES = {
     "sfm_vq_backward": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_vp],
     "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp],
     "sfm_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp],
+    "sfm_adamw_step_masked": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_vp, c_i, c_vp],
     "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_conv_wgrad16": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_vp],
     "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
     "sfm_ew_train": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_uint, c_i, c_vp],
     "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "sfm_bn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_f, c_f, c_i, c_vp],
     "sfm_bn_swish_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_dwconv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_dwconv_wgrad_scratch_floats": [c_i, c_i, c_i, c_i],
@@ -108,6 +112,7 @@ SIGNATURES = {
     "sfm_bilstm_layer_train": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "sfm_memory_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
+    "sfm_memory_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
 }
 
 _lib = None

@@ -729,10 +729,19 @@ def stft_adjoint_ola(frames, dwave, B, T, Ln, n_fft, hop, win, accumulate=True, 
                                                1 if accumulate else 0, _stream()), 0.0, 4.0 * (B * T * win + 2 * B * Ln))
 
 
-def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits):
+def polar_mask_bwd(lm, lp, nr, ni, der, dei, dlog, M, F, phase_scale, ld_logits, mag_bias=None, rows_per_batch=None):
     L = _lib.load()
-    _call("loss_bwd", L.sfm_polar_mask_bwd, (_p(lm), _p(lp), _p(nr), _p(ni), _p(der), _p(dei), _p(dlog), M, F, float(phase_scale),
-                                             ld_logits, dlog.stride(0), _stream()), 0.0, 32.0 * M * F)
+    _call("loss_bwd", L.sfm_polar_mask_bwd, (_p(lm), _p(lp), _p(mag_bias), _p(nr), _p(ni), _p(der), _p(dei), _p(dlog), M,
+                                             rows_per_batch or M, F, float(phase_scale), ld_logits, dlog.stride(0), _stream()),
+          0.0, 32.0 * M * F)
+
+
+def sum_time(src32, B, T, C, ld_src):
+    L = _lib.load()
+    out = torch.empty(B, C, device=src32.device, dtype=torch.float32)
+    scratch = torch.empty(int(L.sfm_mean_time_scratch_floats(B, T, C)), device=src32.device, dtype=torch.float32)
+    _call("pool_time", L.sfm_sum_time, (_p(src32), _p(out), _p(scratch), B, T, C, ld_src, _stream()), 0.0, 4.0 * B * T * C)
+    return out
 
 
 def sinc_wgrad(wave, dy, C, K, exact=False):
@@ -931,7 +940,7 @@ def layernorm_bwd(x32, gamma, dy32, dres32, dgamma, dbeta, eps=1e-5):
     return dx
 
 
-EW_SWISH_FWD, EW_SWISH_BWD, EW_GLU_FWD, EW_GLU_BWD, EW_SCALE_DROP, EW_GELU_FWD, EW_GELU_BWD = range(7)
+EW_SWISH_FWD, EW_SWISH_BWD, EW_GLU_FWD, EW_GLU_BWD, EW_SCALE_DROP, EW_GELU_FWD, EW_GELU_BWD, EW_CPEA_BWD = range(8)
 
 
 def ew_train(mode, out, z=None, g=None, N=None, alpha=1.0, p=0.0, seed=0):
@@ -950,6 +959,16 @@ def col_stats(y32, aux=None, mean=None, rstd=None):
     S = torch.zeros(C, 2, device=y32.device, dtype=torch.float32)
     _call("col_stats", L.sfm_col_stats, (_p(y32), _p(aux), _p(mean), _p(rstd), _p(S), M, C, _stream()))
     return S
+
+
+def bn_finalize(S, gamma, beta, run_mean, run_var, M, eps, momentum, eval_mode=False):
+    """-> mean, rstd, sc [1, C], sh [1, C]; the fp32 running statistics are updated in place (training)"""
+    L = _lib.load()
+    C = gamma.numel()
+    buf = torch.empty(4, C, device=gamma.device, dtype=torch.float32)
+    _call("col_stats", L.sfm_bn_finalize, (_p(S), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(buf[0]), _p(buf[1]), _p(buf[2]),
+                                           _p(buf[3]), C, M, float(eps), float(momentum), 1 if eval_mode else 0, _stream()))
+    return buf[0], buf[1], buf[2:3], buf[3:4]
 
 
 def bn_swish_bwd(g, y32, mean, rstd, gamma, beta, eval_mode=False):
@@ -1030,6 +1049,24 @@ def bilstm_layer_bwd(save, whh, dout, B, T, H):
     dxg = torch.empty(B, T, 2, 4 * H, device=dout.device, dtype=torch.float32)
     _call("bilstm_bwd", L.sfm_bilstm_layer_bwd, (_p(save), _p(whh), _p(dout), _p(dxg), B, T, H, _stream()))
     return dxg
+
+
+def stft_lognorm_bwd(re, im, g, M, F):
+    L = _lib.load()
+    dre, dim_ = torch.empty_like(re), torch.empty_like(im)
+    _call("stft_lognorm_bwd", L.sfm_stft_lognorm_bwd, (_p(re), _p(im), _p(g), _p(dre), _p(dim_), M, F, g.stride(0), _stream()))
+    return dre, dim_
+
+
+def memory_bwd(emb, params, d_out, d_gate, key_dim, value_dim, slots, temperature, want_d_emb=True):
+    """-> (d_emb [B, key_dim] or None, dparams: blob laid out like `params`)"""
+    L = _lib.load()
+    Bn = emb.shape[0]
+    d_emb = torch.empty(Bn, key_dim, device=emb.device, dtype=torch.float32) if want_d_emb else None
+    dparams = torch.zeros_like(params)
+    _call("memory_bwd", L.sfm_memory_bwd, (_p(emb), _p(params), _p(d_out), _p(d_gate), _p(d_emb), _p(dparams), Bn, key_dim, value_dim,
+                                           slots, float(temperature), _stream()))
+    return d_emb, dparams
 
 
 def memory_fwd(emb, params, key_dim, value_dim, slots, temperature):

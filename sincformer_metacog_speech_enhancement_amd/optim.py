@@ -29,6 +29,10 @@ class FlatAdamW:
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.ctl = torch.zeros(8, device=dev, dtype=torch.float64)
+        offs = [0]
+        for _, k in self.sync._spans:
+            offs.append(offs[-1] + k)
+        self.spans = torch.tensor(offs, device=dev, dtype=torch.int64)
 
     def zero_grad(self):
         self.sync.zero()
@@ -41,16 +45,16 @@ class FlatAdamW:
         ops._call("optim", L.sfm_sumsq, (ops._p(self.sync.flat), n, self.ctl[1:].data_ptr(), ops._stream()), 0.0, 4.0 * n)
         self.ctl[2:3].copy_(self.sync.flag.double())
         inv = 1.0 / (float(grad_scale) * self.sync.world)
-        # parameters autograd did not reach this step (`p.grad is None` for torch.optim.AdamW: no decay, no update): the flat
-        # kernel steps everything, so their values are put back afterwards; their moments stay zero either way
-        idle = self.sync.untouched()
-        kept = [self.flat_p[o:o + k].clone() for o, k in idle]
-        ops._call("optim", L.sfm_adamw_step, (ops._p(self.flat_p), ops._p(self.sync.flat), ops._p(self.m), ops._p(self.v), n,
-                                              ops._p(self.ctl), float(lr if lr is not None else self.lr), self.betas[0],
-                                              self.betas[1], self.eps, self.weight_decay, inv, float(self.max_norm or 0.0), 0,
-                                              ops._stream()), 0.0, 28.0 * n)
-        for (o, k), val in zip(idle, kept):
-            self.flat_p[o:o + k].copy_(val)
+        # parameters no rank's backward pass reached in this step (`p.grad is None` for torch.optim.AdamW: no decay, no update,
+        # moments unchanged) are skipped ON THE DEVICE from the mask that was all-reduced with the gradients
+        # (dp.FlatGradSynchronizer): p, m and v stay as they are, and every replica takes the same decision.  (One global step
+        # count feeds the bias corrections; torch keeps one per parameter, which only differs for a parameter that is
+        # trained in some steps and idle in others.)
+        ops._call("optim", L.sfm_adamw_step_masked,
+                  (ops._p(self.flat_p), ops._p(self.sync.flat), ops._p(self.m), ops._p(self.v), n, ops._p(self.ctl),
+                   float(lr if lr is not None else self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, inv,
+                   float(self.max_norm or 0.0), 0, ops._p(self.spans), ops._p(self.sync.touched_dev), len(self.sync.params),
+                   ops._stream()), 0.0, 28.0 * n)
         self._bump_versions()                         # packed-weight caches key on the parameters' version counter
 
     def _bump_versions(self):

@@ -166,21 +166,18 @@ def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5, bn_eval=
     ones = torch.ones(D, device=x.device)
     yc = torch.empty(M, D, device=x.device, dtype=torch.float32)
     ops.dwconv_folded(g16, wdw.t().contiguous(), ones, bdw, B, T, D, out=yc, act=0)   # conv + bias, fp32
-    if bn_eval:                                                              # eval(): the running statistics, no update
-        mean, var = bn_buffers[0].detach().float(), bn_buffers[1].detach().float()
-    else:
-        S = ops.col_stats(yc)
-        mean = S[:, 0] / M
-        var = (S[:, 1] / M - mean * mean).clamp_min(0.0)
-    rstd = torch.rsqrt(var + eps)
-    if bn_buffers is not None and not bn_eval:                               # running statistics (unbiased var), momentum 0.1
-        rm, rv, nbt = bn_buffers
+    # statistics -> mean, rstd, folded affine and the running-statistics update (unbiased var, momentum) in one launch
+    rm, rv = (bn_buffers[0], bn_buffers[1]) if bn_buffers is not None else (None, None)
+    fp32_buffers = rm is not None and rm.dtype == torch.float32 and rv.dtype == torch.float32
+    rm32, rv32 = (rm, rv) if fp32_buffers or rm is None else (rm.detach().float(), rv.detach().float())
+    S = None if bn_eval else ops.col_stats(yc)
+    mean, rstd, sc, sh = ops.bn_finalize(S, gam, bet, rm32, rv32, M, eps, momentum, eval_mode=bn_eval)
+    if bn_buffers is not None and not bn_eval:
         with torch.no_grad():
-            rm.mul_(1 - momentum).add_(momentum * mean.to(rm.dtype))
-            rv.mul_(1 - momentum).add_(momentum * (var * (M / max(M - 1, 1))).to(rv.dtype))
-            nbt += 1
-    sc = (gam * rstd).reshape(1, D).contiguous()
-    sh = (bet - mean * gam * rstd).reshape(1, D).contiguous()
+            if not fp32_buffers:
+                rm.copy_(rm32)
+                rv.copy_(rv32)
+            bn_buffers[2].add_(1)
     s16 = torch.empty(M, D, device=x.device, dtype=dt)
     ops.gn_apply(yc, sc, sh, s16, 1, M, D, act=2)                            # BatchNorm + Swish
     sd = seeds.next()
@@ -724,21 +721,109 @@ class LayerNormFunction(torch.autograd.Function):
         return dx.to(t[0]), dg.to(t[1]), db.to(t[2])
 
 
+class MaskHeadFunction(torch.autograd.Function):
+    """bounded polar mask of agents/msa.py:166-172 from the two heads' logits [M, F] (+ the per-utterance magnitude-logit
+    bias [B, F] of glue G3, or None): (mask_real, mask_imag) [B, T, F] = sigmoid(lm + bias) * (cos, sin)(tanh(lp) * pi/8).
+    Backward: sfm_polar_mask_bwd with the bias and no noisy spectrum; d bias = sum over the frames (sfm_sum_time)."""
+
+    @staticmethod
+    def forward(ctx, lm, lp, mag_bias, B, T, phase_scale):
+        lm32, lp32 = lm.detach().float(), lp.detach().float()
+        if lm32.stride(1) != 1 or lp32.stride(1) != 1 or lm32.stride(0) != lp32.stride(0):
+            lm32, lp32 = lm32.contiguous(), lp32.contiguous()
+        F = lm32.shape[-1]
+        bias = mag_bias.detach().float().contiguous() if mag_bias is not None else None
+        mr = torch.empty(B, T, F, device=lm.device, dtype=torch.float32)
+        mi = torch.empty(B, T, F, device=lm.device, dtype=torch.float32)
+        ops.polar_mask(lm32, lp32, B, T, F, phase_scale, lm32.stride(0), mag_bias=bias, mr=mr, mi=mi)
+        ctx.saved = (lm32, lp32, bias)
+        ctx.meta = (B, T, F, phase_scale, lm.dtype, lp.dtype, mag_bias.dtype if mag_bias is not None else None)
+        return mr, mi
+
+    @staticmethod
+    def backward(ctx, dmr, dmi):
+        lm32, lp32, bias = ctx.saved
+        B, T, F, ps, t0, t1, t2 = ctx.meta
+        M = B * T
+        ld = ops.round_up(2 * F, 8)
+        dl = torch.empty(M, ld, device=lm32.device, dtype=torch.float32)
+        ops.polar_mask_bwd(lm32, lp32, None, None, dmr.detach().float().contiguous(), dmi.detach().float().contiguous(), dl, M, F,
+                           ps, lm32.stride(0), mag_bias=bias, rows_per_batch=T)
+        db = None
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = ops.sum_time(dl, B, T, F, ld).to(t2)
+        ctx.saved = None
+        return dl[:, :F].to(t0), dl[:, F:2 * F].to(t1), db, None, None, None
+
+
+class FusionInputLinearFunction(torch.autograd.Function):
+    """first Linear of MaskSynthesisAgent.fusion applied to the 8-way concatenation of agents/msa.py:134-141:
+    y [M, N] = cat(z_real^T, z_imag^T, rho_s, rho_n, phi1, phi2, lognorm(noisy_real), lognorm(noisy_imag)) @ W^T + b.
+    The concatenation never exists in fp32: the eight sources are written as 16-bit columns of the one [M, 1088] GEMM operand
+    by the transposing / converting / log1p-normalising kernels the inference path uses (functional._msa_pack_inputs), and
+    the backward GEMM's [M, 1026] result is handed back as column views (the two latents through a transposing copy, the
+    noisy STFT through sfm_stft_lognorm_bwd when it carries a gradient)."""
+
+    @staticmethod
+    def forward(ctx, z_real, z_imag, rho_s, rho_n, phi1, phi2, noisy_real, noisy_imag, W, b):
+        from . import functional as Fn
+        B, D, T = z_real.shape
+        M = B * T
+        cp = {"rho_s": rho_s.detach(), "rho_n": rho_n.detach(), "phi1": phi1.detach(), "phi2": phi2.detach()}
+        fused16, nr, ni = Fn._msa_pack_inputs(z_real.detach(), z_imag.detach(), cp, noisy_real.detach(), noisy_imag.detach())
+        N, K = W.shape
+        w32 = _f32(W)
+        y = ops.linear16(fused16, ops.pack_linear(w32, _f32(b), k_pad_to=Fn.FUSE_LD), out_dtype=torch.float32)
+        ctx.saved = (fused16, w32, nr, ni)
+        ctx.dims = (B, D, T, N, K, rho_s.shape[-1], nr.shape[-1])
+        ctx.dtypes = [t.dtype for t in (z_real, z_imag, rho_s, rho_n, phi1, phi2, noisy_real, noisy_imag, W, b)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        fused16, w32, nr, ni = ctx.saved
+        B, D, T, N, K, oc, F = ctx.dims
+        M = B * T
+        dev = dy.device
+        dy = dy.float()
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        Np = ops.round_up(N, 64)
+        dy16 = torch.empty(M, Np, device=dev, dtype=ops.compute_dtype())
+        ops.convert_rows(dy, dy16, M, N, Np, dy.stride(0), Np)
+        dW = torch.zeros(N, K, device=dev, dtype=torch.float32)
+        db = torch.zeros(N, device=dev, dtype=torch.float32)
+        ops.gemm16_tn(dy16[:, :N], fused16[:, :K], dW, db)
+        need = ctx.needs_input_grad
+        t = ctx.dtypes
+        grads = [None] * 8
+        if any(need[:8]):
+            df = ops.linear16(dy16, ops.pack_linear(w32.t().contiguous(), k_pad_to=Np), out_dtype=torch.float32)   # [M, K]
+            dfb = df.reshape(B, T, -1)
+            for i in (0, 1):
+                if need[i]:
+                    grads[i] = dfb[..., i * D:(i + 1) * D].transpose(1, 2).contiguous().to(t[i])
+            for i in range(4):
+                if need[2 + i]:
+                    grads[2 + i] = dfb[..., 2 * D + i * oc:2 * D + (i + 1) * oc].to(t[2 + i])
+            if need[6] or need[7]:
+                c0 = 2 * D + 4 * oc
+                dre, dim_ = ops.stft_lognorm_bwd(nr.reshape(M, F), ni.reshape(M, F), df[:, c0:], M, F)
+                grads[6] = dre.reshape(B, T, F).to(t[6]) if need[6] else None
+                grads[7] = dim_.reshape(B, T, F).to(t[7]) if need[7] else None
+        ctx.saved = None
+        return (*grads, dW.to(t[8]), db.to(t[9]))
+
+
 def msa_train_forward(msa, z_real, z_imag, cpea_outputs, noisy_real, noisy_imag, mag_logit_bias=None):
-    """MaskSynthesisAgent.forward (agents/msa.py:106-174) built from HIP autograd nodes: fusion MLP -> ComplexConformer
-    (its own training / eval-autograd path) -> two GELU heads -> bounded polar mask.  The log1p normalisation of the noisy
-    STFT and the concatenation carry no parameters and run as torch ops on the device (their inputs may carry gradients
-    from a trainable front-end)."""
+    """MaskSynthesisAgent.forward (agents/msa.py:106-174) built from HIP autograd nodes: fusion MLP (its first Linear reads
+    the eight inputs directly, FusionInputLinearFunction) -> ComplexConformer (its own training / eval-autograd path) -> two
+    GELU heads -> bounded polar mask."""
     B, D, T = z_real.shape
     M = B * T
-    nr, ni = noisy_real.float(), noisy_imag.float()
-    mag = torch.sqrt(nr ** 2 + ni ** 2 + 1e-8)
-    nf = torch.log1p(mag) / mag
-    fused = torch.cat([z_real.float().transpose(1, 2), z_imag.float().transpose(1, 2), cpea_outputs["rho_s"].float(),
-                       cpea_outputs["rho_n"].float(), cpea_outputs["phi1"].float(), cpea_outputs["phi2"].float(),
-                       nr * nf, ni * nf], dim=-1).reshape(M, -1)
     f = msa.fusion
-    x = LNLinearFunction.apply(fused, None, None, f[0].weight, f[0].bias)
+    x = FusionInputLinearFunction.apply(z_real, z_imag, cpea_outputs["rho_s"], cpea_outputs["rho_n"], cpea_outputs["phi1"],
+                                        cpea_outputs["phi2"], noisy_real, noisy_imag, f[0].weight, f[0].bias)
     x = GeluFunction.apply(LayerNormFunction.apply(x, f[1].weight, f[1].bias))
     x = LNLinearFunction.apply(x, None, None, f[3].weight, f[3].bias)
     x = LayerNormFunction.apply(x, f[4].weight, f[4].bias)
@@ -749,14 +834,7 @@ def msa_train_forward(msa, z_real, z_imag, cpea_outputs, noisy_real, noisy_imag,
         h = LNLinearFunction.apply(src.reshape(M, -1), None, None, seq[0].weight, seq[0].bias)
         heads.append(LNLinearFunction.apply(GeluFunction.apply(h), None, None, seq[2].weight, seq[2].bias))
     lm, lp = heads
-    if mag_logit_bias is not None:                                            # glue G3
-        lm = (lm.reshape(B, T, -1) + mag_logit_bias.float().unsqueeze(1)).reshape(M, -1)
-    logits = torch.cat([lm, lp], dim=-1)
-    F = lm.shape[-1]
-    ones = torch.ones(B, T, F, device=logits.device, dtype=torch.float32)
-    # mask = polar(logits) applied to the constant spectrum 1 + 0j: the "enhanced" outputs ARE mask_real, mask_imag
-    mr, mi, _ = PolarMaskFunction.apply(logits, ones, torch.zeros_like(ones), 3.14159 / 8.0)
-    return mr, mi
+    return MaskHeadFunction.apply(lm, lp, mag_logit_bias, B, T, 3.14159 / 8.0)
 
 
 # ---------------------------------------------------------------------------
@@ -836,10 +914,51 @@ class DropoutFunction(torch.autograd.Function):
         return dx.to(dtp), None, None
 
 
+class CpeaHeadsFunction(torch.autograd.Function):
+    """the four 64-wide heads of agents/cpea.py:57-76,100-105 as ONE GEMM with the bounded activations in its epilogue
+    (EPI_CPEA: sigmoid on the first half of the columns, pi * tanh on the second) -> [M, 4 * oc] fp32 = rho_s | rho_n | phi1 | phi2.
+    Backward: the activation derivative from the saved OUTPUTS (sfm_ew_train mode 7), then the two GEMMs of a Linear."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        import math
+        M, K = x.shape
+        N = W.shape[0]
+        x32 = x.detach().float()
+        if x32.stride(1) != 1:
+            x32 = x32.contiguous()
+        w32 = _f32(W)
+        x16 = torch.empty(M, K, device=x.device, dtype=ops.compute_dtype())
+        ops.convert_rows(x32, x16, M, K, K, x32.stride(0), K)
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        ops.linear16(x16, ops.pack_linear(w32, _f32(b)), epi=ops.EPI_CPEA, alpha=math.pi, nsplit=N // 2, out=y)
+        ctx.saved = (x16, w32, y)
+        ctx.dtypes = (x.dtype, W.dtype, b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import math
+        x16, w32, y = ctx.saved
+        M, K = x16.shape
+        N = w32.shape[0]
+        dev = dy.device
+        dz = torch.empty(M, N, device=dev, dtype=torch.float32)
+        ops.ew_train(ops.EW_CPEA_BWD, dz, z=y, g=dy.detach().float().contiguous(), alpha=math.pi)
+        Np = ops.round_up(N, 64)
+        dz16 = torch.empty(M, Np, device=dev, dtype=ops.compute_dtype())
+        ops.convert_rows(dz, dz16, M, N, Np, N, Np)
+        dW = torch.zeros(N, K, device=dev, dtype=torch.float32)
+        db = torch.zeros(N, device=dev, dtype=torch.float32)
+        ops.gemm16_tn(dz16[:, :N], x16, dW, db)
+        dx = ops.linear16(dz16, ops.pack_linear(w32.t().contiguous(), k_pad_to=Np), out_dtype=torch.float32)
+        t = ctx.dtypes
+        ctx.saved = None
+        return dx.to(t[0]), dW.to(t[1]), db.to(t[2])
+
+
 def cpea_train_forward(cpea, z_t):
-    """CorrelationPhaseEstimationAgent.forward (agents/cpea.py:79-112) from HIP autograd nodes; the sigmoid / tanh * pi
-    of the four 64-wide heads run as torch element-wise ops on the device."""
-    import math
+    """CorrelationPhaseEstimationAgent.forward (agents/cpea.py:79-112) from HIP autograd nodes."""
     if z_t.dim() == 3 and z_t.shape[-1] != cpea.input_dim:
         z_t = z_t.transpose(1, 2)
     x = z_t.float().contiguous()
@@ -856,29 +975,58 @@ def cpea_train_forward(cpea, z_t):
     heads = [cpea.rho_s_head[0], cpea.rho_n_head[0], cpea.phi1_head[0], cpea.phi2_head[0]]
     W = torch.cat([h.weight for h in heads], dim=0)
     b = torch.cat([h.bias for h in heads], dim=0)
-    lg = LNLinearFunction.apply(x.reshape(M, -1), None, None, W, b).reshape(B, T, -1)
+    y = CpeaHeadsFunction.apply(x.reshape(M, -1), W, b).reshape(B, T, -1)
     oc = heads[0].weight.shape[0]
-    return {"rho_s": torch.sigmoid(lg[..., :oc]), "rho_n": torch.sigmoid(lg[..., oc:2 * oc]),
-            "phi1": torch.tanh(lg[..., 2 * oc:3 * oc]) * math.pi, "phi2": torch.tanh(lg[..., 3 * oc:]) * math.pi}
+    return {"rho_s": y[..., :oc], "rho_n": y[..., oc:2 * oc], "phi1": y[..., 2 * oc:3 * oc], "phi2": y[..., 3 * oc:]}
+
+
+MEMORY_PARAM_ORDER = ("key_proj.0.weight", "key_proj.0.bias", "key_proj.1.weight", "key_proj.1.bias", "key_proj.3.weight",
+                      "key_proj.3.bias", "keys", "values", "value_proj.0.weight", "value_proj.0.bias", "gate.0.weight",
+                      "gate.0.bias")                                  # = functional.pack_memory_params
+
+
+class MemoryFunction(torch.autograd.Function):
+    """EpisodicMemory.forward (agents/memory.py:95-148) as the one-workgroup-per-utterance kernel of the inference path
+    (sfm_memory_fwd) and its adjoint (sfm_memory_bwd: forward recomputed in LDS, parameter gradients accumulated with
+    fp32 atomics into a blob laid out like the packed parameters).  Returns (gated bias [B, vd], gate [B, 1], top_indices,
+    similarity); the last two are bookkeeping outputs and carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, emb, temperature, *params):
+        e = emb.detach().float().contiguous()
+        blob = torch.cat([_f32(p).reshape(-1) for p in params]).contiguous()
+        kd, vd, S = params[0].shape[0], params[7].shape[1], params[6].shape[0]
+        bias, gate, top, sim = ops.memory_fwd(e, blob, kd, vd, S, temperature)
+        ctx.saved = (e, blob)
+        ctx.meta = (kd, vd, S, float(temperature), [tuple(p.shape) for p in params], [p.dtype for p in params], emb.dtype)
+        ctx.mark_non_differentiable(top, sim)
+        return bias, gate, top, sim
+
+    @staticmethod
+    def backward(ctx, d_bias, d_gate, _d_top, _d_sim):
+        e, blob = ctx.saved
+        kd, vd, S, temp, shapes, dtypes, edt = ctx.meta
+        Bn = e.shape[0]
+        dob = d_bias.detach().float().contiguous() if d_bias is not None else torch.zeros(Bn, vd, device=e.device)
+        dg = d_gate.detach().float().reshape(Bn).contiguous() if d_gate is not None else None
+        d_emb, dblob = ops.memory_bwd(e, blob, dob, dg, kd, vd, S, temp, want_d_emb=ctx.needs_input_grad[0])
+        outs, off = [], 0
+        for shp, dt in zip(shapes, dtypes):
+            k = 1
+            for d_ in shp:
+                k *= d_
+            outs.append(dblob[off:off + k].view(shp).to(dt))
+            off += k
+        ctx.saved = None
+        return (d_emb.to(edt) if d_emb is not None else None, None, *outs)
 
 
 def memory_train_forward(mem, emb):
-    """EpisodicMemory.forward (agents/memory.py:95-148) with autograd: the Linear / LayerNorm / GELU layers are the HIP
-    nodes above; the [B, 64]-slot cosine read-out (normalise, softmax, two small matmuls), tanh and the 1-unit gate are a
-    few thousand FLOPs per utterance and run as torch ops on the device."""
-    import torch.nn.functional as F
-    e = emb.float()
-    kp = mem.key_proj
-    q = LNLinearFunction.apply(e, None, None, kp[0].weight, kp[0].bias)
-    q = GeluFunction.apply(LayerNormFunction.apply(q, kp[1].weight, kp[1].bias))
-    q = LNLinearFunction.apply(q, None, None, kp[3].weight, kp[3].bias)
-    sim = (F.normalize(q, dim=-1) @ F.normalize(mem.keys.float(), dim=-1).t()) / mem.temperature
-    att = torch.softmax(sim, dim=-1)
-    retrieved = att @ mem.values.float()
-    bias = torch.tanh(LNLinearFunction.apply(retrieved, None, None, mem.value_proj[0].weight, mem.value_proj[0].bias))
-    gate = torch.sigmoid(F.linear(torch.cat([q, retrieved], dim=-1), mem.gate[0].weight.float(), mem.gate[0].bias.float()))
-    top = sim.argmax(dim=-1)
-    return {"bias": bias * gate, "gate": gate, "top_indices": top, "similarity": sim.max(dim=-1)[0]}
+    """EpisodicMemory.forward (agents/memory.py:95-148) with autograd: one HIP kernel each way (MemoryFunction)."""
+    sd = dict(mem.named_parameters())
+    params = [sd[k] for k in MEMORY_PARAM_ORDER]
+    bias, gate, top, sim = MemoryFunction.apply(emb, float(mem.temperature), *params)
+    return {"bias": bias, "gate": gate, "top_indices": top.long(), "similarity": sim}
 
 
 class IstftFunction(torch.autograd.Function):

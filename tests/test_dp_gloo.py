@@ -125,3 +125,46 @@ def test_bucket_overlap_hooks_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res)
+
+
+def _touched_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sincformer_metacog_speech_enhancement_amd import dp
+    torch.manual_seed(0)
+    trunk, head_a, head_b = torch.nn.Linear(8, 8), torch.nn.Linear(8, 2), torch.nn.Linear(8, 2)
+    params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    sync = dp.FlatGradSynchronizer(params, bucket_bytes=128, overlap=True)
+    x = torch.randn(4, 8)
+    sync.zero()
+    # data-dependent routing: rank 0's graph reaches head_a only, rank 1's head_b only; an extra head is reached by nobody
+    h = trunk(x)
+    loss = (head_a(h) if rank == 0 else head_b(h)).pow(2).mean()
+    loss.backward()
+    local_idle = len(sync.untouched())
+    sync.finish(loss)
+    mask = sync.touched_dev.clone()
+    # trunk: both ranks (2), each head: one rank (1) -> every replica steps all six tensors; locally two were idle
+    ok = local_idle == 2 and mask.tolist() == [2.0, 2.0, 1.0, 1.0, 1.0, 1.0]
+    gathered = [torch.zeros_like(mask) for _ in range(world)]
+    dist.all_gather(gathered, mask)
+    ok = ok and all(torch.equal(g_, mask) for g_ in gathered)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_touched_mask_is_reduced_with_the_gradients():
+    """replicas whose backward passes reach different parameters must still step the same set: the per-rank 0 / 1 mask rides
+    in the header of bucket 0 and comes back summed (optim.FlatAdamW steps a parameter when the sum is > 0)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_touched_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)

@@ -291,7 +291,10 @@ def test_full_size_objective_training_steps_on_the_north_star_composition():
     # same state, same data, no dropout: the first step of the two runs sees identical inputs (fp32 atomics in the weight
     # gradients and 16-bit operand noise behind them: DESIGN.md section 5)
     assert abs(h1[0] - h2[0]) <= 1e-3 * abs(h1[0]), (h1[0], h2[0])
-    assert abs(h1[1] - h2[1]) <= 1e-2 * abs(h1[1]), (h1[1], h2[1])
+    # the second step sees the first AdamW update, which is lr * g / (|g| + eps) = +-lr for EVERY element: an element whose
+    # gradient is at the level of the atomics' ordering noise takes a random sign, so the two runs part ways here (observed
+    # 0.1770 / 0.1801 and 0.1821 / 0.1821 on two boxes); the bound only says "the same trajectory"
+    assert abs(h1[1] - h2[1]) <= 5e-2 * abs(h1[1]), (h1[1], h2[1])
     assert abs(n1[0] - n2[0]) <= 0.1 * n1[0], (n1[0], n2[0])
     assert h1[-1] < h1[0], h1
 

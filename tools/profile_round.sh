@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02
 mkdir -p $O/prof
 # 1. kernel trace of the default bench command and of --streams 1
