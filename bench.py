@@ -245,7 +245,8 @@ def roofline_of(dominant, dom, traffic_src=None):
 
 
 def traffic_file(workload):
-    for d in ("profiles/r02", "profiles"):
+    rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit()), reverse=True)
+    for d in ["profiles/" + r for r in rounds] + ["profiles"]:                   # the newest round that measured this workload
         p = "%s/pmc_traffic_%s.json" % (d, workload)
         if os.path.exists(os.path.join(ROOT, p)):
             return p
@@ -447,6 +448,15 @@ def headline_shape(path, passes=4):
         for _ in range(3):
             ops.attention(qkv, B, T, H, hd, out=o)
         torch.cuda.synchronize()
+        # pass 1: 20 launches back to back between ONE pair of HIP events -> the average launch duration
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            ops.attention(qkv, B, T, H, hd, out=o)
+        e1.record()
+        torch.cuda.synchronize()
+        avg = e0.elapsed_time(e1) / 20.0
+        # pass 2: an event after every launch -> the spread (each interval then also holds the event's own packet)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
         ev[0].record()
         for i in range(20):
@@ -454,16 +464,15 @@ def headline_shape(path, passes=4):
             ev[i + 1].record()
         torch.cuda.synchronize()
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))
-    avg = sum(ms) / len(ms)
     med = 0.5 * (ms[9] + ms[10])
     fl = 4.0 * B * H * T * T * hd
     out["attention"] = {"shape": "B256 x T512 x 4 heads x 64", "operands": "bf16" if adt is torch.bfloat16 else "fp16",
                         "avg_ms": avg, "median_ms": med, "min_ms": ms[0], "tflops": fl / avg / 1e9,
                         "frac_bf16_mfma_peak": fl / avg / 1e9 / PEAKS["mfma16"], "frac_at_median": fl / med / 1e9 / PEAKS["mfma16"],
-                        "frac_at_min": fl / ms[0] / 1e9 / PEAKS["mfma16"], "launches": 20, "kernel": "attn_fwd_hd64p (attention_pipe.hip)",
-                        "note": "kernel alone on the device, random (gaussian) Q K V, 20 back-to-back launches, HIP events "
-                                "between launches (so each figure includes the gap to the next launch); tflops / "
-                                "frac_bf16_mfma_peak are from the AVERAGE"}
+                        "frac_at_min": fl / ms[0] / 1e9 / PEAKS["mfma16"], "launches": 20, "kernel": ops.attention_kernel_name(256, 512, 4),
+                        "note": "kernel alone on the device, random (gaussian) Q K V.  tflops / frac_bf16_mfma_peak: 20 launches back "
+                                "to back between one pair of HIP events (average launch duration, launch gaps included); median / "
+                                "min: a second pass with an event after every launch"}
     return out
 
 

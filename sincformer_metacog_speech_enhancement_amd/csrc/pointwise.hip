@@ -686,28 +686,56 @@ extern "C" int sfm_pool_time(const float* src, void* dst16, float* dst32, int B,
 }
 
 // adjoint of pool_time: dsrc[b, t, c] = sum over the windows i that contain t of dout[b, i, c] / |window i|
+// A thread owns VEC neighbouring channels (16-byte accesses when VEC = 4) and walks 16 consecutive source rows; the window
+// arithmetic is done once per row by every lane alike (scalar), the stream is the [B, Tin, C] fp32 write.
+template <int VEC>
 __global__ __launch_bounds__(256) void pool_time_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc, int Tin,
                                                             int Tout, int C, long long ld_dout, long long ld_dsrc) {
-  const int b = blockIdx.z, t = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  long long lo = ((long long)t * Tout) / Tin;
-  long long hi = (((long long)(t + 1)) * Tout + Tin - 1) / Tin - 1;
-  if (hi > Tout - 1) hi = Tout - 1;
-  float acc = 0.f;
-  for (long long i = lo; i <= hi; ++i) {
-    const long long s = (i * Tin) / Tout, e = ((i + 1) * Tin + Tout - 1) / Tout;
-    acc += dout[((long long)b * Tout + i) * ld_dout + c] / (float)(e - s);
+  constexpr int ROWS = 16;
+  const int b = blockIdx.z;
+  const int nv = C / VEC;                                   // channel vectors per row
+  const int per = 256 / nv > 0 ? 256 / nv : 1;              // rows handled side by side by one block (C <= 256 * VEC)
+  const int cv = threadIdx.x % nv, tr = threadIdx.x / nv;
+  const int v = blockIdx.x * 256 + threadIdx.x;             // (C > 256 * VEC: blockIdx.x walks the channel vectors)
+  const int c = (nv >= 256 ? v : cv) * VEC;
+  if (c >= C || (nv < 256 && tr >= per)) return;
+  const int t0 = (blockIdx.y * (nv >= 256 ? 1 : per) + (nv >= 256 ? 0 : tr)) * ROWS;
+  for (int t = t0; t < min(Tin, t0 + ROWS); ++t) {
+    long long lo = ((long long)t * Tout) / Tin;
+    long long hi = (((long long)(t + 1)) * Tout + Tin - 1) / Tin - 1;
+    if (hi > Tout - 1) hi = Tout - 1;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (long long i = lo; i <= hi; ++i) {
+      const long long s_ = (i * Tin) / Tout, e_ = ((i + 1) * Tin + Tout - 1) / Tout;
+      const float w = 1.0f / (float)(e_ - s_);
+      const float* src = dout + ((long long)b * Tout + i) * ld_dout + c;
+      if (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(src);
+        acc[0] += q.x * w; acc[1] += q.y * w; acc[2] += q.z * w; acc[3] += q.w * w;
+      } else {
+        acc[0] += src[0] * w;
+      }
+    }
+    float* dst = dsrc + ((long long)b * Tin + t) * ld_dsrc + c;
+    if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else dst[0] = acc[0];
   }
-  dsrc[((long long)b * Tin + t) * ld_dsrc + c] = acc;
 }
 
 extern "C" int sfm_pool_time_bwd(const float* dout, float* dsrc, int B, int Tin, int Tout, int C, long long ld_dout,
                                  long long ld_dsrc, void* stream) {
   if (!dout || !dsrc) return SFM_ERR_ARG;
-  if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0 || Tin > 65535 * 16 || B > 65535) return SFM_ERR_SHAPE;
-  dim3 grid((C + 255) / 256, Tin, B), block(256);
-  SFM_LAUNCH(pool_time_bwd_kernel, grid, block, 0, (hipStream_t)stream, dout, dsrc, Tin, Tout, C, ld_dout, ld_dsrc);
+  if (B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0 || B > 65535) return SFM_ERR_SHAPE;
+  const bool vec = (C % 4 == 0) && (ld_dout % 4 == 0) && (ld_dsrc % 4 == 0) && (((uintptr_t)dout | (uintptr_t)dsrc) % 16 == 0);
+  const int nv = vec ? C / 4 : C;
+  const int per = nv >= 256 ? 1 : 256 / nv;
+  const long long row_blocks = ((long long)Tin + 16LL * per - 1) / (16LL * per);
+  if (row_blocks > 65535) return SFM_ERR_SHAPE;
+  dim3 grid(nv >= 256 ? (nv + 255) / 256 : 1, (unsigned)row_blocks, B), block(256);
+  if (vec) SFM_LAUNCH((pool_time_bwd_kernel<4>), grid, block, 0, (hipStream_t)stream, dout, dsrc, Tin, Tout, C, ld_dout, ld_dsrc);
+  else SFM_LAUNCH((pool_time_bwd_kernel<1>), grid, block, 0, (hipStream_t)stream, dout, dsrc, Tin, Tout, C, ld_dout, ld_dsrc);
   SFM_CHECK_LAUNCH();
   return SFM_OK;
 }

@@ -465,6 +465,22 @@ def pack_f32_matrix(wt_kn):
 ATTN_QSCALE_LOG2E = 1.4426950408889634
 
 
+def attention_kernel_name(B, T, H, variant=None):
+    """name of the forward kernel sfm_attention_fwd_ex picks for head_dim 64 (mirrors the rule in csrc/attention.hip)"""
+    v = _ATTN_VARIANT[0] if variant is None else variant
+    nqt5 = (T + 511) // 512
+    enough = B * H * nqt5 >= 128
+    if v == 0:
+        if enough and (T >= 1024 or 100 * T >= 78 * 512 * nqt5):
+            v = 4
+        elif enough and T <= 256 and 100 * T >= 90 * 256:
+            v = 5
+        else:
+            v = 2 if T >= 1024 else 1
+    return {1: "attn_fwd_hd64_kernel", 2: "attn_fwd_hd64x2_kernel", 3: "attn_fwd_hd64r_kernel", 4: "attn_fwd_hd64p8_kernel",
+            5: "attn_fwd_hd64p4_kernel"}[v]
+
+
 def set_attention_variant(v):
     """0: chosen by shape (default), 1: 32 query rows per wave, 3: persistent ring kernel, 4 / 5: pipelined persistent kernel
     with one 8-wave / two 4-wave workgroups per CU (A/B measurements).  Host-side state only: the value is passed to
@@ -900,18 +916,30 @@ def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
     return dW.reshape(N, ksize, Cin).permute(0, 2, 1).contiguous(), db
 
 
-def conv_dgrad16(dy16, weight, B, Lout, Lin, stride, pad, accumulate_into=None):
+def conv_dgrad16(dy16, weight, B, Lout, Lin, stride, pad, accumulate_into=None, out_dtype=torch.float32, add_even=None):
     """input gradient of Conv1d(weight [N, Cin, k], stride 1 or 2, zero padding) on channels-last tensors:
-    dy16 [B, Lout, N] 16-bit -> dx [B, Lin, Cin] fp32 (added to `accumulate_into` when given).  Stride 1 is the
+    dy16 [B, Lout, N] 16-bit -> dx [B, Lin, Cin] in `out_dtype` (fp32 or the 16-bit compute type).  Stride 1 is the
     correlation with the flipped, transposed kernel; stride 2 is that per output parity (two implicit GEMMs writing the
-    even / odd rows)."""
+    even / odd rows).  Every row is written exactly once, so there is no zero-fill and no read-modify-write:
+      add_even [B, ceil(Lin / stride), Cin] fp32: added to the rows of parity 0 in the GEMM's epilogue - the input gradient of a
+                 parallel k = 1 convolution with the same stride (the residual blocks' skip path, agents/perception.py:121-129);
+      accumulate_into (fp32 [B, Lin, Cin]): the older read-modify-write form, kept for a parity that has no tap."""
     N, Cin, k = weight.shape
     w = weight.detach().float()
-    dx = accumulate_into if accumulate_into is not None else torch.zeros(B, Lin, Cin, device=dy16.device, dtype=torch.float32)
+    plan = []
     for r in range(stride):
         t0 = (r + pad) % stride
         taps = list(range(t0, k, stride))
         nq = (Lin - r + stride - 1) // stride
+        plan.append((r, t0, taps, nq))
+    covered = all(taps and nq > 0 for _, _, taps, nq in plan)
+    if accumulate_into is not None:
+        dx = accumulate_into
+    elif covered:
+        dx = torch.empty(B, Lin, Cin, device=dy16.device, dtype=out_dtype)
+    else:
+        dx = torch.zeros(B, Lin, Cin, device=dy16.device, dtype=out_dtype)
+    for r, t0, taps, nq in plan:
         if not taps or nq <= 0:
             continue
         J = len(taps)
@@ -920,8 +948,15 @@ def conv_dgrad16(dy16, weight, B, Lout, Lin, stride, pad, accumulate_into=None):
         wf = torch.stack([w[:, :, taps[J - 1 - j]] for j in range(J)], dim=2).permute(1, 0, 2).contiguous()   # [Cin, N, J]
         pw = pack_linear(wf)
         view = dx.reshape(B, Lin * Cin)[:, r * Cin:]
-        gemm16(dy16, pw, view, B=B, Lout=nq, Lin=Lout, a_batch_stride=Lout * N, ldo=stride * Cin, o_batch_stride=Lin * Cin,
-               stride=1, pad=J - 1 - c0, epi=EPI_RESID, resid=view, ldr=stride * Cin, r_batch_stride=Lin * Cin, alpha=1.0)
+        kw = dict(B=B, Lout=nq, Lin=Lout, a_batch_stride=Lout * N, ldo=stride * Cin, o_batch_stride=Lin * Cin, stride=1,
+                  pad=J - 1 - c0)
+        if accumulate_into is not None:
+            gemm16(dy16, pw, view, epi=EPI_RESID, resid=view, ldr=stride * Cin, r_batch_stride=Lin * Cin, alpha=1.0, **kw)
+        elif add_even is not None and r == 0:
+            assert add_even.dtype == torch.float32 and add_even.shape[1] == nq
+            gemm16(dy16, pw, view, epi=EPI_RESID, resid=add_even, ldr=Cin, r_batch_stride=nq * Cin, alpha=1.0, **kw)
+        else:
+            gemm16(dy16, pw, view, **kw)
     return dx
 
 

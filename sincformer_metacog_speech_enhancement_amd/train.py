@@ -1166,12 +1166,12 @@ class PerceptionFunction(torch.autograd.Function):
         dWz, dbz0 = ops.conv_wgrad16(d_rz.reshape(B * Tpa, 2 * D), S["xd"], B, Tpa, Tpa, D, 2 * D, 1, 1, 0)
         G["real_proj.0.weight"], G["imag_proj.0.weight"] = dWz[:D], dWz[D:]
         G["real_proj.0.bias"], G["imag_proj.0.bias"] = dbz0[:D], dbz0[D:]
-        d_xd = ops.conv_dgrad16(d_rz, S["wz"], B, Tpa, Tpa, 1, 0)
+        d_xd = ops.conv_dgrad16(d_rz, S["wz"], B, Tpa, Tpa, 1, 0, out_dtype=dt)
         # downsample: conv k5 s2 p2 -> GN(16) -> GELU
         d_rd, G["downsample.1.weight"], G["downsample.1.bias"] = gnb(d_xd, 1, 16, [S["rd"]], S["td"], [P["downsample.1.weight"]])
         L3 = S["L3"]
         G["downsample.0.weight"], G["downsample.0.bias"] = ops.conv_wgrad16(d_rd.reshape(B * Tpa, D), S["x3"], B, Tpa, L3, D, D, 5, 2, 2)
-        dx = ops.conv_dgrad16(d_rd, P["downsample.0.weight"], B, Tpa, L3, 2, 2)
+        dx = ops.conv_dgrad16(d_rd, P["downsample.0.weight"], B, Tpa, L3, 2, 2, out_dtype=dt)
         # residual blocks, last to first
         for i in (2, 1, 0):
             b_ = S["blocks"][i]
@@ -1181,12 +1181,14 @@ class PerceptionFunction(torch.autograd.Function):
             res = gnb(dx, 1, Gp, [b_["r2"], b_["rs"]], b_["t2"], [P[pre + "main.4.weight"], P[pre + "skip.1.weight"]])
             d_r2, G[pre + "main.4.weight"], G[pre + "main.4.bias"], d_rs, G[pre + "skip.1.weight"], G[pre + "skip.1.bias"] = res
             G[pre + "main.3.weight"], G[pre + "main.3.bias"] = ops.conv_wgrad16(d_r2.reshape(B * L1, C), b_["a1"], B, L1, L1, C, C, 3, 1, 1)
-            d_a1 = ops.conv_dgrad16(d_r2, P[pre + "main.3.weight"], B, L1, L1, 1, 1)
+            d_a1 = ops.conv_dgrad16(d_r2, P[pre + "main.3.weight"], B, L1, L1, 1, 1, out_dtype=dt)
             d_r1, G[pre + "main.1.weight"], G[pre + "main.1.bias"] = gnb(d_a1, 1, Gp, [b_["r1"]], b_["t1"], [P[pre + "main.1.weight"]])
             G[pre + "main.0.weight"], G[pre + "main.0.bias"] = ops.conv_wgrad16(d_r1.reshape(B * L1, C), b_["xin"], B, L1, Lin, Cin, C, 7, 2, 3)
             G[pre + "skip.0.weight"], G[pre + "skip.0.bias"] = ops.conv_wgrad16(d_rs.reshape(B * L1, C), b_["xin"], B, L1, Lin, Cin, C, 1, 2, 0)
-            dx = ops.conv_dgrad16(d_r1, P[pre + "main.0.weight"], B, L1, Lin, 2, 3)
-            dx = ops.conv_dgrad16(d_rs, P[pre + "skip.0.weight"], B, L1, Lin, 2, 0, accumulate_into=dx)
+            # input gradient: the skip path (k 1, stride 2: even rows only) is a plain GEMM whose fp32 result rides into the main
+            # conv's even-row GEMM as its epilogue addend; dx is written once, in the 16-bit format the next node reads
+            skip_even = ops.conv_dgrad16(d_rs, P[pre + "skip.0.weight"], B, L1, L1, 1, 0)
+            dx = ops.conv_dgrad16(d_r1, P[pre + "main.0.weight"], B, L1, Lin, 2, 3, out_dtype=dt, add_even=skip_even)
         # sinc stage: GN(8) + GELU, then the FIR tap gradient and the chain rule to the cut-off parameters
         d_raw0, G["sinc_norm.weight"], G["sinc_norm.bias"] = gnb(dx, 1, 8, [S["raw0"]], S["t0"], [P["sinc_norm.weight"]])
         C0, K = S["filt_shape"]

@@ -268,6 +268,24 @@ def test_conv1d_wgrad_and_dgrad(ops, dt, B, Lin, Cin, N, k, s, p):
     base = arr("cvb", (B, Lin, Cin), 603).cuda()
     dx2 = ops.conv_dgrad16(dy16, w.cuda(), B, Lout, Lin, s, p, accumulate_into=base.clone())
     report("conv dgrad accumulate", (dx2 - base).cpu(), xr.grad, 3e-3 * float(xr.grad.abs().max()) + 1e-3)
+    # the training path's form: 16-bit result written once (no zero-fill, no read-modify-write); for the stride-2 convs the
+    # parallel k = 1 skip conv's input gradient (its own plain GEMM, fp32, even rows) rides in as the epilogue addend
+    dx16 = ops.conv_dgrad16(dy16, w.cuda(), B, Lout, Lin, s, p, out_dtype=dt)
+    assert dx16.dtype == dt
+    gmax = float(xr.grad.abs().max())
+    report("conv dgrad 16-bit out", dx16.float().cpu(), xr.grad, (3e-3 + (2 ** -8 if dt is torch.bfloat16 else 2 ** -11)) * gmax + 1e-3)
+    if s == 2 and (Lin + 2 * p - k) // 2 + 1 == (Lin + 1) // 2:
+        ws = q16(arr("cvws", (N, Cin, 1), 604, 0.1), dt)
+        dys = q16(arr("cvdys", (B, Lout, N), 605, 0.5), dt)
+        xs = x.clone().requires_grad_(True)
+        ys = F.conv1d(xs.transpose(1, 2), ws, None, stride=2, padding=0).transpose(1, 2)
+        assert ys.shape[1] == Lout
+        ys.backward(dys)
+        even = ops.conv_dgrad16(dys.cuda().to(dt).contiguous(), ws.cuda(), B, Lout, Lout, 1, 0)
+        both = ops.conv_dgrad16(dy16, w.cuda(), B, Lout, Lin, s, p, out_dtype=dt, add_even=even)
+        ref = xr.grad + xs.grad
+        report("conv dgrad main + skip", both.float().cpu(), ref,
+               (3e-3 + (2 ** -8 if dt is torch.bfloat16 else 2 ** -11)) * float(ref.abs().max()) + 1e-3)
 
 
 @pytest.mark.parametrize("B,L", [(1, 800), (3, 2113), (2, 16000)])
@@ -293,11 +311,13 @@ def test_sinc_fir_tap_gradient(B, L, dt):
     assert rel16 < 4 * EPS[dt]
 
 
+@pytest.mark.parametrize("C", [48, 512, 50, 1028])
 @pytest.mark.parametrize("Tin,Tout", [(200, 21), (21, 200), (150, 16), (7, 7), (1000, 101)])
-def test_pool_time_adjoint(Tin, Tout):
-    """glue G1 (adaptive average pooling over time) and its adjoint vs F.adaptive_avg_pool1d + autograd"""
+def test_pool_time_adjoint(Tin, Tout, C):
+    """glue G1 (adaptive average pooling over time) and its adjoint vs F.adaptive_avg_pool1d + autograd (C 512: the path's
+    latents; 50: the scalar kernel; 1028: more than 256 channel vectors per row)"""
     from sincformer_metacog_speech_enhancement_amd import train
-    B, C = 2, 48
+    B = 2
     x = arr("ptx", (B, Tin, C), 41)
     cot = arr("ptc", (B, Tout, C), 42)
     xr = x.clone().requires_grad_(True)

@@ -12,7 +12,7 @@ ap.add_argument("--frames", type=int, default=512)
 ap.add_argument("--heads", type=int, default=4)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--variant", type=int, default=0, help="0: auto by T, 1: 32 q rows/wave, 2: 64 q rows/wave (pipelined), 3: persistent ring kernel")
+ap.add_argument("--variant", type=int, default=0, help="0: auto, 1: 32 q rows/wave, 2: 64 q rows/wave, 3: persistent ring, 4 / 5: pipelined persistent kernel with 8 / 4 waves (attention_pipe.hip)")
 ap.add_argument("--check", action="store_true", help="compare with the 32-rows-per-wave kernel (variant 1) and fp32 torch on one (b, h)")
 a = ap.parse_args()
 ops.set_compute_dtype(a.dtype)
@@ -44,5 +44,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 fl = 4.0 * B * H * T * T * hd
-print(json.dumps({"kernel": "attn_fwd_hd64r" if (a.variant == 3 or (a.variant == 0 and 256 < a.frames <= 512 and B * H >= 256)) else "attn_fwd_hd64x2" if (a.variant == 2 or (a.variant == 0 and a.frames >= 1024)) else "attn_fwd_hd64", "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
+print(json.dumps({"kernel": ops.attention_kernel_name(B, T, H), "B": B, "T": T, "H": H, "dtype": a.dtype, "ms": ms,
                   "tflops": fl / ms / 1e9, "frac_of_2.5PF": fl / ms / 1e9 / 2500.0}))

@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes over tools/conv_bench.py (conv16p on the PerceptionAgent layer shapes), summary per kernel instantiation
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-out=$ROOT/gpurun_out/r02/pmc_conv16p
+out=$ROOT/gpurun_out/${SFM_ROUND:-r03}/pmc_conv16p
 mkdir -p $out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; sub=$2; shift 2
-out=$ROOT/gpurun_out/r02/pmc_$tag
+out=$ROOT/gpurun_out/${SFM_ROUND:-r03}/pmc_$tag
 mkdir -p $out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \

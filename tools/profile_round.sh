@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${SFM_ROUND:-r03}
 mkdir -p $O/prof
 # 1. kernel trace of the default bench command and of --streams 1
 rocprofv3 --kernel-trace --stats -d $O/prof/c2 -o c2 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-headline > $O/prof/bench_c2_profiled.json 2> $O/prof/c2.log

@@ -27,7 +27,7 @@ def main():
     ops.set_compute_dtype(a.dtype)
     B, L, desc = bench.WORKLOADS[a.workload]
     B = a.batch or B
-    if a.workload == "c2t":
+    if a.workload in ("c2t", "c3t"):
         model, _ = bench.build_path(a.dtype, seed=4321)
     else:
         model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15)
@@ -40,7 +40,7 @@ def main():
 
     def step():
         opt.zero_grad()
-        if a.workload == "c2t":
+        if a.workload in ("c2t", "c3t"):
             total, _ = compute_path_loss(model, noisy, clean)
         else:
             total, _ = compute_loss(model, *batch_stft(noisy, 256, 80, 160), clean, *batch_stft(clean, 256, 80, 160))
