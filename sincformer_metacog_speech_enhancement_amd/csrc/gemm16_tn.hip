@@ -356,10 +356,23 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const void* __restrict_
   }
 }
 
+// gemm16_tn2.hip: the LDS-DMA ring form (SFM_ERR_SHAPE = not a shape it takes)
+int sfm_tn2_launch(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw, int dtype,
+                   void* stream, const TnConv& cv, long long x_elems, int variant);
+
 static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw,
-                            int dtype, void* stream, TnConv cv) {
+                            int dtype, void* stream, TnConv cv, long long x_elems) {
   if (!G || !X || !dW) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (cv.Lout == 0 && (ldx % 8) != 0)) return SFM_ERR_SHAPE;
+  // The LDS-DMA ring kernel (gemm16_tn2.hip) takes the Conv1d / sinc-FIR weight gradients (M = 1 .. 16 M im2col rows: 1.3-1.4x the first
+  // kernel, profiles/README.md round 3); on the plain K = 256 / 1024 linears the 256 x 256-tile kernel below stays ahead.
+  // A/B knob (tools/gemm_tn_bench.py): SFM_TN2 = 0 first kernels only, 1 / 2 = ring kernel everywhere, 128 x 128 / 128 x 256 tiles
+  static const int tn2 = getenv("SFM_TN2") ? atoi(getenv("SFM_TN2")) : -1;
+  const bool tn2_auto = (tn2 < 0) && cv.Lout > 0;              // conv and the sinc bank's Toeplitz form (2.6 -> 1.8 ms at B 256 x 4 s)
+  if ((tn2 > 0 || tn2_auto) && M >= 4096) {
+    const int rc = sfm_tn2_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv, x_elems, tn2 > 0 ? tn2 : 2);
+    if (rc != SFM_ERR_SHAPE) return rc;
+  }
   static const int wide_on = getenv("SFM_TN_WIDE") ? atoi(getenv("SFM_TN_WIDE")) : 1;          // A/B knob
   if (wide_on && cv.Lout == 0 && cv.toeplitz == 0 && (N % 256) == 0 && (K % 256) == 0 && M >= 8192) {
     const int tiles_w = (N / 256) * (K / 256);
@@ -415,7 +428,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
 extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx,
                              int ldw, int dtype, void* stream) {
   TnConv cv = {0, 0, 0, 0, 0, 0, 0};
-  return gemm16_tn_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv);
+  return gemm16_tn_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv, (long long)(M - 1) * ldx + K);
 }
 
 // Conv1d weight gradient: G = dY [B*Lout, N] (16-bit), x [B, Lin, Cin] channels-last 16-bit;
@@ -425,7 +438,8 @@ extern "C" int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* 
                                 void* stream) {
   if (B <= 0 || Lout <= 0 || Lin <= 0 || Cin <= 0 || (Cin % 8) != 0 || ksize <= 0 || stride <= 0) return SFM_ERR_SHAPE;
   TnConv cv = {Lout, Lin, Cin, stride, pad, x_batch_stride, 0};
-  return gemm16_tn_launch(G, x, dW, db, B * Lout, N, ksize * Cin, ldg, 0, ldw, dtype, stream, cv);
+  return gemm16_tn_launch(G, x, dW, db, B * Lout, N, ksize * Cin, ldg, 0, ldw, dtype, stream, cv,
+                          (long long)(B - 1) * x_batch_stride + (long long)Lin * Cin);
 }
 
 // Tap gradient of the sinc FIR bank (agents/perception.py:115-118 backward) on the matrix cores.
@@ -457,7 +471,7 @@ extern "C" int sfm_sinc_shift_pack(const float* x, void* xs, int B, int L, int d
 extern "C" int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, void* stream) {
   if (B <= 0 || L <= 0 || C <= 0 || (C % 8) != 0 || (long long)B * L > 2000000000LL) return SFM_ERR_SHAPE;
   TnConv cv = {L, L, 1, 1, 128 - 125, sfm_sinc_shift_len(L), 1};
-  return gemm16_tn_launch(dy, xs, dW, nullptr, B * L, C, 256, C, 0, 256, dtype, stream, cv);
+  return gemm16_tn_launch(dy, xs, dW, nullptr, B * L, C, 256, C, 0, 256, dtype, stream, cv, (long long)B * 8 * sfm_sinc_shift_len(L));
 }
 
 extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream) {

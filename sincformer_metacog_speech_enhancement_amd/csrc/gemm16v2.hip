@@ -11,6 +11,7 @@
 //     bias / activation / GLU / residual / GroupNorm partials, then 16-byte row stores;
 //   * XCD-aware block order: the N-tiles of one M-tile (same A rows) run on one XCD (L2 reuse).
 #include "sfm_common.h"
+#include <cstdlib>
 
 #include "gemm16_epi.h"
 
@@ -239,6 +240,75 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
         for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(y[2 * e], y[2 * e + 1], p.out_f32 == 2);
         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
       }
+    }
+    continue;                                          // next 64-row pass of the wave tile
+  }
+  // Fused Swish of the FFN in training (EPI_SWISH_DUAL / EPI_SWISH_BWD: gemm16_epi.h).  Backward: ALL of the tile's saved
+  // derivative factors are requested before the first is used (in the strip epilogue of the wide / persistent kernels each of the
+  // 8 passes waits out its own global round trip: 0.53 ms per launch at M 205 056, N 1024 against 0.19 ms of HBM time).
+  // Forward: sigmoid by v_exp + v_rcp (1 ulp) instead of the division sequence; u and d from one sigmoid.
+  if ((p.epi == EPI_SWISH_BWD || p.epi == EPI_SWISH_DUAL) && ncol0 + 8 <= p.N) {
+    constexpr int CPR = WN >> 3, RPP = 64 / CPR;
+    const int c8s = (lane % CPR) * 8, rs = lane / CPR;
+    const int nc = colb + c8s;
+    u32x4 ax[CPR];
+    if (p.epi == EPI_SWISH_BWD) {
+#pragma unroll
+      for (int it = 0; it < CPR; ++it) {
+        int m = row_base + it * RPP + rs;
+        m = m < p.Lout ? m : p.Lout - 1;               // clamped: loaded, not used
+        ax[it] = *reinterpret_cast<const u32x4*>(p.aux + obase + (long long)m * p.ldo + nc);
+      }
+    }
+    f32x4 bb0 = {0.f, 0.f, 0.f, 0.f}, bb1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      bb0 = *reinterpret_cast<const f32x4*>(p.bias + nc);
+      bb1 = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
+    }
+    const float ik = (p.p_drop > 0.f) ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+#pragma unroll
+    for (int it = 0; it < CPR; ++it) {
+      const int row = it * RPP + rs;
+      const int m = row_base + row;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8s]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&img[row * IMG_LD + c8s + 4]);
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = x0[e] + bb0[e];
+        y[4 + e] = x1[e] + bb1[e];
+      }
+      const long long orow = obase + (long long)m * p.ldo + nc;
+      if (p.epi == EPI_SWISH_BWD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[2 * e] *= T::to_f32((u16)(ax[it][e] & 0xffffu));
+          y[2 * e + 1] *= T::to_f32((u16)(ax[it][e] >> 16));
+        }
+      } else {
+        float kp[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (p.p_drop > 0.f)
+          sfm_keep_scale8(p.seed, ((unsigned long long)b * p.Lout + (m < p.Lout ? m : 0)) * p.N + nc, p.p_drop, ik, kp);
+        float dd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y[e]));
+          const float ks = kp[e] * sg;
+          dd[e] = ks * (1.0f + y[e] * (1.0f - sg));
+          y[e] = y[e] * ks;
+        }
+        if (m < p.Lout) {
+          u32x4 pd;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pd[e] = pack2<T>(dd[2 * e], dd[2 * e + 1]);
+          *reinterpret_cast<u32x4*>(p.out2 + orow) = pd;
+        }
+      }
+      if (m >= p.Lout) continue;
+      u32x4 pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = pack2<T>(y[2 * e], y[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
     }
     continue;                                          // next 64-row pass of the wave tile
   }
@@ -691,7 +761,7 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
     if (out_f32 != 0 || (N % 8) != 0 || (ldo % 8) != 0 || (o_batch_stride % 8) != 0 || gn_partial) return SFM_ERR_SHAPE;
     if ((((uintptr_t)out) % 16) != 0 || (out2 && (((uintptr_t)out2) % 16) != 0) || (aux && (((uintptr_t)aux) % 16) != 0))
       return SFM_ERR_SHAPE;
-    if (variant != 6 && variant != 9 && variant != 10) variant = 0;
+    if (variant != 2 && variant != 6 && variant != 9 && variant != 10) variant = 0;
   }
   if (B <= 0 || Lout <= 0 || N <= 0 || out_f32 < 0 || out_f32 > 2) return SFM_ERR_SHAPE;
   const long long a_rec = ((long long)(Lin - 1) * lda + Cin) * 2;
@@ -759,7 +829,7 @@ static int gemm16_impl(const void* A, const void* W, const float* bias, void* ou
   hipStream_t st = (hipStream_t)stream;
   // the persistent kernel is 5-20 % faster than variant 2 on isolated launches of the path's skinny GEMMs
   // (tools/gemm_bench.py) but 2 % slower inside the forward pass (bench.py, same box, A/B/A/B): not the default
-  const bool persistent = (variant == 6) || (swish && !wide && !tall);   // the fused-Swish modes live in the strip epilogue
+  const bool persistent = (variant == 6) || (swish && !wide && !tall && variant != 2);
 #define GO(TT)                                                                                            \
   if (tall) return launch_w<TT, 512, 128, 16>(p, st);                                                   \
   if (wide) return wide256 ? launch_w<TT, 256, 256, 16>(p, st) : launch_w<TT, 256, 128, 8>(p, st);      \
@@ -789,8 +859,12 @@ extern "C" int sfm_gemm16_train(const void* A, const void* W, const float* bias,
 extern "C" int sfm_gemm16_swish(const void* A, const void* W, const float* bias, void* out, const void* aux, void* out2, int M,
                                 int Cin, int lda, int Kpad, int N, int Npad, int ldo, int backward, float p_drop,
                                 unsigned int seed, int dtype, void* stream) {
+  // 128 x 128 tiles with the whole-tile epilogue (variant 2): 0.34 / 0.29 ms per launch at M 205 056, N 1024, K 256 against 0.47 /
+  // 0.39 ms on the 256-row tiles with the strip epilogue and 0.46 / 0.49 ms on the persistent kernel (tools/gemm_train_bench.py,
+  // round 3).  A/B knob: SFM_SWISH_VARIANT = 0 (256-row tiles when they fill the chip), 6, 9, 10.
+  static const int sv = getenv("SFM_SWISH_VARIANT") ? atoi(getenv("SFM_SWISH_VARIANT")) : 2;
   return gemm16_impl(A, W, bias, out, nullptr, nullptr, 1, M, M, Cin, lda, 1, 1, 0, 0, Kpad, N, Npad, ldo, 0, 0, 0, 1.0f,
-                     backward ? EPI_SWISH_BWD : EPI_SWISH_DUAL, 0, 0, 0, dtype, 0, p_drop, seed, aux, out2, stream);
+                     backward ? EPI_SWISH_BWD : EPI_SWISH_DUAL, 0, 0, 0, dtype, sv, p_drop, seed, aux, out2, stream);
 }
 
 extern "C" int sfm_gemm16_ex(const void* A, const void* W, const float* bias, void* out, const float* resid,

@@ -31,7 +31,8 @@ def report(name, got, ref, tol):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (5000, 1024, 256), (333, 129, 128), (4096, 256, 1024), (70, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (5000, 1024, 256), (333, 129, 128), (4096, 256, 1024), (70, 768, 256),
+                                   (4500, 136, 72), (6001, 129, 128), (20011, 128, 448)])
 def test_gemm16_tn_and_colsum(ops, dt, M, N, K):
     ops.set_compute_dtype(dt)
     g, x = arr("tg", (M, N), 1) * 0.1, arr("tx", (M, K), 2)
@@ -245,7 +246,10 @@ def test_groupnorm_act_backward(ops, dt, B, L, C, G, act, two):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,Lin,Cin,N,k,s,p", [(2, 400, 64, 128, 7, 2, 3), (2, 301, 128, 128, 3, 1, 1), (3, 200, 64, 128, 1, 2, 0),
-                                               (1, 333, 256, 256, 5, 2, 2), (2, 150, 256, 512, 1, 1, 0)])
+                                               (1, 333, 256, 256, 5, 2, 2), (2, 150, 256, 512, 1, 1, 0),
+                                               # B * Lout >= 4096: the weight gradient runs on the LDS-DMA ring kernel (gemm16_tn2.hip)
+                                               (3, 4001, 64, 128, 7, 2, 3), (2, 2500, 128, 128, 3, 1, 1), (5, 2000, 64, 128, 1, 2, 0),
+                                               (2, 4099, 256, 256, 5, 2, 2), (1, 4500, 128, 256, 3, 1, 1)])
 def test_conv1d_wgrad_and_dgrad(ops, dt, B, Lin, Cin, N, k, s, p):
     """weight / bias / input gradients of the PerceptionAgent's Conv1d shapes (channels-last, implicit GEMMs) vs F.conv1d"""
     ops.set_compute_dtype(dt)

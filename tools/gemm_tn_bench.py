@@ -10,7 +10,10 @@ sys.path.insert(0, ROOT)
 SHAPES = [(205056, 1024, 256), (205056, 256, 1024), (205056, 256, 256), (205056, 768, 256), (205056, 512, 256),
           (51264, 1024, 256), (51264, 256, 1024), (51264, 256, 256)]
 CONVS = [(64, 32000, 64000, 64, 128, 7, 2, 3), (64, 16000, 32000, 128, 128, 7, 2, 3), (64, 8000, 16000, 128, 256, 7, 2, 3),
-         (64, 32000, 32000, 128, 128, 3, 1, 1), (64, 32000, 64000, 64, 128, 1, 2, 0)]
+         (64, 32000, 32000, 128, 128, 3, 1, 1), (64, 32000, 64000, 64, 128, 1, 2, 0),
+         # the training step at B 256 x 4 s (bench.py --workload c3t)
+         (256, 32000, 64000, 64, 128, 7, 2, 3), (256, 32000, 32000, 128, 128, 3, 1, 1), (256, 16000, 32000, 128, 128, 7, 2, 3),
+         (256, 8000, 16000, 128, 256, 7, 2, 3), (256, 8000, 8000, 256, 256, 3, 1, 1), (256, 4000, 8000, 256, 256, 5, 2, 2)]
 
 
 def main():
