@@ -340,6 +340,12 @@ int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, in
 /* BatchNorm1d training statistics / backward (through the following Swish) */
 int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C,
                   void* stream);
+/* gradient fan-in: out[m, c] = a[m, c] + (c < Cb ? b[m, c] : 0), fp32 rows with strides lda / ldb / ldo (C, Cb multiples of 4) */
+int sfm_add_cols(const float* a, const float* b, float* out, long long M, int C, int Cb, long long lda, long long ldb, long long ldo,
+                 void* stream);
+/* BiLSTM dW_hh operand: previous output of each chain, h fp32 [B, T, 2H] -> out 16-bit [B*T, 2H]
+ * (out[b,t,:H] = h[b,t-1,:H], out[b,t,H:] = h[b,t+1,H:], zero at the chain's first step) */
+int sfm_lstm_hprev16(const float* h, void* out, int B, int T, int H, int dtype, void* stream);
 /* nn.BatchNorm1d training statistics from sfm_col_stats' sums: mean, rstd, folded affine (sc, sh) and the in-place update of the
  * running statistics (unbiased variance; run_* may be NULL); eval_mode: statistics = run_mean / run_var, nothing updated */
 int sfm_bn_finalize(const float* S, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,

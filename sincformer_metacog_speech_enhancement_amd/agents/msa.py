@@ -35,9 +35,10 @@ class MaskSynthesisAgent(HipModule):
                     nn.init.zeros_(m.bias)
         nn.init.constant_(self.mask_proj_real[-1].bias, 5.0)
 
-    def forward(self, z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag, mag_logit_bias=None):
+    def forward(self, z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag, mag_logit_bias=None, latents_cl=None):
         """Returns (mask_real, mask_imag), each [B, T, n_freq] fp32.  `mag_logit_bias` ([B, n_freq],
-        optional, build-defined glue G3) is added to the magnitude logit before the sigmoid."""
+        optional, build-defined glue G3) is added to the magnitude logit before the sigmoid.  `latents_cl` (optional, train()
+        mode): z_real | z_imag as ONE channels-last [B, T, 2 latent_dim] tensor - the layout the path holds them in."""
         self._require_device(z_real, z_imag, noisy_stft_real, noisy_stft_imag)
         if z_real.shape[-1] != noisy_stft_real.shape[1]:
             raise RuntimeError("Sizes of tensors must match except in dimension 2. Expected size %d but got size %d "
@@ -45,7 +46,7 @@ class MaskSynthesisAgent(HipModule):
         if self.training or self._wants_autograd(z_real, z_imag, *cpea_outputs.values()):
             from .. import train                   # train() (or eval() under autograd): HIP autograd nodes
             return train.msa_train_forward(self, z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag,
-                                           mag_logit_bias)
+                                           mag_logit_bias, latents_cl=latents_cl)
         pk = self._packed(lambda sd: Fn.pack_msa(sd, self.conformer.num_blocks, self.conformer.num_heads))
         return Fn.msa_forward(z_real, z_imag, cpea_outputs, noisy_stft_real, noisy_stft_imag, pk,
                               self.conformer.num_heads, mag_bias=mag_logit_bias)

@@ -355,6 +355,68 @@ extern "C" int sfm_col_stats(const float* y, const float* aux, const float* mean
   return SFM_OK;
 }
 
+// Gradient fan-in of a tensor whose first Cb columns also fed a second consumer: out[m, c] = a[m, c] + (c < Cb ? b[m, c] : 0)
+// (fp32, row strides lda / ldb / ldo; training: the pooled latents feed the mask-synthesis fusion whole and the BiLSTM by their
+// real half).  One pass instead of a zero-fill, a strided copy and an add.
+__global__ __launch_bounds__(256) void add_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                       long long M, int C, int Cb, long long lda, long long ldb, long long ldo) {
+  const int c4 = C >> 2;
+  const long long total = M * c4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long m = e / c4;
+    const int c = (int)(e - m * c4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a + m * lda + c);
+    if (c < Cb) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(b + m * ldb + c);
+      v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+    }
+    *reinterpret_cast<f32x4*>(out + m * ldo + c) = v;
+  }
+}
+
+extern "C" int sfm_add_cols(const float* a, const float* b, float* out, long long M, int C, int Cb, long long lda, long long ldb,
+                            long long ldo, void* stream) {
+  if (!a || !b || !out) return SFM_ERR_ARG;
+  if (M <= 0 || C <= 0 || Cb < 0 || Cb > C || (C % 4) || (Cb % 4) || (lda % 4) || (ldb % 4) || (ldo % 4) || lda < C || ldb < Cb ||
+      ldo < C || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16) != 0)
+    return SFM_ERR_SHAPE;
+  long long nb = (M * (C >> 2) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  SFM_LAUNCH(add_cols_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, b, out, M, C, Cb, lda, ldb, ldo);
+  return SFM_OK;
+}
+
+// BiLSTM weight gradient operand: the previous output of each chain as 16-bit rows,
+//   out[b, t, 0:H) = h[b, t - 1, 0:H) (forward chain, 0 at t = 0),  out[b, t, H:2H) = h[b, t + 1, H:2H) (reverse chain, 0 at t = T - 1)
+// h fp32 [B, T, 2H] -> out [B*T, 2H] in one pass (was: zero-fill + two strided copies + convert).
+template <class T>
+__global__ __launch_bounds__(256) void lstm_hprev16_kernel(const float* __restrict__ h, u16* __restrict__ out, int Tn, int H,
+                                                           long long total4) {
+  const int W = 2 * H, w4 = W >> 2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+    const long long row = e / w4;
+    const int c = (int)(e - row * w4) * 4;
+    const int t = (int)(row % Tn);
+    const long long src = (c < H) ? row - 1 : row + 1;
+    const bool ok = (c < H) ? (t > 0) : (t < Tn - 1);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4*>(h + src * W + c);
+    u32x2 pk = {T::pack(v[0], v[1]), T::pack(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(out + row * W + c) = pk;
+  }
+}
+
+extern "C" int sfm_lstm_hprev16(const float* h, void* out, int B, int Tn, int H, int dtype, void* stream) {
+  if (!h || !out) return SFM_ERR_ARG;
+  if (B <= 0 || Tn <= 0 || H <= 0 || (H % 4) || (((uintptr_t)h) % 16) != 0 || (((uintptr_t)out) % 8) != 0) return SFM_ERR_SHAPE;
+  const long long total4 = (long long)B * Tn * (2 * H / 4);
+  long long nb = (total4 + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (dtype == SFM_DT_F16) SFM_LAUNCH((lstm_hprev16_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, h, (u16*)out, Tn, H, total4);
+  else SFM_LAUNCH((lstm_hprev16_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, h, (u16*)out, Tn, H, total4);
+  return SFM_OK;
+}
+
 // BatchNorm1d training statistics finalised on the device (models/conformer.py ConvolutionModule's nn.BatchNorm1d, train() mode):
 // S[c] = {sum y, sum y^2} over the M rows ->  mean, rstd = 1/sqrt(biased var + eps), the folded affine
 // sc = gamma rstd, sh = beta - mean sc, and the running statistics (unbiased variance, momentum) updated in place.

@@ -862,7 +862,7 @@ extern "C" int sfm_gemm16_swish(const void* A, const void* W, const float* bias,
   // 128 x 128 tiles with the whole-tile epilogue (variant 2): 0.34 / 0.29 ms per launch at M 205 056, N 1024, K 256 against 0.47 /
   // 0.39 ms on the 256-row tiles with the strip epilogue and 0.46 / 0.49 ms on the persistent kernel (tools/gemm_train_bench.py,
   // round 3).  A/B knob: SFM_SWISH_VARIANT = 0 (256-row tiles when they fill the chip), 6, 9, 10.
-  static const int sv = getenv("SFM_SWISH_VARIANT") ? atoi(getenv("SFM_SWISH_VARIANT")) : 2;
+  const int sv = getenv("SFM_SWISH_VARIANT") ? atoi(getenv("SFM_SWISH_VARIANT")) : 2;   // (read per call: tools/swish_sensitivity.py toggles it)
   return gemm16_impl(A, W, bias, out, nullptr, nullptr, 1, M, M, Cin, lda, 1, 1, 0, 0, Kpad, N, Npad, ldo, 0, 0, 0, 1.0f,
                      backward ? EPI_SWISH_BWD : EPI_SWISH_DUAL, 0, 0, 0, dtype, sv, p_drop, seed, aux, out2, stream);
 }

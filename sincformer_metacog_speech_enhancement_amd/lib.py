@@ -100,6 +100,8 @@ SIGNATURES = {
     "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
     "sfm_ew_train": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_uint, c_i, c_vp],
     "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "sfm_add_cols": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_ll, c_vp],
+    "sfm_lstm_hprev16": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_f, c_f, c_i, c_vp],
     "sfm_bn_swish_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_dwconv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],

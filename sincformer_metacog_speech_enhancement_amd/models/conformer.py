@@ -152,21 +152,24 @@ class ComplexConformer(HipModule):
             [ConformerBlock(self.d_model, num_heads, d_ff, kernel_size, dropout) for _ in range(num_blocks)])
         self.output_proj = nn.Linear(self.d_model, 2 * self.n_freq)
 
-    def _train_forward(self, stft_real, stft_imag):
-        """train() mode (the mode the reference's tests/test_conformer.py runs in): HIP autograd nodes throughout —
-        Linear(2F -> d) -> N x ConformerBlock (dropout, BatchNorm batch statistics) -> + skip -> Linear(d -> 2F)."""
-        from .. import train, ops
-        B, T, F = stft_real.shape
+    def train_core(self, x, B, T):
+        """[M, 2F] (real | imag side by side) -> [M, 2F]: Linear(2F -> d) -> N x ConformerBlock (dropout, BatchNorm batch
+        statistics) -> + skip -> Linear(d -> 2F), HIP autograd nodes throughout"""
+        from .. import train
         M = B * T
-        x = torch.cat([stft_real.float(), stft_imag.float()], dim=-1).reshape(M, 2 * F)
         x = train.LNLinearFunction.apply(x, None, None, self.input_proj.weight, self.input_proj.bias)
         skip = x
         h = x.reshape(B, T, -1)
         for block in self.blocks:
             h = block(h)
         x = h.reshape(M, -1) + skip
-        y = train.LNLinearFunction.apply(x, None, None, self.output_proj.weight, self.output_proj.bias)
-        y = y.reshape(B, T, 2 * F)
+        return train.LNLinearFunction.apply(x, None, None, self.output_proj.weight, self.output_proj.bias)
+
+    def _train_forward(self, stft_real, stft_imag):
+        """train() mode (the mode the reference's tests/test_conformer.py runs in)"""
+        B, T, F = stft_real.shape
+        x = torch.cat([stft_real.float(), stft_imag.float()], dim=-1).reshape(B * T, 2 * F)
+        y = self.train_core(x, B, T).reshape(B, T, 2 * F)
         return y[..., :F], y[..., F:]
 
     def forward(self, stft_real, stft_imag):

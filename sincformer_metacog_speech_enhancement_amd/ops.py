@@ -996,6 +996,21 @@ def col_stats(y32, aux=None, mean=None, rstd=None):
     return S
 
 
+def add_cols(a, b, M, C, Cb):
+    """out [M, C] fp32 = a[:, :C] + pad(b[:, :Cb]); a / b may be row-strided views"""
+    L = _lib.load()
+    out = torch.empty(M, C, device=a.device, dtype=torch.float32)
+    _call("ew_train", L.sfm_add_cols, (_p(a), _p(b), _p(out), M, C, Cb, a.stride(0), b.stride(0), C, _stream()))
+    return out
+
+
+def lstm_hprev16(h32, B, T, H):
+    L = _lib.load()
+    out = torch.empty(B * T, 2 * H, device=h32.device, dtype=_state["dtype"])
+    _call("convert_rows", L.sfm_lstm_hprev16, (_p(h32), _p(out), B, T, H, _dt(), _stream()))
+    return out
+
+
 def bn_finalize(S, gamma, beta, run_mean, run_var, M, eps, momentum, eval_mode=False):
     """-> mean, rstd, sc [1, C], sh [1, C]; the fp32 running statistics are updated in place (training)"""
     L = _lib.load()

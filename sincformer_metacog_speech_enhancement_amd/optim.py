@@ -60,8 +60,9 @@ class FlatAdamW:
     def _bump_versions(self):
         # The parameters were rebound to views of flat_p (`p.data = ...`), which gives each of them its OWN version
         # counter: an in-place op on flat_p does not bump it.  The packed-weight caches therefore also key on a global
-        # weights generation (ops.policy_key), advanced here; the in-place no-op keeps flat_p's own counter honest.
-        self.flat_p.add_(0.0)
+        # weights generation (ops.policy_key), advanced here; the in-place no-op on ONE element keeps flat_p's own counter
+        # honest (views share their base's version counter).
+        self.flat_p[:1].add_(0.0)
         ops.bump_weights_generation()
 
     def stats(self):

@@ -722,28 +722,37 @@ class LayerNormFunction(torch.autograd.Function):
 
 
 class MaskHeadFunction(torch.autograd.Function):
-    """bounded polar mask of agents/msa.py:166-172 from the two heads' logits [M, F] (+ the per-utterance magnitude-logit
-    bias [B, F] of glue G3, or None): (mask_real, mask_imag) [B, T, F] = sigmoid(lm + bias) * (cos, sin)(tanh(lp) * pi/8).
+    """bounded polar mask of agents/msa.py:166-172 from the two heads' logits (lm, lp [M, F] each, or lp = None and lm = the
+    merged [M, 2F] = magnitude | phase) (+ the per-utterance magnitude-logit bias [B, F] of glue G3, or None):
+    (mask_real, mask_imag) [B, T, F] = sigmoid(lm + bias) * (cos, sin)(tanh(lp) * pi/8).
     Backward: sfm_polar_mask_bwd with the bias and no noisy spectrum; d bias = sum over the frames (sfm_sum_time)."""
 
     @staticmethod
     def forward(ctx, lm, lp, mag_bias, B, T, phase_scale):
-        lm32, lp32 = lm.detach().float(), lp.detach().float()
-        if lm32.stride(1) != 1 or lp32.stride(1) != 1 or lm32.stride(0) != lp32.stride(0):
-            lm32, lp32 = lm32.contiguous(), lp32.contiguous()
-        F = lm32.shape[-1]
+        merged = lp is None
+        if merged:
+            lg = lm.detach().float()
+            if lg.stride(1) != 1:
+                lg = lg.contiguous()
+            F = lg.shape[-1] // 2
+            lm32, lp32 = lg[:, :F], lg[:, F:]
+        else:
+            lm32, lp32 = lm.detach().float(), lp.detach().float()
+            if lm32.stride(1) != 1 or lp32.stride(1) != 1 or lm32.stride(0) != lp32.stride(0):
+                lm32, lp32 = lm32.contiguous(), lp32.contiguous()
+            F = lm32.shape[-1]
         bias = mag_bias.detach().float().contiguous() if mag_bias is not None else None
         mr = torch.empty(B, T, F, device=lm.device, dtype=torch.float32)
         mi = torch.empty(B, T, F, device=lm.device, dtype=torch.float32)
         ops.polar_mask(lm32, lp32, B, T, F, phase_scale, lm32.stride(0), mag_bias=bias, mr=mr, mi=mi)
         ctx.saved = (lm32, lp32, bias)
-        ctx.meta = (B, T, F, phase_scale, lm.dtype, lp.dtype, mag_bias.dtype if mag_bias is not None else None)
+        ctx.meta = (B, T, F, phase_scale, lm.dtype, None if merged else lp.dtype, mag_bias.dtype if mag_bias is not None else None, merged)
         return mr, mi
 
     @staticmethod
     def backward(ctx, dmr, dmi):
         lm32, lp32, bias = ctx.saved
-        B, T, F, ps, t0, t1, t2 = ctx.meta
+        B, T, F, ps, t0, t1, t2, merged = ctx.meta
         M = B * T
         ld = ops.round_up(2 * F, 8)
         dl = torch.empty(M, ld, device=lm32.device, dtype=torch.float32)
@@ -753,6 +762,8 @@ class MaskHeadFunction(torch.autograd.Function):
         if bias is not None and ctx.needs_input_grad[2]:
             db = ops.sum_time(dl, B, T, F, ld).to(t2)
         ctx.saved = None
+        if merged:
+            return dl[:, :2 * F].to(t0), None, db, None, None, None
         return dl[:, :F].to(t0), dl[:, F:2 * F].to(t1), db, None, None, None
 
 
@@ -815,26 +826,127 @@ class FusionInputLinearFunction(torch.autograd.Function):
         return (*grads, dW.to(t[8]), db.to(t[9]))
 
 
-def msa_train_forward(msa, z_real, z_imag, cpea_outputs, noisy_real, noisy_imag, mag_logit_bias=None):
+class FusionInputPackedFunction(torch.autograd.Function):
+    """FusionInputLinearFunction for callers that hold the inputs in the path's own layouts: the pooled latents channels-last
+    and whole (zcat [B, T, 2D] = z_real | z_imag) and the four CPEA outputs as the one [B, T, 4 oc] tensor the fused heads
+    write.  Two converting copies and the log1p pack build the operand; the backward hands the two column blocks of the input
+    gradient back as views (no transposes, no per-output slices for autograd to re-assemble)."""
+
+    @staticmethod
+    def forward(ctx, zcat, cp_all, noisy_real, noisy_imag, W, b):
+        from . import functional as Fn
+        B, T, D2 = zcat.shape
+        M = B * T
+        C4 = cp_all.shape[-1]
+        dt = ops.compute_dtype()
+        fused16 = torch.empty(M, Fn.FUSE_LD, device=zcat.device, dtype=dt)
+        z32, c32 = zcat.detach().float().reshape(M, D2), cp_all.detach().float().reshape(M, C4)
+        if z32.stride(1) != 1:
+            z32 = z32.contiguous()
+        if c32.stride(1) != 1:
+            c32 = c32.contiguous()
+        ops.convert_rows(z32, fused16, M, D2, D2, z32.stride(0), Fn.FUSE_LD)
+        ops.convert_rows(c32, fused16[:, D2:], M, C4, C4, c32.stride(0), Fn.FUSE_LD)
+        nr, ni = noisy_real.detach().float().contiguous(), noisy_imag.detach().float().contiguous()
+        F = nr.shape[-1]
+        col = D2 + C4
+        ops.stft_lognorm_pack(nr, ni, fused16[:, col:], M, F, Fn.FUSE_LD - col - 2 * F, Fn.FUSE_LD)
+        N, K = W.shape
+        w32 = _f32(W)
+        y = ops.linear16(fused16, ops.pack_linear(w32, _f32(b), k_pad_to=Fn.FUSE_LD), out_dtype=torch.float32)
+        ctx.saved = (fused16, w32, nr, ni)
+        ctx.dims = (B, T, D2, C4, N, K, F)
+        ctx.dtypes = [t.dtype for t in (zcat, cp_all, noisy_real, noisy_imag, W, b)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        fused16, w32, nr, ni = ctx.saved
+        B, T, D2, C4, N, K, F = ctx.dims
+        M = B * T
+        dev = dy.device
+        dy = dy.float()
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        Np = ops.round_up(N, 64)
+        dy16 = torch.empty(M, Np, device=dev, dtype=ops.compute_dtype())
+        ops.convert_rows(dy, dy16, M, N, Np, dy.stride(0), Np)
+        dW = torch.zeros(N, K, device=dev, dtype=torch.float32)
+        db = torch.zeros(N, device=dev, dtype=torch.float32)
+        ops.gemm16_tn(dy16[:, :N], fused16[:, :K], dW, db)
+        need = ctx.needs_input_grad
+        t = ctx.dtypes
+        g = [None] * 4
+        if any(need[:4]):
+            df = torch.empty(M, ops.round_up(K, 8), device=dev, dtype=torch.float32)[:, :K]      # 16-byte aligned rows
+            ops.linear16(dy16, ops.pack_linear(w32.t().contiguous(), k_pad_to=Np), out=df)          # [M, K]
+            if need[0]:
+                g[0] = df[:, :D2].reshape(B, T, D2).to(t[0])                 # row-strided views of df
+            if need[1]:
+                g[1] = df[:, D2:D2 + C4].reshape(B, T, C4).to(t[1])
+            if need[2] or need[3]:
+                dre, dim_ = ops.stft_lognorm_bwd(nr.reshape(M, F), ni.reshape(M, F), df[:, D2 + C4:], M, F)
+                g[2] = dre.reshape(B, T, F).to(t[2]) if need[2] else None
+                g[3] = dim_.reshape(B, T, F).to(t[3]) if need[3] else None
+        ctx.saved = None
+        return (*g, dW.to(t[4]), db.to(t[5]))
+
+
+class LatentFanoutFunction(torch.autograd.Function):
+    """the pooled latents zp [B, T, 2D] feed the mask-synthesis fusion whole and the CPEA by their real half (glue G1 of
+    DESIGN.md): returns (zp, zp[..., :D]) and folds the two gradients in ONE pass (sfm_add_cols) - left to autograd the fan-in is
+    a zero-fill and a strided copy per slice plus an add per consumer, each over the [B, T, 2D] tensor."""
+
+    @staticmethod
+    def forward(ctx, zp, D):
+        ctx.D = D
+        return zp.view_as(zp), zp[..., :D]
+
+    @staticmethod
+    def backward(ctx, g_all, g_half):
+        D = ctx.D
+        if g_half is None:
+            return g_all, None
+        B, T = g_half.shape[0], g_half.shape[1]
+        M = B * T
+        gh = g_half.float().reshape(M, D)
+        if gh.stride(1) != 1:
+            gh = gh.contiguous()
+        if g_all is None:
+            out = torch.zeros(B, T, 2 * D, device=g_half.device, dtype=torch.float32)
+            out[..., :D].copy_(gh.reshape(B, T, D))
+            return out, None
+        ga = g_all.float().reshape(M, 2 * D)                                   # a row-strided view stays a view
+        if ga.stride(1) != 1 or ga.stride(0) % 4 or ga.data_ptr() % 16:
+            ga = ga.contiguous()
+        return ops.add_cols(ga, gh, M, 2 * D, D).reshape(B, T, 2 * D).to(g_all.dtype), None
+
+
+def msa_train_forward(msa, z_real, z_imag, cpea_outputs, noisy_real, noisy_imag, mag_logit_bias=None, latents_cl=None):
     """MaskSynthesisAgent.forward (agents/msa.py:106-174) built from HIP autograd nodes: fusion MLP (its first Linear reads
-    the eight inputs directly, FusionInputLinearFunction) -> ComplexConformer (its own training / eval-autograd path) -> two
-    GELU heads -> bounded polar mask."""
+    the eight inputs directly) -> ComplexConformer (its own training / eval-autograd path, real | imag kept side by side in one
+    [M, d_model] tensor) -> the two GELU heads as block-diagonal GEMMs on that tensor -> bounded polar mask.
+    latents_cl (optional, [B, T, 2D] = z_real | z_imag channels-last) and cpea_outputs.packed ([B, T, 4 oc], set by
+    cpea_train_forward) are the path's own layouts of the same inputs: with them no transposed / sliced copies are made."""
     B, D, T = z_real.shape
     M = B * T
     f = msa.fusion
-    x = FusionInputLinearFunction.apply(z_real, z_imag, cpea_outputs["rho_s"], cpea_outputs["rho_n"], cpea_outputs["phi1"],
-                                        cpea_outputs["phi2"], noisy_real, noisy_imag, f[0].weight, f[0].bias)
+    packed = getattr(cpea_outputs, "packed", None)
+    if latents_cl is not None and packed is not None and latents_cl.shape == (B, T, 2 * D):
+        x = FusionInputPackedFunction.apply(latents_cl, packed, noisy_real, noisy_imag, f[0].weight, f[0].bias)
+    else:
+        x = FusionInputLinearFunction.apply(z_real, z_imag, cpea_outputs["rho_s"], cpea_outputs["rho_n"], cpea_outputs["phi1"],
+                                            cpea_outputs["phi2"], noisy_real, noisy_imag, f[0].weight, f[0].bias)
     x = GeluFunction.apply(LayerNormFunction.apply(x, f[1].weight, f[1].bias))
     x = LNLinearFunction.apply(x, None, None, f[3].weight, f[3].bias)
     x = LayerNormFunction.apply(x, f[4].weight, f[4].bias)
-    half = x.shape[-1] // 2
-    mask_r, mask_i = msa.conformer(x[:, :half].reshape(B, T, half), x[:, half:].reshape(B, T, half))
-    heads = []
-    for seq, src in ((msa.mask_proj_real, mask_r), (msa.mask_proj_imag, mask_i)):
-        h = LNLinearFunction.apply(src.reshape(M, -1), None, None, seq[0].weight, seq[0].bias)
-        heads.append(LNLinearFunction.apply(GeluFunction.apply(h), None, None, seq[2].weight, seq[2].bias))
-    lm, lp = heads
-    return MaskHeadFunction.apply(lm, lp, mag_logit_bias, B, T, 3.14159 / 8.0)
+    y = msa.conformer.train_core(x, B, T)                                       # [M, d_model] = mask_r | mask_i
+    pr, pi = msa.mask_proj_real, msa.mask_proj_imag
+    # the two heads side by side: block-diagonal weights (the off-diagonal zeros contribute exact zeros), one GEMM per layer
+    h = LNLinearFunction.apply(y, None, None, torch.block_diag(pr[0].weight, pi[0].weight), torch.cat([pr[0].bias, pi[0].bias]))
+    logits = LNLinearFunction.apply(GeluFunction.apply(h), None, None, torch.block_diag(pr[2].weight, pi[2].weight),
+                                    torch.cat([pr[2].bias, pi[2].bias]))         # [M, 2F] = magnitude | phase logits
+    return MaskHeadFunction.apply(logits, None, mag_logit_bias, B, T, 3.14159 / 8.0)
 
 
 # ---------------------------------------------------------------------------
@@ -850,12 +962,14 @@ class BiLSTMLayerFunction(torch.autograd.Function):
         H = whf.shape[1]
         M = B * T
         dt = ops.compute_dtype()
-        x32 = x.detach().float().reshape(M, Din).contiguous()
+        x32 = x.detach().float()
+        if x32.stride(2) != 1 or x32.stride(0) != T * x32.stride(1):              # (a column slice of a wider row is fine as it is)
+            x32 = x32.contiguous()
         wih = torch.cat([_f32(wif), _f32(wir)], dim=0)                               # [8H, Din]
         bias = torch.cat([_f32(bif) + _f32(bhf), _f32(bir) + _f32(bhr)], dim=0)
         whh = torch.stack([_f32(whf), _f32(whr)], dim=0).contiguous()                # [2, 4H, H]
         x16 = torch.empty(M, Din, device=x.device, dtype=dt)
-        ops.convert_rows(x32, x16, M, Din, Din, Din, Din)
+        ops.convert_rows(x32, x16, M, Din, Din, x32.stride(1), Din)
         xg = ops.linear16(x16, ops.pack_linear(wih, bias), out_dtype=torch.float32)   # [M, 8H] = [B, T, 2, 4H]
         h, save = ops.bilstm_layer_train(xg, whh, B, T, H)
         ctx.saved = (x16, wih, whh, save, h)
@@ -877,11 +991,7 @@ class BiLSTMLayerFunction(torch.autograd.Function):
         ops.gemm16_tn(dxg16, x16, dwih, db)
         dx = ops.linear16(dxg16, ops.pack_linear(wih.t().contiguous()), out_dtype=torch.float32).reshape(B, T, Din)
         # dW_hh[dir] = sum_t da[t] (x) h_prev[t]: the chain's previous output (zero at its first step)
-        hprev = torch.zeros_like(h)
-        hprev[:, 1:, :H] = h[:, :-1, :H]
-        hprev[:, :-1, H:] = h[:, 1:, H:]
-        hp16 = torch.empty(M, 2 * H, device=dev, dtype=dt)
-        ops.convert_rows(hprev.reshape(M, 2 * H), hp16, M, 2 * H, 2 * H, 2 * H, 2 * H)
+        hp16 = ops.lstm_hprev16(h, B, T, H)
         dwhh = torch.zeros(2, 4 * H, H, device=dev, dtype=torch.float32)
         for d in range(2):
             ops.gemm16_tn(dxg16[:, d * 4 * H:(d + 1) * 4 * H], hp16[:, d * H:(d + 1) * H], dwhh[d])
@@ -957,6 +1067,11 @@ class CpeaHeadsFunction(torch.autograd.Function):
         return dx.to(t[0]), dW.to(t[1]), db.to(t[2])
 
 
+class CpeaOutputs(dict):
+    """the reference's output dict (agents/cpea.py:107-112) plus `.packed`: the same four tensors as one [B, T, 4 oc] tensor"""
+    packed = None
+
+
 def cpea_train_forward(cpea, z_t):
     """CorrelationPhaseEstimationAgent.forward (agents/cpea.py:79-112) from HIP autograd nodes."""
     if z_t.dim() == 3 and z_t.shape[-1] != cpea.input_dim:
@@ -977,7 +1092,9 @@ def cpea_train_forward(cpea, z_t):
     b = torch.cat([h.bias for h in heads], dim=0)
     y = CpeaHeadsFunction.apply(x.reshape(M, -1), W, b).reshape(B, T, -1)
     oc = heads[0].weight.shape[0]
-    return {"rho_s": y[..., :oc], "rho_n": y[..., oc:2 * oc], "phi1": y[..., 2 * oc:3 * oc], "phi2": y[..., 3 * oc:]}
+    out = CpeaOutputs({"rho_s": y[..., :oc], "rho_n": y[..., oc:2 * oc], "phi1": y[..., 2 * oc:3 * oc], "phi2": y[..., 3 * oc:]})
+    out.packed = y                     # the four outputs side by side, as the fused heads wrote them (msa_train_forward)
+    return out
 
 
 MEMORY_PARAM_ORDER = ("key_proj.0.weight", "key_proj.0.bias", "key_proj.1.weight", "key_proj.1.bias", "key_proj.3.weight",
@@ -1224,6 +1341,25 @@ class PoolTimeFunction(torch.autograd.Function):
     def backward(ctx, dout):
         B, Tin, Tout, C = ctx.dims
         return ops.pool_time_bwd(dout.detach().float(), B, Tin, Tout, C), None
+
+
+class MeanTimeFunction(torch.autograd.Function):
+    """glue G2 under autograd: mean over the frames of channels-last rows, x [B, T, C] fp32 (a column slice of wider rows is
+    read in place) -> [B, C]; backward = the adjoint of pooling to one frame (sfm_pool_time_bwd)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x32 = x.detach().float()
+        B, T, C = x32.shape
+        if x32.stride(2) != 1 or x32.stride(0) != T * x32.stride(1):
+            x32 = x32.contiguous()
+        ctx.dims = (B, T, C, x.dtype)
+        return ops.mean_time(x32, B, T, C, x32.stride(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, C, dtp = ctx.dims
+        return ops.pool_time_bwd(g.detach().float().reshape(B, 1, C), B, T, 1, C).to(dtp)
 
 
 def perception_latents_train(pa, waveform):

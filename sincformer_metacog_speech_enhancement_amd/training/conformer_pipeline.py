@@ -236,15 +236,19 @@ class EnhancementPath(HipModule):
                 ops.pool_time(rz, None, zp, B, rz.shape[1], T, 2 * D, 2 * D, 2 * D, scale=sz, shift=hz)      # glue G1
         else:
             zp = train.PoolTimeFunction.apply(train.perception_latents_train(self.perception, wave), T)     # glue G1
-        z_real, z_imag = zp[..., :D].transpose(1, 2), zp[..., D:].transpose(1, 2)
-        cpea = self.cpea(zp[..., :D])
+        if zp.requires_grad:
+            zp_all, z_half = train.LatentFanoutFunction.apply(zp, D)             # one fused gradient fan-in for the two consumers
+        else:
+            zp_all, z_half = zp, zp[..., :D]
+        z_real, z_imag = zp_all[..., :D].transpose(1, 2), zp_all[..., D:].transpose(1, 2)
+        cpea = self.cpea(z_half)
         bias = None
         out = {}
         if self.memory is not None:
-            mem = self.memory(zp[..., :self.memory.key_dim].mean(dim=1))                                 # glue G2
+            mem = self.memory(train.MeanTimeFunction.apply(zp[..., :self.memory.key_dim]))                # glue G2
             bias = mem["bias"]                                                                            # glue G3
             out.update(mem_bias=mem["bias"], mem_gate=mem["gate"], mem_top=mem["top_indices"], mem_sim=mem["similarity"])
-        mr, mi = self.msa(z_real, z_imag, cpea, nr, ni, mag_logit_bias=bias)
+        mr, mi = self.msa(z_real, z_imag, cpea, nr, ni, mag_logit_bias=bias, latents_cl=zp_all)
         er, ei = train.ComplexMulFunction.apply(nr, ni, mr, mi)
         out.update(mask_real=mr, mask_imag=mi, noisy_real=nr, noisy_imag=ni, enh_real=er, enh_imag=ei)
         if "wave" in want:

@@ -2,6 +2,7 @@
 modules (tests/golden/state_shapes.json, captured from the reference) and
 golden loaders.  Test-side only."""
 import json
+import math
 import os
 import numpy as np
 import torch
@@ -62,3 +63,23 @@ def metric_cases():
     cases.append(("identical", 8000, clean[0], clean[0].copy()))
     cases.append(("short", 8000, clean[0][:100], noisy[0][:100]))
     return cases
+
+
+def central_difference_along_gradient(params, objective, eps):
+    """objective() -> scalar tensor with grad; returns (|g|, central-difference slope of the objective along g / |g|)"""
+    total = objective()
+    total.backward()
+    params = [p_ for p_ in params if p_.grad is not None]
+    gnorm = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in params)))
+    assert math.isfinite(gnorm) and gnorm > 0
+    base = [p_.detach().clone() for p_ in params]
+    vals = []
+    for sign in (1.0, -1.0):
+        with torch.no_grad():
+            for p_, b0 in zip(params, base):
+                p_.copy_(b0 + sign * eps * p_.grad / gnorm)
+        vals.append(float(objective().detach()))
+    with torch.no_grad():
+        for p_, b0 in zip(params, base):
+            p_.copy_(b0)
+    return float(total.detach()), gnorm, (vals[0] - vals[1]) / (2 * eps)

@@ -101,24 +101,7 @@ def test_stft_istft_identity_at_full_size(path_and_out):
     assert float(((full / 256.0) - (fr ** 2).sum(-1)).abs().max()) < 1e-3
 
 
-def _central_difference_along_gradient(params, objective, eps):
-    """objective() -> scalar tensor with grad; returns (|g|, central-difference slope of the objective along g / |g|)"""
-    total = objective()
-    total.backward()
-    params = [p_ for p_ in params if p_.grad is not None]
-    gnorm = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in params)))
-    assert math.isfinite(gnorm) and gnorm > 0
-    base = [p_.detach().clone() for p_ in params]
-    vals = []
-    for sign in (1.0, -1.0):
-        with torch.no_grad():
-            for p_, b0 in zip(params, base):
-                p_.copy_(b0 + sign * eps * p_.grad / gnorm)
-        vals.append(float(objective().detach()))
-    with torch.no_grad():
-        for p_, b0 in zip(params, base):
-            p_.copy_(b0)
-    return float(total.detach()), gnorm, (vals[0] - vals[1]) / (2 * eps)
+from helpers import central_difference_along_gradient as _central_difference_along_gradient  # noqa: E402
 
 
 def test_training_backward_directional_derivative_at_full_size():
