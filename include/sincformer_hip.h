@@ -334,6 +334,10 @@ int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* db, int B, 
 int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream);
 int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                       float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream);
+/* the same with dy in the 16-bit format `dtype` (dy_16 != 0) and its own row stride ldy; ld = row stride of dres and dx */
+int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
+                         float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
+                         void* stream);
 /* mode 0 swish fwd, 1 swish bwd, 2 GLU fwd, 3 GLU bwd, 4 alpha*g*dropout; counter-based dropout (p, seed) */
 int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                  float alpha, float p, unsigned int seed, int dtype, void* stream);

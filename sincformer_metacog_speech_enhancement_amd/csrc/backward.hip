@@ -7,11 +7,13 @@
 // LayerNorm backward: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //                     dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy          (D <= 512)
 // ---------------------------------------------------------------------------
-template <bool VEC>
+// DYF: format of dy - 0 fp32, 1 bf16, 2 fp16 (the 16-bit result of the GEMM that produced it: half the bytes of that stream,
+// written and read)
+template <bool VEC, int DYF>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ dy, const float* __restrict__ dres,
+                                                            const void* __restrict__ dyv, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int M, int D, int ldx, int ld,
+                                                            float* __restrict__ dbeta, int M, int D, int ldx, int ldy, int ld,
                                                             float eps) {
   __shared__ float red[4][2][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -22,7 +24,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float* xr = x + (long long)row * ldx;
-    const float* gr = dy + (long long)row * ld;
+    const float* gr = reinterpret_cast<const float*>(dyv) + (long long)row * ldy;          // DYF == 0
+    const u16* gh = reinterpret_cast<const u16*>(dyv) + (long long)row * ldy;               // DYF != 0
     float v[8], g[8];
     float s = 0.f;
     if (VEC) {
@@ -32,7 +35,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
         if (d < D) {
           a = *reinterpret_cast<const f32x4*>(xr + d);
-          c = *reinterpret_cast<const f32x4*>(gr + d);
+          if (DYF == 0) c = *reinterpret_cast<const f32x4*>(gr + d);
+          else {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(gh + d);
+            if (DYF == 1) c = f32x4{BF16::to_f32((u16)(w[0] & 0xffffu)), BF16::to_f32((u16)(w[0] >> 16)), BF16::to_f32((u16)(w[1] & 0xffffu)), BF16::to_f32((u16)(w[1] >> 16))};
+            else c = f32x4{F16::to_f32((u16)(w[0] & 0xffffu)), F16::to_f32((u16)(w[0] >> 16)), F16::to_f32((u16)(w[1] & 0xffffu)), F16::to_f32((u16)(w[1] >> 16))};
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[4 * h + j] = a[j]; g[4 * h + j] = c[j]; s += a[j]; }
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       for (int i = 0; i < 8; ++i) {
         const int d = LN_COL(i);
         v[i] = (d < D) ? xr[d] : 0.f;
-        g[i] = (d < D) ? gr[d] : 0.f;
+        g[i] = (d < D) ? (DYF == 0 ? gr[d] : DYF == 1 ? BF16::to_f32(gh[d]) : F16::to_f32(gh[d])) : 0.f;
         s += v[i];
       }
     }
@@ -112,21 +120,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 #undef LN_COL
 
-extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
-                                 float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream) {
+// dy_16: 0 = dy fp32, 1 = dy in the 16-bit format `dtype`; ldy = row stride of dy (elements), ld = row stride of dres and dx
+extern "C" int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
+                                    float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
+                                    void* stream) {
   if (!x || !gamma || !dy || !dx || !dgamma || !dbeta) return SFM_ERR_ARG;
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
   int nb = (M + 3) / 4;
   if (nb > 1024) nb = 1024;                                  // 1024 x 512 contended atomics at the end: measured best of 512..4096
-  const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ld % 4 == 0) &&
-                   ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0);
-  if (vec)
-    SFM_LAUNCH(layernorm_bwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dres, dx, dgamma, dbeta,
-               M, D, ldx, ld, eps);
-  else
-    SFM_LAUNCH(layernorm_bwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dres, dx, dgamma, dbeta,
-               M, D, ldx, ld, eps);
+  const int dyb = dy_16 ? 2 : 4;
+  const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ld % 4 == 0) && (ldy % 4 == 0) &&
+                   ((((uintptr_t)x | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0) && (((uintptr_t)dy) % (4 * dyb)) == 0;
+  const int f = dy_16 ? (dtype == SFM_DT_F16 ? 2 : 1) : 0;
+  hipStream_t st = (hipStream_t)stream;
+#define LNB_GO(V, F) SFM_LAUNCH((layernorm_bwd_kernel<V, F>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps)
+  if (vec) { if (f == 0) LNB_GO(true, 0); else if (f == 1) LNB_GO(true, 1); else LNB_GO(true, 2); }
+  else { if (f == 0) LNB_GO(false, 0); else if (f == 1) LNB_GO(false, 1); else LNB_GO(false, 2); }
+#undef LNB_GO
   return SFM_OK;
+}
+
+extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
+                                 float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream) {
+  return sfm_layernorm_bwd_ex(x, gamma, dy, 0, dres, dx, dgamma, dbeta, M, D, ldx, ld, ld, eps, SFM_DT_BF16, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -187,18 +187,24 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
   // Linear of the unfused / training path): all of the tile's residual rows are requested BEFORE the first one is used.  In the
   // general loop below each pass loads its 32 bytes and waits for them (a global round trip per 8 rows: the epilogue of these
   // GEMMs took 23 us of their 37 at M 51 264).
-  if (p.epi == EPI_RESID && !glu && p.vec_ok && !p.gn_partial && ncol0 + 8 <= p.N) {
+  // The same lean loop serves the plain epilogue (EPI_NONE: bias, one rounding, 16-byte stores - the input-gradient GEMMs of the
+  // training step, Q | K | V): the general loop below spends ~560 VALU instructions per wave tile on its per-element predicates
+  // and mode switches (profiles/r03/pmc_gemm16v2.json: 10.9 VALU per MFMA at K = 256), this one about a third of that.
+  if ((p.epi == EPI_RESID || p.epi == EPI_NONE) && !glu && p.vec_ok && !p.gn_partial && ncol0 + 8 <= p.N) {
     constexpr int CPR = WN >> 3, RPP = 64 / CPR;
+    const bool has_res = (p.epi == EPI_RESID);
     const int c8s = (lane % CPR) * 8, rs = lane / CPR;
     const int nc = colb + c8s;
     f32x4 rr[CPR][2];
+    if (has_res) {
 #pragma unroll
-    for (int it = 0; it < CPR; ++it) {
-      int m = row_base + it * RPP + rs;
-      m = m < p.Lout ? m : p.Lout - 1;                 // clamped: loaded, not used
-      const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + nc;
-      rr[it][0] = *reinterpret_cast<const f32x4*>(rp);
-      rr[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+      for (int it = 0; it < CPR; ++it) {
+        int m = row_base + it * RPP + rs;
+        m = m < p.Lout ? m : p.Lout - 1;               // clamped: loaded, not used
+        const float* rp = p.resid + (long long)b * p.r_batch_stride + (long long)m * p.ldr + nc;
+        rr[it][0] = *reinterpret_cast<const f32x4*>(rp);
+        rr[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+      }
     }
     f32x4 bb0 = {0.f, 0.f, 0.f, 0.f}, bb1 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -217,16 +223,18 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
         y[e] = x0[e] + bb0[e];
         y[4 + e] = x1[e] + bb1[e];
       }
-      if (p.p_drop > 0.f) {                              // residual-branch dropout, same counters as sfm_ew_train mode 4
-        float kp[8];
-        sfm_keep_scale8(p.seed, ((unsigned long long)b * p.Lout + (m < p.Lout ? m : 0)) * p.N + nc, p.p_drop, 1.0f / (1.0f - p.p_drop), kp);
+      if (has_res) {
+        if (p.p_drop > 0.f) {                            // residual-branch dropout, same counters as sfm_ew_train mode 4
+          float kp[8];
+          sfm_keep_scale8(p.seed, ((unsigned long long)b * p.Lout + (m < p.Lout ? m : 0)) * p.N + nc, p.p_drop, 1.0f / (1.0f - p.p_drop), kp);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] *= kp[e];
-      }
+          for (int e = 0; e < 8; ++e) y[e] *= kp[e];
+        }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        y[e] = rr[it][0][e] + p.alpha * y[e];
-        y[4 + e] = rr[it][1][e] + p.alpha * y[4 + e];
+        for (int e = 0; e < 4; ++e) {
+          y[e] = rr[it][0][e] + p.alpha * y[e];
+          y[4 + e] = rr[it][1][e] + p.alpha * y[4 + e];
+        }
       }
       if (m >= p.Lout) continue;
       const long long orow = obase + (long long)m * p.ldo + nc;

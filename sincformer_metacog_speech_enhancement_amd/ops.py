@@ -966,12 +966,16 @@ def colsum(G, out):
     _call("colsum", L.sfm_colsum, (_p(G), _p(out), M, N, G.stride(0), 1 if G.dtype == torch.float32 else 0, _dt(), _stream()))
 
 
-def layernorm_bwd(x32, gamma, dy32, dres32, dgamma, dbeta, eps=1e-5):
+def layernorm_bwd(x32, gamma, dy, dres32, dgamma, dbeta, eps=1e-5):
+    """dy: fp32, or the 16-bit result of the GEMM that produced it (its own row stride); dres / dx fp32 [M, D]"""
     L = _lib.load()
-    M, D = dy32.shape
-    dx = torch.empty_like(dy32)
-    _call("layernorm_bwd", L.sfm_layernorm_bwd, (_p(x32), _p(gamma), _p(dy32), _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
-                                                 x32.stride(0), dy32.stride(0), eps, _stream()))
+    M, D = dy.shape
+    dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+    dy16 = 0 if dy.dtype == torch.float32 else 1
+    if dy16 and dy.dtype != _state["dtype"]:
+        raise RuntimeError("layernorm_bwd: a 16-bit dy must be in the compute format")
+    _call("layernorm_bwd", L.sfm_layernorm_bwd_ex, (_p(x32), _p(gamma), _p(dy), dy16, _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
+                                                    x32.stride(0), dy.stride(0), D, eps, _dt(), _stream()))
     return dx
 
 

@@ -99,7 +99,7 @@ def _ffn_bwd(dy, c, G, pre):
         dz = torch.empty(M, FF, device=dy.device, dtype=dt)
         ops.ew_train(ops.EW_SWISH_BWD, dz, z=c["z1"], g=du, p=c["p"], seed=c["s1"])
     ops.gemm16_tn(dz, c["h16"], G[pre + "linear1.weight"], G[pre + "linear1.bias"])
-    dh = ops.linear16(dz, c["b1"], out_dtype=torch.float32)                 # [M, D]
+    dh = ops.linear16(dz, c["b1"])                                          # [M, D] 16-bit: read once, by the LayerNorm backward
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G[pre + "layer_norm.weight"], G[pre + "layer_norm.bias"])
 
 
@@ -142,7 +142,7 @@ def _mhsa_bwd(dy, c, G):
         tb[:D] *= c["qs"]
         gw += tw
         gb += tb
-    dh = ops.linear16(dqkv, c["bin"], out_dtype=torch.float32)
+    dh = ops.linear16(dqkv, c["bin"])
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G["mhsa.layer_norm.weight"], G["mhsa.layer_norm.bias"])
 
 
@@ -209,7 +209,7 @@ def _conv_bwd(dy, c, G):
     dpre = torch.empty(M, 2 * D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_GLU_BWD, dpre, z=c["pre"], g=dg, N=D)
     ops.gemm16_tn(dpre, c["h16"], G["conv.pointwise1.weight"].view(2 * D, D), G["conv.pointwise1.bias"])
-    dh = ops.linear16(dpre, c["b1"], out_dtype=torch.float32)
+    dh = ops.linear16(dpre, c["b1"])
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G["conv.layer_norm.weight"], G["conv.layer_norm.bias"])
 
 
@@ -324,7 +324,7 @@ class LNLinearFunction(torch.autograd.Function):
         db = torch.zeros(N, device=dev, dtype=torch.float32)
         ops.gemm16_tn(dy16[:, :N], h16[:, :K], dW, db)
         bwd = ops.pack_linear(w32.t().contiguous(), k_pad_to=Np)
-        dh = ops.linear16(dy16, bwd, out_dtype=torch.float32)                  # [M, K]
+        dh = ops.linear16(dy16, bwd, out_dtype=torch.float32 if lw is None else None)   # [M, K]; 16-bit into the LayerNorm backward
         t = ctx.dtypes
         ctx.saved = None
         if lw is None:
