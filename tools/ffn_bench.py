@@ -9,7 +9,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=51264)
 ap.add_argument("--ff", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dtype", default="f16")
 a = ap.parse_args()
+ops.set_compute_dtype(a.dtype)
 M, D, FF = a.rows, 256, a.ff
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn(M, D, device="cuda", generator=g)
