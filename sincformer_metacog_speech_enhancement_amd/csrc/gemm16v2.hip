@@ -190,9 +190,13 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
   // The same lean loop serves the plain epilogue (EPI_NONE: bias, one rounding, 16-byte stores - the input-gradient GEMMs of the
   // training step, Q | K | V): the general loop below spends ~560 VALU instructions per wave tile on its per-element predicates
   // and mode switches (profiles/r03/pmc_gemm16v2.json: 10.9 VALU per MFMA at K = 256), this one about a third of that.
-  if ((p.epi == EPI_RESID || p.epi == EPI_NONE) && !glu && p.vec_ok && !p.gn_partial && ncol0 + 8 <= p.N) {
+  // With GroupNorm partials (the conv forward of the training step) the whole wave tile has to be inside N: the sums are folded
+  // across the wave's lanes below, every lane takes part.
+  if ((p.epi == EPI_RESID || p.epi == EPI_NONE) && !glu && p.vec_ok &&
+      (p.gn_partial ? (colb + WN <= p.N) : (ncol0 + 8 <= p.N))) {
     constexpr int CPR = WN >> 3, RPP = 64 / CPR;
     const bool has_res = (p.epi == EPI_RESID);
+    float gs = 0.f, gq = 0.f;                          // GroupNorm partials of this lane's 8 columns over its rows
     const int c8s = (lane % CPR) * 8, rs = lane / CPR;
     const int nc = colb + c8s;
     f32x4 rr[CPR][2];
@@ -223,6 +227,10 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
         y[e] = x0[e] + bb0[e];
         y[4 + e] = x1[e] + bb1[e];
       }
+      if (p.gn_partial && m < p.Lout) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs += y[e]; gq = __builtin_fmaf(y[e], y[e], gq); }   // (fmaf: profiles/README.md, "the lost sums of squares")
+      }
       if (has_res) {
         if (p.p_drop > 0.f) {                            // residual-branch dropout, same counters as sfm_ew_train mode 4
           float kp[8];
@@ -247,6 +255,24 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) pk[e] = pack2_out<T>(y[2 * e], y[2 * e + 1], p.out_f32 == 2);
         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.out) + orow) = pk;
+      }
+    }
+    if (p.gn_partial) {
+      // lanes with the same column chunk hold different rows: fold them, then fold the chunks of a group
+      for (int o = CPR; o < 64; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+      }
+      const int cpg = p.gn_group >> 3;                 // 8-column chunks per group (1, 2 or 4)
+      for (int o = 1; o < cpg; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gq += __shfl_xor(gq, o, 64);
+      }
+      if (lane < CPR && (lane % cpg) == 0 && (row_base >> 6) < p.gn_slots) {
+        const int ngroups = p.N / p.gn_group;           // one partial per 64-row block of the output, whatever BM is
+        const long long slot = ((long long)b * p.gn_slots + (row_base >> 6)) * ngroups + nc / p.gn_group;
+        p.gn_partial[slot * 2 + 0] = gs;
+        p.gn_partial[slot * 2 + 1] = gq;
       }
     }
     continue;                                          // next 64-row pass of the wave tile
