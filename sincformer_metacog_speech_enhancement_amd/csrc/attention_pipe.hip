@@ -243,12 +243,22 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
 #define ATTNP_SCHED_AUG
 #else
 #define ATTNP_SET_NEGM(X, HI, LO, MNEW) qa[X][0] = (hl == 0) ? pack2<T>(-(HI), -(LO)) : 0u;
+#if SFM_ATTNP_ABL == 8
+  // timing experiment only (results wrong): no augmented k-step, no overflow-triggered rescale - what would a kernel gain that
+  // needs no running maximum (bf16 has fp32's exponent range: P = 2^s directly)?
+#define ATTNP_S_FIRST(U, AFIRST)                                                                                       \
+    if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
+    f32x16 sn = T::mfma(kf[0], qf[U][0], zero);
+#define ATTNP_PAD_FIX(STEP)
+#define ATTNP_SCHED_AUG
+#else
 #define ATTNP_S_FIRST(U, AFIRST)                                                                                       \
     f32x16 sn = T::mfma(ka, qa[U], zero);                                                                              \
     if (AFIRST) ATTNP_KF_WAIT(8);                                                                                      \
     sn = T::mfma(kf[0], qf[U][0], sn);
 #define ATTNP_PAD_FIX(STEP)
 #define ATTNP_SCHED_AUG ATTNP_SG(0x008, 1) ATTNP_SG(0x400, 3)
+#endif
 #endif
   // rare path: raise the running maximum of sub-block X from the block whose scores are in s[X], rescale O and l, redo P
 #define ATTNP_RESCALE(X, FORCE)                                                                                        \
@@ -319,7 +329,8 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
     s[U] = sn;                                                                                                         \
     /* the forced case enters through the same data-dependent test (a short-circuit on FORCE lets the compiler sink the   \
        exponentials out of this block, behind the branch) */                                                           \
-    if (__any(((flag_ | ((FORCE) ? 0x4000u : 0u)) & 0x40004000u) != 0u)) ATTNP_RESCALE(V_, FORCE)                      \
+    if (__any((((SFM_ATTNP_ABL == 8) ? (flag_ & 0u) : flag_) | ((FORCE) ? 0x4000u : 0u)) & 0x40004000u) != 0u)          \
+      ATTNP_RESCALE(V_, FORCE)                                                                                         \
   }
 
 #if SFM_ATTNP_ABL == 2
