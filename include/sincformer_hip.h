@@ -215,6 +215,10 @@ int sfm_ffn_fused_ln(const float* x, const float* lnw, const float* lnb, const v
 int sfm_sinc_fir16_tiles(int L);
 int sfm_sinc_fir16(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B,
                    int L, int C, int K, int out_f32, int dtype, void* stream);
+/* passes: 3 = split operands (hi x hi + hi x lo + lo x hi: 1e-7 / 1e-6 max error), 1 = one rounding of waveform and taps to the
+ * operand format, 0 = auto (1 for fp16 operands with a 16-bit result, else 3) - sfm_sinc_fir16 = passes 0 */
+int sfm_sinc_fir16_ex(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B, int L, int C, int K,
+                      int out_f32, int dtype, int passes, void* stream);
 /* The same frames-x-matrix product on the 16-bit matrix cores with split bf16 operands (hi + lo, 3 MFMAs per k-step,
  * ~4e-6 relative error): the STFTs of the training objective (training/conformer_pipeline.py:74-108) and their adjoints.
  * Whi / Wlo: the constant matrix pre-split and n-major, [Npad (x256)][Kpad (x32)] uint16; out fp32 [b][m][n] with row

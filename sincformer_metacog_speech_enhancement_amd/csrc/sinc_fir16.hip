@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256) void sinc_fir16_prep_kernel(const float* __res
   }
 }
 
-template <class T>
+// PASSES = 3: hi x hi + hi x lo + lo x hi (fp32-class accuracy); PASSES = 1: hi x hi only - waveform and taps rounded ONCE to the
+// operand format.  With fp16 operands and a 16-bit result that rounding (2^-11) is the size of the output's own, and the mask
+// RMSE of the whole path does not move (2.127e-4 -> 2.125e-4, profiles/README.md round 3) at 0.62 x the time.
+template <class T, int PASSES>
 __global__ __launch_bounds__(FIR_WAVES * 64) void sinc_fir16_kernel(const float* __restrict__ sig, const u16* __restrict__ wsh,
                                                          void* __restrict__ out, float* __restrict__ gn_partial,
                                                          int L, int pad, int out_f32, int tiles_per_batch) {
@@ -110,8 +113,10 @@ __global__ __launch_bounds__(FIR_WAVES * 64) void sinc_fir16_kernel(const float*
         const u32x4 bh = *reinterpret_cast<const u32x4*>(Wh + wo);
         const u32x4 bl = *reinterpret_cast<const u32x4*>(Wl + wo);
         acc[j] = T::mfma(ah, bh, acc[j]);
-        acc[j] = T::mfma(ah, bl, acc[j]);
-        acc[j] = T::mfma(al, bh, acc[j]);
+        if (PASSES == 3) {
+          acc[j] = T::mfma(ah, bl, acc[j]);
+          acc[j] = T::mfma(al, bh, acc[j]);
+        }
       }
     }
 
@@ -171,34 +176,45 @@ extern "C" int sfm_sinc_fir16_tiles(int L) {
   return nchunks * FIR_NSUB * 8 * FIR_WAVES;                  // (chunks x sub-tiles) x 8 shifts x waves; ZERO-FILLED by the caller
 }
 
-extern "C" int sfm_sinc_fir16(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B,
-                              int L, int C, int K, int out_f32, int dtype, void* stream) {
+template <class T, int PASSES>
+static int sinc_fir16_go(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int L, int K, int out_f32,
+                         dim3 grid, int lds, int tpb, hipStream_t st) {
+  static bool attr_set_dev[64] = {false};              // hipFuncSetAttribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
+  if (!attr_set_dev[dev]) {
+    if (hipFuncSetAttribute((const void*)sinc_fir16_kernel<T, PASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr_set_dev[dev] = true;
+  }
+  SFM_LAUNCH((sinc_fir16_prep_kernel<T>), dim3(8, FIR_C), dim3(256), 0, st, filt, (u16*)wsh, K);
+  SFM_LAUNCH((sinc_fir16_kernel<T, PASSES>), grid, dim3(FIR_WAVES * 64), lds, st, wave, (const u16*)wsh, out, gn_partial, L, K / 2,
+             out_f32, tpb);
+  return SFM_OK;
+}
+
+// passes: 3 = split operands (hi x hi + hi x lo + lo x hi, fp32-class accuracy), 1 = hi x hi only (one rounding of the waveform
+// and the taps to the operand format), 0 = auto: 1 for fp16 operands with a 16-bit result, 3 otherwise
+extern "C" int sfm_sinc_fir16_ex(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B, int L, int C,
+                                 int K, int out_f32, int dtype, int passes, void* stream) {
   if (!wave || !filt || !wsh || !out) return SFM_ERR_ARG;
-  if (C != FIR_C || K < 1 || K + 7 > FIR_KP || (K & 1) == 0 || B <= 0 || L <= 0) return SFM_ERR_SHAPE;
+  if (C != FIR_C || K < 1 || K + 7 > FIR_KP || (K & 1) == 0 || B <= 0 || L <= 0 || (passes != 0 && passes != 1 && passes != 3))
+    return SFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int chunk = FIR_NSUB * FIR_SUB;
   const int nchunks = (L + chunk - 1) / chunk;
   const int lds = (2 * FIR_C * FIR_WROW + 2 * FIR_SPAN) * 2 + FIR_WAVES * 32 * 68 * 4;
   const int tpb = nchunks * FIR_NSUB * 8 * FIR_WAVES;
-  dim3 grid(8, nchunks, B), block(FIR_WAVES * 64);
-  if (dtype == SFM_DT_F16) {
-    static bool set16 = false;
-    if (!set16) {
-      if (hipFuncSetAttribute((const void*)sinc_fir16_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return SFM_ERR_LAUNCH;
-      set16 = true;
-    }
-    SFM_LAUNCH((sinc_fir16_prep_kernel<F16>), dim3(8, FIR_C), dim3(256), 0, st, filt, (u16*)wsh, K);
-    SFM_LAUNCH((sinc_fir16_kernel<F16>), grid, block, lds, st, wave, (const u16*)wsh, out, gn_partial, L, K / 2, out_f32, tpb);
-  } else {
-    static bool setb = false;
-    if (!setb) {
-      if (hipFuncSetAttribute((const void*)sinc_fir16_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return SFM_ERR_LAUNCH;
-      setb = true;
-    }
-    SFM_LAUNCH((sinc_fir16_prep_kernel<BF16>), dim3(8, FIR_C), dim3(256), 0, st, filt, (u16*)wsh, K);
-    SFM_LAUNCH((sinc_fir16_kernel<BF16>), grid, block, lds, st, wave, (const u16*)wsh, out, gn_partial, L, K / 2, out_f32, tpb);
-  }
-  return SFM_OK;
+  dim3 grid(8, nchunks, B);
+  if (passes == 0) passes = (dtype == SFM_DT_F16 && out_f32 == 0) ? 1 : 3;
+  if (dtype == SFM_DT_F16)
+    return passes == 1 ? sinc_fir16_go<F16, 1>(wave, filt, wsh, out, gn_partial, L, K, out_f32, grid, lds, tpb, st)
+                       : sinc_fir16_go<F16, 3>(wave, filt, wsh, out, gn_partial, L, K, out_f32, grid, lds, tpb, st);
+  return passes == 1 ? sinc_fir16_go<BF16, 1>(wave, filt, wsh, out, gn_partial, L, K, out_f32, grid, lds, tpb, st)
+                     : sinc_fir16_go<BF16, 3>(wave, filt, wsh, out, gn_partial, L, K, out_f32, grid, lds, tpb, st);
+}
+
+extern "C" int sfm_sinc_fir16(const float* wave, const float* filt, void* wsh, void* out, float* gn_partial, int B,
+                              int L, int C, int K, int out_f32, int dtype, void* stream) {
+  return sfm_sinc_fir16_ex(wave, filt, wsh, out, gn_partial, B, L, C, K, out_f32, dtype, 0, stream);
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
                          c_vp],
     "sfm_sinc_fir16_tiles": [c_i],
     "sfm_sinc_fir16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_sinc_fir16_ex": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_framed_gemm_split16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll,
                                 c_ll, c_i, c_vp],
     "sfm_wave_moments": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],

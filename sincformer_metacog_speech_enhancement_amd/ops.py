@@ -688,8 +688,9 @@ def ffn_fused_ln(x32, lnw, lnb, w1_16, b1, w2_16, b2, ln2w, ln2b, ln_f32, want_y
     return y, ln
 
 
-def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True):
-    """SincConv1d FIR on split 16-bit operands -> out [B, L, C] channels-last (+ GroupNorm partials)."""
+def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True, passes=0):
+    """SincConv1d FIR on 16-bit operands -> out [B, L, C] channels-last (+ GroupNorm partials).  passes: 3 = split operands
+    (fp32-class accuracy), 1 = operands rounded once, 0 = auto (1 for fp16 operands with a 16-bit result, else 3)."""
     Lb = _lib.load()
     dev = wave.device
     wsh = torch.empty(8 * 2 * 64 * 272, device=dev, dtype=torch.int16)
@@ -697,8 +698,8 @@ def sinc_fir16(wave, filt, out, B, L, C, K, want_stats=True):
     part = torch.zeros(B, P, 8, 2, device=dev, dtype=torch.float32) if want_stats else None
     out_f32 = 1 if out.dtype == torch.float32 else 0
     flops, nbytes = 2.0 * B * L * C * K, B * L * 4 + B * L * C * (4 if out_f32 else 2)
-    _call("sinc_fir16", Lb.sfm_sinc_fir16, (_p(wave), _p(filt), _p(wsh), _p(out), _p(part), B, L, C, K, out_f32, _dt(),
-                                            _stream()), flops, nbytes)
+    _call("sinc_fir16", Lb.sfm_sinc_fir16_ex, (_p(wave), _p(filt), _p(wsh), _p(out), _p(part), B, L, C, K, out_f32, _dt(), int(passes),
+                                               _stream()), flops, nbytes)
     return part, P
 
 
