@@ -122,6 +122,28 @@ def istft_from_packed(spec, B, T, length, n_fft=N_FFT, hop=HOP, win=WIN):
     return out
 
 
+def istft_from_packed_split16(spec, B, T, length, n_fft=N_FFT, hop=HOP, win=WIN):
+    """istft_from_packed with the irfft product on the 16-bit matrix cores (split bf16 operands, ~4e-6 relative error)."""
+    F = n_fft // 2 + 1
+    c = _stft_consts(n_fft, win, spec.device)
+    if "inv16" not in c:
+        c["inv16"] = ops.pack_split16_matrix(c["inv"][:2 * F, :win].contiguous())
+    ld = spec.stride(0)
+    M = B * T
+    frames = torch.empty(M, win, device=spec.device, dtype=torch.float32)
+    ops.framed_gemm_split16(spec, c["inv16"], frames, B=1, M=M, Ls=M * ld, sig_batch_stride=0, hop=ld, padl=0, o_batch_stride=0,
+                            ldm=win, mode=0)
+    out = torch.empty(B, length, device=spec.device, dtype=torch.float32)
+    ops.istft_ola(frames, c["win2"], out, B, T, length, n_fft, hop, win, win)
+    return out
+
+
+# The fused inference path (enhance_path) takes its STFT / iSTFT on split bf16 operands: 4e-6 relative error against the exact
+# fp32 matrix instruction, far below the path's 16-bit activations, at a third of the time.  The module API (batch_stft,
+# batch_istft, the loss mirrors) keeps the exact form.
+FUSED_STFT_SPLIT16 = True
+
+
 def istft(real, imag, length, n_fft=N_FFT, hop=HOP, win=WIN):
     real, imag = real.contiguous(), imag.contiguous()
     B, T, F = real.shape
@@ -639,7 +661,7 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
         ops.pool_time(zsrc, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD, scale=zsc, shift=zsh)   # G1 -> fused[:, :2D]
     oc4 = 4 * packs["cpea"]["oc"]
     cpea_forward(fused, packs["cpea"], B, T, out=fused[:, 2 * D:2 * D + oc4])   # CPEA(z_real pooled) -> fused cols
-    nr, ni = stft(wave)
+    nr, ni = (stft_split16 if FUSED_STFT_SPLIT16 else stft)(wave)
     col = 2 * D + oc4
     with ops.stage("front"):
         ops.stft_lognorm_pack(nr, ni, fused[:, col:], M, N_FREQ, FUSE_LD - col - 2 * N_FREQ, FUSE_LD)
@@ -663,7 +685,7 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     if want_lat:
         out["zcat"] = zcat
     if "wave" in want:
-        out["enhanced"] = istft_from_packed(spec, B, T, L)
+        out["enhanced"] = (istft_from_packed_split16 if FUSED_STFT_SPLIT16 else istft_from_packed)(spec, B, T, L)
     return out
 
 
