@@ -387,7 +387,10 @@ extern "C" int sfm_ffn_fused_ln(const float* x, const float* lnw, const float* l
   dim3 grid((M + FF_BM - 1) / FF_BM), block(512);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SFM_DT_F16) {
-    static bool s16 = false;
+    static bool s16_dev[64] = {false};                     // hipFuncSetAttribute is per device
+    int d16 = 0;
+    if (hipGetDevice(&d16) != hipSuccess || d16 < 0 || d16 >= 64) return SFM_ERR_LAUNCH;
+    bool& s16 = s16_dev[d16];
     if (!s16) {
       if (hipFuncSetAttribute((const void*)ffn_fused_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return SFM_ERR_LAUNCH;
@@ -396,7 +399,10 @@ extern "C" int sfm_ffn_fused_ln(const float* x, const float* lnw, const float* l
     SFM_LAUNCH((ffn_fused_kernel<F16>), grid, block, lds, st, x, lnw, lnb, (const u16*)W1, b1, (const u16*)W2, b2, out, M,
                FF, alpha, eps, wbytes, wbytes, ln2w, ln2b, ln_out, ln_out_f32);
   } else {
-    static bool sb = false;
+    static bool sb_dev[64] = {false};
+    int db = 0;
+    if (hipGetDevice(&db) != hipSuccess || db < 0 || db >= 64) return SFM_ERR_LAUNCH;
+    bool& sb = sb_dev[db];
     if (!sb) {
       if (hipFuncSetAttribute((const void*)ffn_fused_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return SFM_ERR_LAUNCH;

@@ -407,7 +407,10 @@ template <class T, int KS>
 static int launch_dwconv_reg(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int Tn,
                              int C, int act, int out_f32, hipStream_t st) {
   const int lds = (DW_TT + KS - 1) * C * 2;
-  static bool attr = false;
+  static bool attr_dev[64] = {false};                        // hipFuncSetAttribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
+  bool& attr = attr_dev[dev];
   if (!attr) {
     if (hipFuncSetAttribute((const void*)dwconv_reg_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SFM_ERR_LAUNCH;
