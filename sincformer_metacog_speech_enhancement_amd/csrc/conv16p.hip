@@ -397,8 +397,8 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
 #pragma unroll
     for (int j = 0; j < TPS; ++j) {
       const int q = q0 + j;
-      wait_vmcnt<0>();                                 // this wave's share of weight tile q has landed
-      __builtin_amdgcn_s_barrier();                    // ... everyone's has, and tile q-1 is no longer being read
+      wait_ring<0>();                                  // this wave's share of weight tile q has landed, its reads of tile q-1 have returned
+      __builtin_amdgcn_s_barrier();                    // ... everyone's have: tile q is complete and tile q-1's slot may be refilled
       if (q + 1 < Q && (!TWO_IN || j + 1 < TPS)) issue_w(q + 1);
       if (SKIP && j == TPS - 1) {
         mma_tile(q, p.pad, accs);                      // 1x1 stride-2 conv = the centre tap of the same patch

@@ -51,6 +51,17 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// The wait in front of a ring barrier: this wave's LDS-DMA pieces of the stage to consume have landed (counted vmcnt) AND its
+// own ds_reads of the stage it read last have RETURNED (lgkmcnt(0)).  The second half is what makes the refill right after the
+// barrier safe (WAR): the compiler sinks the last MFMAs of a k-tile below the next barrier and leaves their operand reads in
+// flight across it; without the lgkmcnt a fast wave's refill of that slot (L2-hit latency: a few hundred cycles) could land
+// before a slow wave's reads were served - rare wrong 64 x 32 accumulator blocks (found in round 3 by
+// tools/pa_determinism_probe.py: 3-7 passes of 300 at B 64 in conv16p; cdna guide: "restage ... 1 phase after when an lgkmcnt
+// before the reading phase's first barrier retired those reads").
+template <int N>
+__device__ __forceinline__ void wait_ring() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 

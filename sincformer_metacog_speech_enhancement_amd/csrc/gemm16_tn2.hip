@@ -23,7 +23,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int N>
 __device__ __forceinline__ void tn2_wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  // + lgkmcnt(0): this wave's transposed reads of the slot refilled after the barrier have returned (WAR, see gemm16_epi.h wait_ring)
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
 template <class T, int WNW, int WKW, int STAGES>

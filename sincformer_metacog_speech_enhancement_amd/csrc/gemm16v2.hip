@@ -121,9 +121,9 @@ __global__ __launch_bounds__(256) void gemm16v2_kernel(Gemm2Params p) {
   for (int t = 0; t < nt; ++t) {
     // tile t must have landed; up to D-1 younger tiles may stay in flight
     const int younger = (nt - 1 - t) < (D - 1) ? (nt - 1 - t) : (D - 1);
-    if (younger >= 2) wait_vmcnt<2 * NLD>();
-    else if (younger == 1) wait_vmcnt<NLD>();
-    else wait_vmcnt<0>();
+    if (younger >= 2) wait_ring<2 * NLD>();              // (+ lgkmcnt(0): the reads of the stage refilled below have returned)
+    else if (younger == 1) wait_ring<NLD>();
+    else wait_ring<0>();
     __builtin_amdgcn_s_barrier();
     if (t + D < nt) {
       int st = stage + D;
@@ -577,8 +577,8 @@ __global__ __launch_bounds__(256) void gemm16p_kernel(Gemm2Params p, int total_t
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int t = 0; t < nt; ++t) {
-      wait_vmcnt<0>();                                 // this wave's share of the current k-tile has landed
-      __builtin_amdgcn_s_barrier();                    // ... everyone's has, and the other stage is no longer being read
+      wait_ring<0>();                                  // this wave's share of the current k-tile has landed, its reads of the other stage returned
+      __builtin_amdgcn_s_barrier();                    // ... everyone's have, and the other stage is no longer being read
       if (tile_i < t_end) issue_next(stage ^ 1);
       const unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(NW * 64) void gemm16w_kernel(Gemm2Params p) {
   issue(0, 0);
   int stage = 0;
   for (int t = 0; t < nt; ++t) {
-    wait_vmcnt<0>();
+    wait_ring<0>();
     __builtin_amdgcn_s_barrier();
     if (t + 1 < nt) issue(t + 1, stage ^ 1);
     const unsigned char* sbase = smem + stage * STAGE;
