@@ -399,7 +399,12 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
       const int q = q0 + j;
       wait_ring<0>();                                  // this wave's share of weight tile q has landed, its reads of tile q-1 have returned
       __builtin_amdgcn_s_barrier();                    // ... everyone's have: tile q is complete and tile q-1's slot may be refilled
-      if (q + 1 < Q && (!TWO_IN || j + 1 < TPS)) issue_w(q + 1);
+      // Inside a slab the next tile's refill is UNCONDITIONAL (q + 1 < Q always holds there): behind a conditional refill the
+      // compiler no longer knows which LDS-DMA operations are pending at the join and guards the tile's first fragment reads
+      // with vmcnt waits of its own - i.e. waits for the refill it has just issued (seen in the ISA of round 3's race hunt).
+      // The slab's last tile issues the next slab's first tile AFTER its own reads instead: the patch staging that follows is
+      // far longer than a weight tile's latency.
+      if (j + 1 < TPS) issue_w(q + 1);
       if (SKIP && j == TPS - 1) {
         mma_tile(q, p.pad, accs);                      // 1x1 stride-2 conv = the centre tap of the same patch
       } else {
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
         if (np == 0) mma_tile(q, t, acc[0]);
         else mma_tile(q, t, acc[NPASS - 1]);
       }
+      if (j + 1 == TPS && !TWO_IN && q + 1 < Q) issue_w(q + 1);
     }
   }
   __syncthreads();                                     // the ring becomes the epilogue strips
