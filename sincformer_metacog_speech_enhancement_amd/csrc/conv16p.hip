@@ -3,6 +3,9 @@
 #ifndef SFM_CONVP_GELU_H2
 #define SFM_CONVP_GELU_H2 1
 #endif
+#ifndef SFM_CONVP_MIX
+#define SFM_CONVP_MIX 1                 // fp16 operands: GroupNorm affine by v_fma_mix* on the packed inputs (A/B: -DSFM_CONVP_MIX=0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv16p: the PerceptionAgent's Conv1d layers (agents/perception.py:192-206, 167-171) with the GroupNorm + GELU of their
@@ -48,9 +51,15 @@ __device__ __forceinline__ float gelu_as(float z) {    // z Phi(z), erf by A&S 7
 // 1 - poly * ex cancels).  z itself (scale / shift of the GroupNorm) is still formed in fp32 from the fp16 inputs: a packed
 // x * a + d would cancel |mean / std| ulps.
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gelu_as_h2p(uint32_t zb);
 __device__ __forceinline__ uint32_t gelu_as_h2(float z0, float z1) {
   const h2_t z = {(_Float16)z0, (_Float16)z1};
-  const uint32_t zb = __builtin_bit_cast(uint32_t, z);
+  return gelu_as_h2p(__builtin_bit_cast(uint32_t, z));
+}
+// z pair already packed (the GroupNorm affine of the fp16 inputs formed by v_fma_mixlo / mixhi_f16: fp32 arithmetic, ONE rounding
+// to fp16, no unpack / pack instructions)
+__device__ __forceinline__ uint32_t gelu_as_h2p(uint32_t zb) {
+  const h2_t z = __builtin_bit_cast(h2_t, zb);
   const h2_t az = __builtin_bit_cast(h2_t, zb & 0x7fff7fffu);
   const h2_t u = az * (h2_t)(_Float16)(0.3275911f * 0.70710678118654752440f) + (h2_t)(_Float16)1.0f;
   h2_t t;
@@ -340,6 +349,23 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(ConvPParams p) {
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+#if SFM_CONVP_GELU_H2 && SFM_CONVP_MIX
+        if (T::id == SFM_DT_F16) {
+          // z = x1 * a1 [+ x2 * a2] + d straight from the packed fp16 inputs (mixed-precision FMA: fp16 source halves, fp32
+          // coefficients and arithmetic) into a packed fp16 pair: 2 (4) instructions per pair instead of 4 (7)
+          uint32_t zpk;
+          float t0 = d1[2 * e], t1 = d1[2 * e + 1];
+          if (TWO_IN) {
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(v2[e]), "v"(a2[2 * e]), "v"(d1[2 * e]));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(v2[e]), "v"(a2[2 * e + 1]), "v"(d1[2 * e + 1]));
+          }
+          asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+              "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+              : "=&v"(zpk) : "v"(v1[e]), "v"(a1[2 * e]), "v"(t0), "v"(a1[2 * e + 1]), "v"(t1));
+          o[e] = gelu_as_h2p(zpk);
+          continue;
+        }
+#endif
         float z0 = T::to_f32((u16)(v1[e] & 0xffffu)) * a1[2 * e] + d1[2 * e];
         float z1 = T::to_f32((u16)(v1[e] >> 16)) * a1[2 * e + 1] + d1[2 * e + 1];
         if (TWO_IN) {
