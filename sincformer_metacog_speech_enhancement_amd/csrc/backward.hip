@@ -8,107 +8,121 @@
 //                     dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy          (D <= 512)
 // ---------------------------------------------------------------------------
 // DYF: format of dy - 0 fp32, 1 bf16, 2 fp16 (the 16-bit result of the GEMM that produced it: half the bytes of that stream,
-// written and read)
-template <bool VEC, int DYF>
+// written and read).  NH: 256-column halves a row spans (1 for D <= 256, 2 up to 512).  R: rows a wave carries per trip, all
+// their loads (x, dy, dres) issued before the first wave reduction - one row per trip left the four dependent DPP reductions
+// with nothing in flight behind them (2.6 TB/s on the c3t rows; see profiles/README.md, round 3).
+template <bool VEC, int DYF, int NH, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const void* __restrict__ dyv, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int M, int D, int ldx, int ldy, int ld,
                                                             float eps) {
-  __shared__ float red[4][2][512];
+  constexpr int NI = 4 * NH;
+  __shared__ float red[4][2][256 * NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // VEC: lane owns columns 4*lane..4*lane+3 of each 256-column half (16-byte loads); else column lane + 64*i
 #define LN_COL(i) (VEC ? (((i) >> 2) * 256 + 4 * lane + ((i) & 3)) : (lane + 64 * (i)))
-  float pg[8], pb[8];
+  float pg[NI], pb[NI], gm[NI];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float* xr = x + (long long)row * ldx;
-    const float* gr = reinterpret_cast<const float*>(dyv) + (long long)row * ldy;          // DYF == 0
-    const u16* gh = reinterpret_cast<const u16*>(dyv) + (long long)row * ldy;               // DYF != 0
-    float v[8], g[8];
-    float s = 0.f;
-    if (VEC) {
+  for (int i = 0; i < NI; ++i) {
+    pg[i] = 0.f; pb[i] = 0.f;
+    const int d = LN_COL(i);
+    gm[i] = (d < D) ? gamma[d] : 0.f;
+  }
+  const float inv_d = 1.f / (float)D;
+  for (int row0 = (blockIdx.x * 4 + wave) * R; row0 < M; row0 += gridDim.x * 4 * R) {
+    float v[R][NI], g[R][NI], dr[R][NI];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int d = h * 256 + 4 * lane;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-        if (d < D) {
-          a = *reinterpret_cast<const f32x4*>(xr + d);
-          if (DYF == 0) c = *reinterpret_cast<const f32x4*>(gr + d);
-          else {
-            const u32x2 w = *reinterpret_cast<const u32x2*>(gh + d);
-            if (DYF == 1) c = f32x4{BF16::to_f32((u16)(w[0] & 0xffffu)), BF16::to_f32((u16)(w[0] >> 16)), BF16::to_f32((u16)(w[1] & 0xffffu)), BF16::to_f32((u16)(w[1] >> 16))};
-            else c = f32x4{F16::to_f32((u16)(w[0] & 0xffffu)), F16::to_f32((u16)(w[0] >> 16)), F16::to_f32((u16)(w[1] & 0xffffu)), F16::to_f32((u16)(w[1] >> 16))};
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      const bool live = row < M;
+      const float* xr = x + (long long)row * ldx;
+      const float* gr = reinterpret_cast<const float*>(dyv) + (long long)row * ldy;          // DYF == 0
+      const u16* gh = reinterpret_cast<const u16*>(dyv) + (long long)row * ldy;               // DYF != 0
+      const float* rr = dres + (long long)row * ld;
+      if (VEC) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const int d = h * 256 + 4 * lane;
+          f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f}, e = {0.f, 0.f, 0.f, 0.f};
+          if (live && d < D) {
+            a = *reinterpret_cast<const f32x4*>(xr + d);
+            if (DYF == 0) c = *reinterpret_cast<const f32x4*>(gr + d);
+            else {
+              const u32x2 w = *reinterpret_cast<const u32x2*>(gh + d);
+              if (DYF == 1) c = f32x4{BF16::to_f32((u16)(w[0] & 0xffffu)), BF16::to_f32((u16)(w[0] >> 16)), BF16::to_f32((u16)(w[1] & 0xffffu)), BF16::to_f32((u16)(w[1] >> 16))};
+              else c = f32x4{F16::to_f32((u16)(w[0] & 0xffffu)), F16::to_f32((u16)(w[0] >> 16)), F16::to_f32((u16)(w[1] & 0xffffu)), F16::to_f32((u16)(w[1] >> 16))};
+            }
+            if (dres) e = *reinterpret_cast<const f32x4*>(rr + d);
           }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[r][4 * h + j] = a[j]; g[r][4 * h + j] = c[j]; dr[r][4 * h + j] = e[j]; }
         }
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[4 * h + j] = a[j]; g[4 * h + j] = c[j]; s += a[j]; }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int d = LN_COL(i);
-        v[i] = (d < D) ? xr[d] : 0.f;
-        g[i] = (d < D) ? (DYF == 0 ? gr[d] : DYF == 1 ? BF16::to_f32(gh[d]) : F16::to_f32(gh[d])) : 0.f;
-        s += v[i];
-      }
-    }
-    const float mean = wave_sum_dpp(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int d = LN_COL(i);
-      const float c = (d < D) ? v[i] - mean : 0.f;
-      v[i] = c;
-      q += c * c;
-    }
-    const float rstd = rsqrtf(wave_sum_dpp(q) / (float)D + eps);
-    float a = 0.f, bsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int d = LN_COL(i);
-      const float xh = v[i] * rstd;
-      v[i] = xh;
-      pg[i] += g[i] * xh;
-      pb[i] += g[i];
-      const float gg = (d < D) ? g[i] * gamma[d] : 0.f;
-      g[i] = gg;
-      a += gg;
-      bsum += gg * xh;
-    }
-    a = wave_sum_dpp(a) / (float)D;
-    bsum = wave_sum_dpp(bsum) / (float)D;
-    if (VEC) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int d = h * 256 + 4 * lane;
-        if (d < D) {
-          f32x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = rstd * (g[4 * h + j] - a - v[4 * h + j] * bsum);
-          if (dres) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(dres + (long long)row * ld + d);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += r[j];
-          }
-          *reinterpret_cast<f32x4*>(dx + (long long)row * ld + d) = o;
+        for (int i = 0; i < NI; ++i) {
+          const int d = LN_COL(i);
+          const bool ok = live && d < D;
+          v[r][i] = ok ? xr[d] : 0.f;
+          g[r][i] = ok ? (DYF == 0 ? gr[d] : DYF == 1 ? BF16::to_f32(gh[d]) : F16::to_f32(gh[d])) : 0.f;
+          dr[r][i] = (ok && dres) ? rr[d] : 0.f;
         }
       }
-    } else {
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) s += v[r][i];
+      const float mean = wave_sum_dpp(s) * inv_d;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
         const int d = LN_COL(i);
-        if (d < D) {
-          float o = rstd * (g[i] - a - v[i] * bsum);
-          if (dres) o += dres[(long long)row * ld + d];
-          dx[(long long)row * ld + d] = o;
+        const float c = (d < D) ? v[r][i] - mean : 0.f;
+        v[r][i] = c;
+        q += c * c;
+      }
+      const float rstd = rsqrtf(wave_sum_dpp(q) * inv_d + eps);
+      float a = 0.f, bsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float xh = v[r][i] * rstd;
+        v[r][i] = xh;
+        pg[i] += g[r][i] * xh;
+        pb[i] += g[r][i];
+        const float gg = g[r][i] * gm[i];
+        g[r][i] = gg;
+        a += gg;
+        bsum += gg * xh;
+      }
+      a = wave_sum_dpp(a) * inv_d;
+      bsum = wave_sum_dpp(bsum) * inv_d;
+      if (row < M) {
+        if (VEC) {
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            const int d = h * 256 + 4 * lane;
+            if (d < D) {
+              f32x4 o;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = rstd * (g[r][4 * h + j] - a - v[r][4 * h + j] * bsum) + dr[r][4 * h + j];
+              *reinterpret_cast<f32x4*>(dx + (long long)row * ld + d) = o;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int d = LN_COL(i);
+            if (d < D) dx[(long long)row * ld + d] = rstd * (g[r][i] - a - v[r][i] * bsum) + dr[r][i];
+          }
         }
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NI; ++i) {
     red[wave][0][LN_COL(i)] = pg[i];
     red[wave][1][LN_COL(i)] = pb[i];
   }
@@ -126,17 +140,20 @@ extern "C" int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const vo
                                     void* stream) {
   if (!x || !gamma || !dy || !dx || !dgamma || !dbeta) return SFM_ERR_ARG;
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
-  int nb = (M + 3) / 4;
+  constexpr int LNB_R = 2;
+  int nb = (M + 4 * LNB_R - 1) / (4 * LNB_R);
   if (nb > 1024) nb = 1024;                                  // 1024 x 512 contended atomics at the end: measured best of 512..4096
   const int dyb = dy_16 ? 2 : 4;
   const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ld % 4 == 0) && (ldy % 4 == 0) &&
                    ((((uintptr_t)x | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0) && (((uintptr_t)dy) % (4 * dyb)) == 0;
   const int f = dy_16 ? (dtype == SFM_DT_F16 ? 2 : 1) : 0;
   hipStream_t st = (hipStream_t)stream;
-#define LNB_GO(V, F) SFM_LAUNCH((layernorm_bwd_kernel<V, F>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps)
+#define LNB_GO2(V, F, H) SFM_LAUNCH((layernorm_bwd_kernel<V, F, H, LNB_R>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps)
+#define LNB_GO(V, F) do { if (D <= 256) LNB_GO2(V, F, 1); else LNB_GO2(V, F, 2); } while (0)
   if (vec) { if (f == 0) LNB_GO(true, 0); else if (f == 1) LNB_GO(true, 1); else LNB_GO(true, 2); }
   else { if (f == 0) LNB_GO(false, 0); else if (f == 1) LNB_GO(false, 1); else LNB_GO(false, 2); }
 #undef LNB_GO
+#undef LNB_GO2
   return SFM_OK;
 }
 

@@ -50,15 +50,23 @@ __device__ __forceinline__ void gn_st8(void* p, long long e, int f32, const floa
   }
 }
 
-// d/dz of z Phi(z) = Phi(z) + z phi(z); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), sharing exp(-z^2/2) with phi
+// d/dz of z Phi(z) = Phi(z) + z phi(z).  Phi(z) - 1/2 = z Q(z^2) on |z| <= 3.75 (clamped beyond), Q of degree 6 fitted
+// minimax to the erf form: |error| < 5.7e-5 over all z, under the 16-bit spacing of the d it scales.  One transcendental
+// (the exponential of phi) instead of the two of the Abramowitz-Stegun form (reciprocal + exponential): the reduce pass is
+// VALU-bound (tools/gn_bwd_bench.py; profiles/README.md, round 3).
 __device__ __forceinline__ float gelu_grad(float z) {
-  const float ax = fabsf(z) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  const float ex = __expf(-0.5f * z * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erfa = 1.0f - poly * ex;                                      // erf(|z| / sqrt 2)
-  const float cdf = 0.5f * (1.0f + copysignf(erfa, z));
-  return cdf + z * 0.39894228040143267794f * ex;
+  const float zc = __builtin_amdgcn_fmed3f(z, -3.75f, 3.75f);
+  const float u = zc * zc;
+  float q = 3.912424329e-08f;
+  q = fmaf(q, u, -2.376248530e-06f);
+  q = fmaf(q, u, 6.234773063e-05f);
+  q = fmaf(q, u, -9.441793120e-04f);
+  q = fmaf(q, u, 9.362551949e-03f);
+  q = fmaf(q, u, -6.578987097e-02f);
+  q = fmaf(q, u, 3.987064729e-01f);
+  const float cdf = fmaf(zc, q, 0.5f);
+  const float ex = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);          // exp(-z^2 / 2)
+  return fmaf(z * 0.39894228040143267794f, ex, cdf);
 }
 
 struct GnRegs {
@@ -77,10 +85,9 @@ __device__ __forceinline__ void gn_load_regs(const GnIn& in, long long b, int c0
 }
 
 // grid (row tiles, B); block 256 = (C/8 channel vectors) x (2048/C row lanes); C in {64, 128, 256, 512, 1024, 2048}
-template <class T, int TWO>
+template <class T, int TWO, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void* __restrict__ dout, int dout_f32, GnIn i1, GnIn i2,
-                                                            float* __restrict__ S, int L, int C, int G, int act,
-                                                            int rows_per_block) {
+                                                            float* __restrict__ S, int L, int C, int G, int rows_per_block) {
   extern __shared__ float red[];                       // [rl][3][C]
   const long long b = blockIdx.y;
   const int nv = C >> 3, rl = 256 / nv;
@@ -98,20 +105,23 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void* __restri
     gn_ld8<T>(dout, e, dout_f32, dp);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float p = x1[j] * r1.sc[j] + r1.sh[j];
-      if (TWO) p += x2[j] * r2.sc[j] + r2.sh[j];
-      const float d = act ? dp[j] * gelu_grad(p) : dp[j];
+      if (ACT) {
+        float p = x1[j] * r1.sc[j] + r1.sh[j];
+        if (TWO) p += x2[j] * r2.sc[j] + r2.sh[j];
+        dp[j] *= gelu_grad(p);
+      }
+      const float d = dp[j];
       s0[j] += d;
-      s1[j] += d * (x1[j] - r1.mu[j]) * r1.rs[j];
-      if (TWO) s2[j] += d * (x2[j] - r2.mu[j]) * r2.rs[j];
+      s1[j] += d * (x1[j] - r1.mu[j]);                 // x rstd once, below
+      if (TWO) s2[j] += d * (x2[j] - r2.mu[j]);
     }
   }
   float* mine = red + (long long)tr * 3 * C;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mine[c0 + j] = s0[j];
-    mine[C + c0 + j] = s1[j];
-    mine[2 * C + c0 + j] = s2[j];
+    mine[C + c0 + j] = s1[j] * r1.rs[j];
+    mine[2 * C + c0 + j] = TWO ? s2[j] * r2.rs[j] : 0.f;
   }
   __syncthreads();
   const int nk = TWO ? 3 * C : 2 * C;
@@ -161,9 +171,9 @@ __global__ __launch_bounds__(256) void gn_bwd_coefs_kernel(const float* __restri
   }
 }
 
-template <class T, int TWO>
+template <class T, int TWO, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ dout, int dout_f32, GnIn i1, GnIn i2,
-                                                           int B, int L, int C, int G, int act, int rows_per_block) {
+                                                           int B, int L, int C, int G, int rows_per_block) {
   const long long b = blockIdx.y;
   const int nv = C >> 3, rl = 256 / nv;
   const int tv = threadIdx.x % nv, tr = threadIdx.x / nv, c0 = tv * 8;
@@ -175,8 +185,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
   if (TWO) gn_load_regs(i2, b, c0, C, G, r2);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    a1[j] = i1.coef[b * C + c0 + j]; b1[j] = i1.coef[BC + b * C + c0 + j]; k1[j] = i1.coef[2 * BC + b * C + c0 + j];
-    if (TWO) { a2[j] = i2.coef[b * C + c0 + j]; b2[j] = i2.coef[BC + b * C + c0 + j]; k2[j] = i2.coef[2 * BC + b * C + c0 + j]; }
+    // d1 = a d - b - (x - mu) rstd k  =  a d - (b - mu rstd k) - x (rstd k)
+    a1[j] = i1.coef[b * C + c0 + j];
+    k1[j] = i1.coef[2 * BC + b * C + c0 + j] * r1.rs[j];
+    b1[j] = i1.coef[BC + b * C + c0 + j] - r1.mu[j] * k1[j];
+    if (TWO) {
+      a2[j] = i2.coef[b * C + c0 + j];
+      k2[j] = i2.coef[2 * BC + b * C + c0 + j] * r2.rs[j];
+      b2[j] = i2.coef[BC + b * C + c0 + j] - r2.mu[j] * k2[j];
+    }
   }
   for (int l = l0 + tr; l < l1; l += rl) {
     const long long e = (b * L + l) * C + c0;
@@ -186,11 +203,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
     gn_ld8<T>(dout, e, dout_f32, dp);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float p = x1[j] * r1.sc[j] + r1.sh[j];
-      if (TWO) p += x2[j] * r2.sc[j] + r2.sh[j];
-      const float d = act ? dp[j] * gelu_grad(p) : dp[j];
-      d1[j] = a1[j] * d - b1[j] - (x1[j] - r1.mu[j]) * r1.rs[j] * k1[j];
-      if (TWO) d2[j] = a2[j] * d - b2[j] - (x2[j] - r2.mu[j]) * r2.rs[j] * k2[j];
+      float d = dp[j];
+      if (ACT) {
+        float p = x1[j] * r1.sc[j] + r1.sh[j];
+        if (TWO) p += x2[j] * r2.sc[j] + r2.sh[j];
+        d *= gelu_grad(p);
+      }
+      d1[j] = fmaf(-x1[j], k1[j], fmaf(a1[j], d, -b1[j]));
+      if (TWO) d2[j] = fmaf(-x2[j], k2[j], fmaf(a2[j], d, -b2[j]));
     }
     gn_st8<T>(i1.dx, e, i1.dx_f32, d1);
     if (TWO) gn_st8<T>(i2.dx, e, i2.dx_f32, d2);
@@ -225,13 +245,11 @@ extern "C" int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1,
   dim3 grid((L + rpb - 1) / rpb, B), block(256);
   const size_t lds = (size_t)(2048 / C) * 3 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SFM_DT_F16) {
-    if (x2) SFM_LAUNCH((gn_bwd_reduce_kernel<F16, 1>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
-    else SFM_LAUNCH((gn_bwd_reduce_kernel<F16, 0>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
-  } else {
-    if (x2) SFM_LAUNCH((gn_bwd_reduce_kernel<BF16, 1>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
-    else SFM_LAUNCH((gn_bwd_reduce_kernel<BF16, 0>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, act, rpb);
-  }
+#define GNR_GO(T, TWO, ACT) SFM_LAUNCH((gn_bwd_reduce_kernel<T, TWO, ACT>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, rpb)
+#define GNR_T(T) do { if (x2) { if (act) GNR_GO(T, 1, 1); else GNR_GO(T, 1, 0); } else { if (act) GNR_GO(T, 0, 1); else GNR_GO(T, 0, 0); } } while (0)
+  if (dtype == SFM_DT_F16) GNR_T(F16); else GNR_T(BF16);
+#undef GNR_T
+#undef GNR_GO
   return SFM_OK;
 }
 
@@ -262,12 +280,10 @@ extern "C" int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, 
   const int rpb = gn_rows_per_block(C);
   dim3 grid((L + rpb - 1) / rpb, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SFM_DT_F16) {
-    if (x2) SFM_LAUNCH((gn_bwd_apply_kernel<F16, 1>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
-    else SFM_LAUNCH((gn_bwd_apply_kernel<F16, 0>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
-  } else {
-    if (x2) SFM_LAUNCH((gn_bwd_apply_kernel<BF16, 1>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
-    else SFM_LAUNCH((gn_bwd_apply_kernel<BF16, 0>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, act, rpb);
-  }
+#define GNA_GO(T, TWO, ACT) SFM_LAUNCH((gn_bwd_apply_kernel<T, TWO, ACT>), grid, block, 0, st, dout, dout_f32, a, c, B, L, C, G, rpb)
+#define GNA_T(T) do { if (x2) { if (act) GNA_GO(T, 1, 1); else GNA_GO(T, 1, 0); } else { if (act) GNA_GO(T, 0, 1); else GNA_GO(T, 0, 0); } } while (0)
+  if (dtype == SFM_DT_F16) GNA_T(F16); else GNA_T(BF16);
+#undef GNA_T
+#undef GNA_GO
   return SFM_OK;
 }

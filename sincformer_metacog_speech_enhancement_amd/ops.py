@@ -809,7 +809,7 @@ def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, s
     work = torch.zeros(3 * B * C + 3 * C, device=dev, dtype=torch.float32)       # S [B][3][C] | dparam [3][C]
     S, dparam = work[:3 * B * C], work[3 * B * C:].view(3, C)
     nbytes = float(B * L * C) * ((4 if f32(dout) else 2) + (1 + two) * (4 if f32(x1) else 2))
-    _call("gn_bwd", L_.sfm_gn_bwd_reduce, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(x2),
+    _call("gn_bwd_reduce", L_.sfm_gn_bwd_reduce, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(x2),
                                            f32(x2) if two else 0, _p(sc2), _p(sh2), _p(mean2), _p(rstd2), _p(S), B, L, C, G,
                                            int(act), _dt(), _stream()), 0.0, nbytes)
     coef = torch.empty(2, 3, B, C, device=dev, dtype=torch.float32)
@@ -818,7 +818,7 @@ def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, s
           4.0 * 9 * B * C)
     dx1 = torch.empty(B, L, C, device=dev, dtype=dx_dtype)
     dx2 = torch.empty(B, L, C, device=dev, dtype=dx_dtype) if two else None
-    _call("gn_bwd", L_.sfm_gn_bwd_apply, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(coef[0]),
+    _call("gn_bwd_apply", L_.sfm_gn_bwd_apply, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(coef[0]),
                                           _p(dx1), f32(dx1), _p(x2), f32(x2) if two else 0, _p(sc2), _p(sh2), _p(mean2), _p(rstd2),
                                           _p(coef[1]) if two else None, _p(dx2), f32(dx2) if two else 0, B, L, C, G, int(act),
                                           _dt(), _stream()), 0.0, nbytes + float(B * L * C) * (1 + two) * (4 if f32(dx1) else 2))

@@ -91,13 +91,15 @@ def _ffn_bwd(dy, c, G, pre):
     FF = c["z1"].shape[1]
     do = torch.empty(M, D, device=dy.device, dtype=dt)
     ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=0.5, p=c["p"], seed=c["s2"])
-    ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"], G[pre + "linear2.bias"])
+    # input gradient first, weight gradient second: the K = 1024 weight-gradient GEMM launched right behind the streaming
+    # ew_train ran 0.28 ms against 0.21 ms behind a GEMM (tools/ffn_bwd_probe.py --variant late; profiles/README.md, round 3)
     if FUSE_FFN_SWISH and FF % 8 == 0:
         dz = ops.linear16_swish(do, c["b2"], p_drop=c["p"], seed=c["s1"], aux=c["z1"])   # (do W2) * d, d saved by the forward
     else:
         du = ops.linear16(do, c["b2"], out_dtype=torch.float32)             # [M, FF]
         dz = torch.empty(M, FF, device=dy.device, dtype=dt)
         ops.ew_train(ops.EW_SWISH_BWD, dz, z=c["z1"], g=du, p=c["p"], seed=c["s1"])
+    ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"], G[pre + "linear2.bias"])
     ops.gemm16_tn(dz, c["h16"], G[pre + "linear1.weight"], G[pre + "linear1.bias"])
     dh = ops.linear16(dz, c["b1"])                                          # [M, D] 16-bit: read once, by the LayerNorm backward
     return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G[pre + "layer_norm.weight"], G[pre + "layer_norm.bias"])
