@@ -20,3 +20,20 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(json.dumps({"ms": ms, "us_per_step": 1e3 * ms / T, "checksum": float(out.double().abs().sum())}))
+# training pair at the c3t batch (B 256): forward with the saved gates, then the BPTT kernel
+Bt = 256
+xg = torch.randn(Bt, T, 2, 4 * H, device="cuda", generator=g)
+out, save = ops.bilstm_layer_train(xg, whh, Bt, T, H)
+dout = torch.randn(Bt, T, 2 * H, device="cuda", generator=g)
+for name, fn in (("fwd_train_b256", lambda: ops.bilstm_layer_train(xg, whh, Bt, T, H)), ("bwd_b256", lambda: ops.bilstm_layer_bwd(save, whh, dout, Bt, T, H))):
+    for _ in range(2):
+        r = fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        r = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    r0 = r[0] if isinstance(r, tuple) else r
+    print(json.dumps({"what": name, "ms": ms, "us_per_step": 1e3 * ms / T, "checksum": float(r0.double().abs().sum())}))
