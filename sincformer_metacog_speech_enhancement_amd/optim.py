@@ -3,6 +3,7 @@
 with no host synchronisation: the clip coefficient, the skip decision and the bias corrections are computed
 on the device.  Data parallel: pass a dp.FlatGradSynchronizer; its buffer holds the SUM over ranks and 1/world
 is folded into the unscale factor."""
+import os
 import torch
 
 from . import ops, dp as _dp
@@ -10,12 +11,17 @@ from . import ops, dp as _dp
 
 class FlatAdamW:
     def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_norm=5.0, sync=None,
-                 bucket_bytes=16 << 20, overlap=True):
+                 bucket_bytes=16 << 20, overlap=True, steal_grads=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params or not self.params[0].is_cuda:
             raise RuntimeError("FlatAdamW: parameters must live on the MI355X (no CPU fallback)")
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
-        self.sync = sync or _dp.FlatGradSynchronizer(self.params, bucket_bytes=bucket_bytes, overlap=overlap)
+        if steal_grads is None:
+            steal_grads = os.environ.get("SFM_STEAL_GRADS", "1") != "0"          # A/B knob
+        # steal_grads: autograd keeps the gradient tensors of the backward nodes and the synchronizer gathers them into the flat
+        # buffer with a few cat launches (dp.FlatGradSynchronizer) instead of one aten add per parameter; `p.grad` is then None
+        # after zero_grad() (torch's set_to_none) - code that writes gradients into the flat views by hand passes False
+        self.sync = sync or _dp.FlatGradSynchronizer(self.params, bucket_bytes=bucket_bytes, overlap=overlap, steal=steal_grads)
         dev = self.params[0].device
         n = self.sync.n
         self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)

@@ -1,6 +1,7 @@
 """N>1 path on CPU: world_size-2 gloo processes exercise utterance sharding and the flat
 gradient all-reduce / NaN-flag agreement / global-norm clip used for data-parallel training."""
 import os
+import pytest
 import socket
 import numpy as np
 import torch
@@ -74,7 +75,7 @@ def test_shard_range_covers_everything():
             assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
 
 
-def _overlap_worker(rank, world, port, q):
+def _overlap_worker(rank, world, port, q, steal=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -82,7 +83,7 @@ def _overlap_worker(rank, world, port, q):
     torch.manual_seed(0)                                     # same weights on both ranks
     model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
                                 torch.nn.Linear(16, 4))
-    sync = dp.FlatGradSynchronizer(model.parameters(), bucket_bytes=400, overlap=True)
+    sync = dp.FlatGradSynchronizer(model.parameters(), bucket_bytes=400, overlap=True, steal=steal)
     nb = len(sync.buckets)
     torch.manual_seed(100 + rank)                            # different data per rank (the utterance shard)
     x, y = torch.randn(5, 8), torch.randn(5, 4)
@@ -105,6 +106,8 @@ def _overlap_worker(rank, world, port, q):
         dist.all_gather(gathered, local)
         ok = ok and torch.allclose(got, sum(gathered) / world, atol=1e-6)
         ok = ok and float(sync.flag) == 0.0
+        # after finish() every p.grad is the flat view again (steal mode rebinds it), holding the sum over ranks
+        ok = ok and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync._views))
     # flag: NaN loss on one rank -> flag > 0 everywhere after finish()
     sync.zero()
     sync.finish(torch.tensor(float("inf")) if rank == 0 else torch.tensor(1.0))
@@ -113,11 +116,14 @@ def _overlap_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucket_overlap_hooks_two_ranks():
+@pytest.mark.parametrize("steal", [False, True])
+def test_bucket_overlap_hooks_two_ranks(steal):
+    """steal=True: zero() unbinds p.grad, autograd keeps the backward nodes' tensors, each bucket is gathered (torch.cat) into the
+    flat buffer right before it goes out - same reduced gradients, same launch order"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q, steal)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
@@ -127,7 +133,7 @@ def test_bucket_overlap_hooks_two_ranks():
     assert all(r[1] for r in res)
 
 
-def _touched_worker(rank, world, port, q):
+def _touched_worker(rank, world, port, q, steal=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -135,7 +141,7 @@ def _touched_worker(rank, world, port, q):
     torch.manual_seed(0)
     trunk, head_a, head_b = torch.nn.Linear(8, 8), torch.nn.Linear(8, 2), torch.nn.Linear(8, 2)
     params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
-    sync = dp.FlatGradSynchronizer(params, bucket_bytes=128, overlap=True)
+    sync = dp.FlatGradSynchronizer(params, bucket_bytes=128, overlap=True, steal=steal)
     x = torch.randn(4, 8)
     sync.zero()
     # data-dependent routing: rank 0's graph reaches head_a only, rank 1's head_b only; an extra head is reached by nobody
@@ -154,13 +160,14 @@ def _touched_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_touched_mask_is_reduced_with_the_gradients():
+@pytest.mark.parametrize("steal", [False, True])
+def test_touched_mask_is_reduced_with_the_gradients(steal):
     """replicas whose backward passes reach different parameters must still step the same set: the per-rank 0 / 1 mask rides
     in the header of bucket 0 and comes back summed (optim.FlatAdamW steps a parameter when the sum is > 0)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_touched_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_touched_worker, args=(r, 2, port, q, steal)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)

@@ -298,7 +298,8 @@ def test_flat_adamw_matches_torch_adamw_with_clip_and_skip():
     a, b = mk(), mk()
     b.load_state_dict(a.state_dict())
     ref = torch.optim.AdamW(a.parameters(), lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01)
-    opt = FlatAdamW(b.parameters(), lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0)
+    # gradients are written into the flat views by hand here: steal_grads=False keeps p.grad bound to them after zero_grad()
+    opt = FlatAdamW(b.parameters(), lr=5e-4, betas=(0.9, 0.98), weight_decay=0.01, max_norm=5.0, steal_grads=False)
     for it in range(6):
         gs = [torch.randn_like(p) * (10.0 if it % 2 == 0 else 0.01) for p in a.parameters()]   # clip active / inactive
         ref.zero_grad(set_to_none=True)
