@@ -569,7 +569,7 @@ def dwconv_folded(x16, wT, sc, sh, B, T, C, out=None, act=1):
 def convert_rows(src32, dst16, M, C, Cz, ld_src, ld_dst):
     L = _lib.load()
     _call("convert_rows", L.sfm_convert_rows, (_p(src32), _p(dst16), M, C, Cz, ld_src, ld_dst, _dt(), _stream()),
-          *_cost_of("convert_rows", locals()))
+          *_cost_of("convert_rows", locals()), tag="M%d C%d" % (M, C))
 
 
 def transpose(src, dst, B, R, C, src_batch, src_row, dst_batch, dst_row):

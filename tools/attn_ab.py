@@ -15,6 +15,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="3,4")
+ap.add_argument("--prescaled", action="store_true", help="q already carries log2(e)/sqrt(hd), as functional.pack_mhsa folds it into W_q: the call the path makes")
 a = ap.parse_args()
 ops.set_compute_dtype(a.dtype)
 B, T, H, hd = a.batch, a.frames, a.heads, 64
@@ -25,12 +26,14 @@ variants = [int(v) for v in a.variants.split(",")]
 q, k, v = [t.float().reshape(B, T, H, hd) for t in qkv.split(H * hd, dim=1)]
 bi, hi = B - 1, H - 1
 ref = torch.softmax(q[bi, :, hi] @ k[bi, :, hi].t() / hd ** 0.5, dim=-1) @ v[bi, :, hi]
+if a.prescaled:
+    qkv[:, :H * hd] = (qkv[:, :H * hd].float() * (1.4426950408889634 / hd ** 0.5)).to(qkv.dtype)
 res = {}
 for var in variants:
     ops.set_attention_variant(var)
     out.zero_()
     for _ in range(3):
-        ops.attention(qkv, B, T, H, hd, out=out)
+        ops.attention(qkv, B, T, H, hd, out=out, prescaled=a.prescaled)
     torch.cuda.synchronize()
     err = float((out.float().reshape(B, T, H, hd)[bi, :, hi] - ref).abs().max())
     res[var] = {"max_err_vs_fp32": err, "finite": bool(torch.isfinite(out.float()).all()), "ms": []}
@@ -40,7 +43,7 @@ for r in range(a.rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            ops.attention(qkv, B, T, H, hd, out=out)
+            ops.attention(qkv, B, T, H, hd, out=out, prescaled=a.prescaled)
         e1.record()
         torch.cuda.synchronize()
         res[var]["ms"].append(e0.elapsed_time(e1) / a.iters)

@@ -19,27 +19,29 @@ ops.set_compute_dtype(a.dtype)
 ops.set_attention_variant(a.variant)
 B, T, H, hd = a.batch, a.frames, a.heads, 64
 g = torch.Generator(device="cuda").manual_seed(1)
-qkv = (torch.randn(B * T, 3 * H * hd, device="cuda", generator=g) * 1.0).to(ops.compute_dtype())
+qkv = torch.randn(B * T, 3 * H * hd, device="cuda", generator=g)
+qkv[:, :H * hd] *= 1.4426950408889634 / hd ** 0.5            # q pre-scaled as functional.pack_mhsa folds it into W_q: the path's call
+qkv = qkv.to(ops.compute_dtype())
 out = torch.empty(B * T, H * hd, device="cuda", dtype=ops.compute_dtype())
 for _ in range(3):
-    ops.attention(qkv, B, T, H, hd, out=out)
+    ops.attention(qkv, B, T, H, hd, out=out, prescaled=True)
 torch.cuda.synchronize()
 if a.check:
     ops.set_attention_variant(1)
-    ref = ops.attention(qkv, B, T, H, hd)
+    ref = ops.attention(qkv, B, T, H, hd, prescaled=True)
     ops.set_attention_variant(a.variant)
     torch.cuda.synchronize()
     d = (out.float() - ref.float()).abs()
     q, k, v = [t.float().reshape(B, T, H, hd) for t in qkv.split(H * hd, dim=1)]
     bi, hi = B - 1, H - 1
-    p = torch.softmax(q[bi, :, hi] @ k[bi, :, hi].t() / hd ** 0.5, dim=-1) @ v[bi, :, hi]
+    p = torch.softmax(q[bi, :, hi] @ k[bi, :, hi].t() * 0.6931471805599453, dim=-1) @ v[bi, :, hi]   # q carries log2(e)/sqrt(hd)
     e = (out.float().reshape(B, T, H, hd)[bi, :, hi] - p).abs().max()
     print("check: max |variant %d - variant 1| = %.3e (mean %.3e); max |out - fp32 softmax| on (b=%d, h=%d) = %.3e, finite %s" %
           (a.variant, float(d.max()), float(d.mean()), bi, hi, float(e), bool(torch.isfinite(out.float()).all())), file=sys.stderr)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.iters):
-    ops.attention(qkv, B, T, H, hd, out=out)
+    ops.attention(qkv, B, T, H, hd, out=out, prescaled=True)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters

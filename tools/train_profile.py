@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--families", default="", help="comma list: print EVERY tagged shape of these kernel families (e.g. convert_rows)")
     a = ap.parse_args()
     import torch
     import bench
@@ -77,6 +78,11 @@ def main():
         tf = v["flops"] / max(v["ms_total"], 1e-9) / 1e9
         gb = v["bytes"] / max(v["ms_total"], 1e-9) / 1e6
         print("  %-64s n %3d  %8.3f ms  %7.1f TF/s %7.0f GB/s" % (k, v["n"], v["ms_total"], tf, gb))
+    for famname in [f for f in a.families.split(",") if f]:
+        print("all shapes of %s:" % famname)
+        for k, v in sorted(tagged.items(), key=lambda kv: -kv[1]["ms_total"]):
+            if k.startswith(famname + "["):
+                print("  %-64s n %3d  %8.3f ms  %7.0f GB/s" % (k, v["n"], v["ms_total"], v["bytes"] / max(v["ms_total"], 1e-9) / 1e6))
     if a.out:
         with open(a.out, "w") as fh:
             json.dump({"wall_ms": wall, "host_enqueue_ms": host, "kernel_ms": ksum, "launches": nlaunch, "families": fam,
