@@ -50,23 +50,12 @@ __device__ __forceinline__ void gn_st8(void* p, long long e, int f32, const floa
   }
 }
 
-// d/dz of z Phi(z) = Phi(z) + z phi(z).  Phi(z) - 1/2 = z Q(z^2) on |z| <= 3.75 (clamped beyond), Q of degree 6 fitted
-// minimax to the erf form: |error| < 5.7e-5 over all z, under the 16-bit spacing of the d it scales.  One transcendental
-// (the exponential of phi) instead of the two of the Abramowitz-Stegun form (reciprocal + exponential): the reduce pass is
-// VALU-bound (tools/gn_bwd_bench.py; profiles/README.md, round 3).
+// d/dz of z Phi(z) = Phi(z) + z phi(z) with the polynomial CDF of sfm_common.h (|error| < 5.7e-5, under the 16-bit spacing of the
+// d it scales): ONE transcendental (the exponential of phi) instead of the two of the Abramowitz-Stegun form (reciprocal +
+// exponential) - the reduce pass is VALU-bound (tools/gn_bwd_bench.py; profiles/README.md, round 3).
 __device__ __forceinline__ float gelu_grad(float z) {
-  const float zc = __builtin_amdgcn_fmed3f(z, -3.75f, 3.75f);
-  const float u = zc * zc;
-  float q = 3.912424329e-08f;
-  q = fmaf(q, u, -2.376248530e-06f);
-  q = fmaf(q, u, 6.234773063e-05f);
-  q = fmaf(q, u, -9.441793120e-04f);
-  q = fmaf(q, u, 9.362551949e-03f);
-  q = fmaf(q, u, -6.578987097e-02f);
-  q = fmaf(q, u, 3.987064729e-01f);
-  const float cdf = fmaf(zc, q, 0.5f);
   const float ex = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);          // exp(-z^2 / 2)
-  return fmaf(z * 0.39894228040143267794f, ex, cdf);
+  return fmaf(z * 0.39894228040143267794f, ex, normal_cdf_poly(z));
 }
 
 struct GnRegs {
