@@ -530,10 +530,41 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const float* __restri
   }
 }
 
+// 8 columns per thread: two 16-byte loads, one 16-byte store, 32-bit index arithmetic (the scalar kernel above divides a
+// 64-bit index per ELEMENT and stores 2 bytes at a time: 2.9 TB/s on the training step's [205 056, 256] conversions)
+template <class T>
+__global__ __launch_bounds__(256) void convert_rows_vec_kernel(const float* __restrict__ src, u16* __restrict__ dst, int M, int C,
+                                                               int cpr, long long lds_, long long ldd) {
+  const int total = M * cpr;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int m = e / cpr, c = (e - m * cpr) * 8;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (c < C) {                                          // (C % 8 == 0: a chunk is whole or all padding)
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + m * lds_ + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(src + m * lds_ + c + 4);
+      o = u32x4{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3])};
+    }
+    *reinterpret_cast<u32x4*>(dst + m * ldd + c) = o;
+  }
+}
+
 extern "C" int sfm_convert_rows(const float* src, void* dst, long long M, int C, int Cz, long long ld_src,
                                 long long ld_dst, int dtype, void* stream) {
   if (!src || !dst) return SFM_ERR_ARG;
   if (M <= 0 || C <= 0 || Cz < C) return SFM_ERR_SHAPE;
+  if (C % 8 == 0 && Cz % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 &&
+      M * (long long)(Cz / 8) < (1ll << 31)) {
+    const int cpr = Cz / 8;
+    long long nbv = (M * cpr + 255) / 256;
+    if (nbv > 32768) nbv = 32768;
+    if (dtype == SFM_DT_F16)
+      SFM_LAUNCH((convert_rows_vec_kernel<F16>), dim3((unsigned)nbv), dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, (int)M, C, cpr,
+                 ld_src, ld_dst);
+    else
+      SFM_LAUNCH((convert_rows_vec_kernel<BF16>), dim3((unsigned)nbv), dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, (int)M, C, cpr,
+                 ld_src, ld_dst);
+    return SFM_OK;
+  }
   long long nb = (M * Cz + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (dtype == SFM_DT_F16)
