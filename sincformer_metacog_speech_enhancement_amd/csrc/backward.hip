@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void ew_train_vec_kernel(const void* __restric
       gv[i] = 1.0f;
       dr[i] = 1.0f;
     }
-    if (p > 0.f && MODE != 2 && MODE != 3) sfm_keep_scale8(seed, (unsigned long long)e0, p, inv_keep, dr);
+    if (p > 0.f && MODE != 2 && MODE != 3 && MODE != 5 && MODE != 6) sfm_keep_scale8(seed, (unsigned long long)e0, p, inv_keep, dr);
     if (g) {
       if (g_f32) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + e0);
@@ -294,13 +294,24 @@ __global__ __launch_bounds__(256) void ew_train_vec_kernel(const void* __restric
       }
     } else {
       float r[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) r[i] = alpha * gv[i] * dr[i];
-      if (z) {
+      if (MODE == 5 || MODE == 6) {                                 // exact-erf GELU on an fp32 operand: forward, or g * gelu'(z)
         const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(z) + e0);
         const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(z) + e0 + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { r[i] += a[i]; r[4 + i] += b[i]; }
+        for (int i = 0; i < 8; ++i) {
+          const float zv = i < 4 ? a[i & 3] : b[i & 3];
+          const float cdf = 0.5f * (1.0f + erff(zv * 0.70710678118654752440f));
+          r[i] = (MODE == 5) ? zv * cdf : gv[i] * (cdf + zv * 0.39894228040143267794f * __expf(-0.5f * zv * zv));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = alpha * gv[i] * dr[i];
+        if (z) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(z) + e0);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(z) + e0 + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { r[i] += a[i]; r[4 + i] += b[i]; }
+        }
       }
       if (out_f32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + e0) = f32x4{r[0], r[1], r[2], r[3]};
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256) void ew_train_vec_kernel(const void* __restric
 template <class T>
 static int ew_train_launch(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                            float alpha, float p, unsigned int seed, hipStream_t st) {
-  const bool aligned = (mode <= 4) && (N % 8 == 0) && (((uintptr_t)z | (uintptr_t)g | (uintptr_t)out) % 16 == 0);
+  const bool aligned = (mode <= 6) && (N % 8 == 0) && (((uintptr_t)z | (uintptr_t)g | (uintptr_t)out) % 16 == 0);
   if (!aligned) {
     long long nb = (M * N + 255) / 256;
     if (nb > 16384) nb = 16384;
@@ -333,6 +344,8 @@ static int ew_train_launch(const void* z, const void* g, void* out, long long M,
     case 1: SFM_LAUNCH((ew_train_vec_kernel<T, 1>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
     case 2: SFM_LAUNCH((ew_train_vec_kernel<T, 2>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
     case 3: SFM_LAUNCH((ew_train_vec_kernel<T, 3>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+    case 5: SFM_LAUNCH((ew_train_vec_kernel<T, 5>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
+    case 6: SFM_LAUNCH((ew_train_vec_kernel<T, 6>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
     default: SFM_LAUNCH((ew_train_vec_kernel<T, 4>), grid, block, 0, st, z, g, out, M, N, g_f32, out_f32, alpha, p, seed); break;
   }
   return SFM_OK;

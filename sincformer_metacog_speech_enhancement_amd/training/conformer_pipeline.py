@@ -177,7 +177,8 @@ def compute_path_loss(path, noisy_wav, clean_wav):
     from .. import train
     out = path(noisy_wav, want=("mask", "spectrum"))
     with torch.no_grad():
-        cr, ci = Fn.stft(clean_wav.float().contiguous())
+        # split-bf16 operands on the 16-bit matrix cores (4e-6 relative error): the form the objective's own STFTs use
+        cr, ci = Fn.stft_split16(clean_wav.float().contiguous())
     total, aux, _ = train.EnhancerLossFunction.apply(out["enh_real"], out["enh_imag"], clean_wav, cr, ci, Fn.N_FFT, Fn.HOP, Fn.WIN)
     return total, aux[0]
 
@@ -227,7 +228,7 @@ class EnhancementPath(HipModule):
         T = 1 + L // Fn.HOP
         D = self.perception.encoder_channels if hasattr(self.perception, "encoder_channels") else 256
         with torch.no_grad():
-            nr, ni = Fn.stft(wave)
+            nr, ni = Fn.stft_split16(wave)                   # as the fused inference path: split-bf16 operands, 4e-6 relative error
         if self.__dict__.get("_sfm_pa_frozen", False):
             with torch.no_grad():
                 pa = self.perception._packed(lambda sd: Fn.pack_perception(sd, self.sample_rate))     # frozen: packed once
