@@ -750,6 +750,77 @@ __global__ __launch_bounds__(128) void dwconv_wgrad_kernel(const u16* __restrict
   *reinterpret_cast<f32x2*>(pp + (long long)KS * C) = f32x2{sb0, sb1};
 }
 
+// KS = 31, C % 256 == 0 (the Conformer's depthwise conv): thread = one channel of a 256-channel block; the dy rows and the incoming
+// x rows of a 31-frame chunk go through LDS, the NEXT chunk's 12 x 16-byte loads per thread are in flight while the current
+// one is multiplied (the kernel above prefetches one frame = 12 bytes per thread ahead and waits out a full memory round trip per
+// frame: 0.33 ms per launch at [205 056, 256] against 0.05 ms of FMA issue; tools/train_profile.py).  Same partial layout.
+template <class T>
+__global__ __launch_bounds__(256) void dwconv_wgrad31_lds_kernel(const u16* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ part, int Tlen, int C, int span) {
+  constexpr int KS = 31, pad = 15;
+  __shared__ __attribute__((aligned(16))) float gL[KS][256];
+  __shared__ __attribute__((aligned(16))) u16 xL[KS][256];
+  const int tid = threadIdx.x;
+  const int cb = blockIdx.x * 256, c = cb + tid;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * span, t1 = min(Tlen, t0 + span);
+  const u16* xb = x + (long long)b * Tlen * C + cb;
+  const float* gb = dy + (long long)b * Tlen * C + cb;
+  float acc[KS], w[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    acc[k] = 0.f;
+    const int tt = t0 + k - pad;
+    w[k] = (tt >= 0 && tt < Tlen) ? T::to_f32(xb[(long long)tt * C + tid]) : 0.f;
+  }
+  float sb = 0.f;
+  f32x4 gr[8];
+  u32x4 xr[4];
+  auto fetch = [&](int tb) {       // dy rows tb .. tb + 30 (zero from t1 on), x rows tb + pad + 1 .. tb + pad + 31 (zero outside the utterance)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int p = tid + 256 * q, row = p >> 6, col = (p & 63) * 4, t = tb + row;
+      gr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < KS && t < t1) gr[q] = *reinterpret_cast<const f32x4*>(gb + (long long)t * C + col);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = tid + 256 * q, row = p >> 5, col = (p & 31) * 8, t = tb + pad + 1 + row;
+      xr[q] = u32x4{0u, 0u, 0u, 0u};
+      if (row < KS && t >= 0 && t < Tlen) xr[q] = *reinterpret_cast<const u32x4*>(xb + (long long)t * C + col);
+    }
+  };
+  fetch(t0);
+  for (int tb = t0; tb < t1; tb += KS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int p = tid + 256 * q, row = p >> 6, col = (p & 63) * 4;
+      if (row < KS) *reinterpret_cast<f32x4*>(&gL[row][col]) = gr[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = tid + 256 * q, row = p >> 5, col = (p & 31) * 8;
+      if (row < KS) *reinterpret_cast<u32x4*>(&xL[row][col]) = xr[q];
+    }
+    __syncthreads();
+    if (tb + KS < t1) fetch(tb + KS);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const float g = gL[j][tid];
+      const float xa = T::to_f32(xL[j][tid]);
+      sb += g;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) acc[k] = fmaf(g, w[(j + k) % KS], acc[k]);
+      w[j] = xa;                                             // slot j held x[t - pad]: no longer needed
+    }
+    __syncthreads();
+  }
+  float* pp = part + ((long long)(blockIdx.z * gridDim.y + blockIdx.y) * (KS + 1)) * C + c;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) pp[(long long)k * C] = acc[k];
+  pp[(long long)KS * C] = sb;
+}
+
 // dw[c][k] += sum_parts part[p][k][c] ; db[c] += sum_parts part[p][KS][c]
 __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                   float* __restrict__ db, int nparts, int C, int KS,
@@ -784,10 +855,15 @@ extern "C" int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float
   const int ny = (T + span - 1) / span;
   dim3 grid((C + 255) / 256, ny, B), block(128);
   hipStream_t st = (hipStream_t)stream;
+  if (KS == 31 && C % 256 == 0 && (((uintptr_t)x | (uintptr_t)dy) % 16) == 0) {
+    if (dtype == SFM_DT_F16) SFM_LAUNCH((dwconv_wgrad31_lds_kernel<F16>), grid, dim3(256), 0, st, (const u16*)x, dy, scratch, T, C, span);
+    else SFM_LAUNCH((dwconv_wgrad31_lds_kernel<BF16>), grid, dim3(256), 0, st, (const u16*)x, dy, scratch, T, C, span);
+  } else {
 #define GO(TT, KK) SFM_LAUNCH((dwconv_wgrad_kernel<TT, KK>), grid, block, 0, st, (const u16*)x, dy, scratch, T, C, span)
-  if (dtype == SFM_DT_F16) { if (KS == 31) GO(F16, 31); else GO(F16, 7); }
-  else { if (KS == 31) GO(BF16, 31); else GO(BF16, 7); }
+    if (dtype == SFM_DT_F16) { if (KS == 31) GO(F16, 31); else GO(F16, 7); }
+    else { if (KS == 31) GO(BF16, 31); else GO(BF16, 7); }
 #undef GO
+  }
   const int nparts = B * ny;
   const int ppb = 64;
   dim3 g2(((KS + 1) * C + 255) / 256, (nparts + ppb - 1) / ppb);
