@@ -123,22 +123,25 @@ __global__ __launch_bounds__(LPU * H) void bilstm_layer_kernel(const float* __re
 // published through LDS, written to dxg (= gradient w.r.t. the input projection, from which dW_ih, db, dx and dW_hh are
 // GEMMs afterwards) and every thread multiplies its 4 x H/8 slice of W_hh^T into the next step's recurrent dh.
 // ---------------------------------------------------------------------------
-template <int H>
-__global__ __launch_bounds__(8 * H) void bilstm_layer_bwd_kernel(const float* __restrict__ save,
+// LPU lanes per hidden unit (as the forward kernel): 8 = 16 waves at H 128, 64 multiply-adds per lane and step; 4 = 8 waves, 128
+// multiply-adds in two chains, one DPP stage fewer - the per-wave cost of the gate-gradient section (8 or 16 active lanes) is
+// paid by half as many waves.
+template <int H, int LPU>
+__global__ __launch_bounds__(LPU * H) void bilstm_layer_bwd_kernel(const float* __restrict__ save,
                                                                  const float* __restrict__ whh,
                                                                  const float* __restrict__ dout,
                                                                  float* __restrict__ dxg, int T) {
   constexpr int G4 = 4 * H;                                   // contraction length of W_hh^T
-  constexpr int KS = G4 / 8;                                  // slice per lane
+  constexpr int KS = G4 / LPU;                                // slice per lane
   constexpr int SL = KS + 4;
-  __shared__ __attribute__((aligned(16))) float das[2][8 * SL];
+  __shared__ __attribute__((aligned(16))) float das[2][LPU * SL];
   const int tid = threadIdx.x;
-  const int j = tid >> 3, ks = tid & 7;
+  const int j = tid / LPU, ks = tid % LPU;
   const int dir = blockIdx.x, b = blockIdx.y;
   float w[KS];                                                // W_hh[r, j] for r in this lane's slice of the 4H gate rows
 #pragma unroll
   for (int i = 0; i < KS; ++i) w[i] = whh[((long long)dir * G4 + ks * KS + i) * H + j];
-  if (tid < 8 * SL) { das[0][tid] = 0.f; das[1][tid] = 0.f; }
+  for (int i = tid; i < LPU * SL; i += LPU * H) { das[0][i] = 0.f; das[1][i] = 0.f; }
   __syncthreads();
   const long long cb = (long long)b * T;
   float dh_rec = 0.f, dc_next = 0.f;
@@ -177,18 +180,24 @@ __global__ __launch_bounds__(8 * H) void bilstm_layer_bwd_kernel(const float* __
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float* dc_ = das[s & 1] + ks * SL;
-    float a = 0.f;
+    float a = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < KS; i += 4) {
+    for (int i = 0; i < KS; i += 8) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(dc_ + i);
+      const f32x4 u = *reinterpret_cast<const f32x4*>(dc_ + i + 4);
       a += w[i] * v[0];
+      a2 += w[i + 4] * u[0];
       a += w[i + 1] * v[1];
+      a2 += w[i + 5] * u[1];
       a += w[i + 2] * v[2];
+      a2 += w[i + 6] * u[2];
       a += w[i + 3] * v[3];
+      a2 += w[i + 7] * u[3];
     }
+    a += a2;
     a = dpp_add<DPP_XOR1>(a);
     a = dpp_add<DPP_XOR2>(a);
-    a = dpp_add<DPP_HALF_MIRROR>(a);
+    if (LPU == 8) a = dpp_add<DPP_HALF_MIRROR>(a);
     dh_rec = a;                                                // every lane of the unit holds it; lane 0 uses it
   }
 }
@@ -224,9 +233,11 @@ extern "C" int sfm_bilstm_layer_bwd(const float* save, const float* whh, const f
   if (!save || !whh || !dout || !dxg) return SFM_ERR_ARG;
   if (B <= 0 || T <= 0) return SFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (H == 128) SFM_LAUNCH((bilstm_layer_bwd_kernel<128>), dim3(2, B), dim3(1024), 0, st, save, whh, dout, dxg, T);
-  else if (H == 64) SFM_LAUNCH((bilstm_layer_bwd_kernel<64>), dim3(2, B), dim3(512), 0, st, save, whh, dout, dxg, T);
-  else if (H == 32) SFM_LAUNCH((bilstm_layer_bwd_kernel<32>), dim3(2, B), dim3(256), 0, st, save, whh, dout, dxg, T);
+  static const int lpu = getenv("SFM_LSTM_BWD_LPU") ? atoi(getenv("SFM_LSTM_BWD_LPU")) : 4;    // A/B knob (tools/lstm_bench.py)
+  if (H == 128 && lpu == 4) SFM_LAUNCH((bilstm_layer_bwd_kernel<128, 4>), dim3(2, B), dim3(512), 0, st, save, whh, dout, dxg, T);
+  else if (H == 128) SFM_LAUNCH((bilstm_layer_bwd_kernel<128, 8>), dim3(2, B), dim3(1024), 0, st, save, whh, dout, dxg, T);
+  else if (H == 64) SFM_LAUNCH((bilstm_layer_bwd_kernel<64, 8>), dim3(2, B), dim3(512), 0, st, save, whh, dout, dxg, T);
+  else if (H == 32) SFM_LAUNCH((bilstm_layer_bwd_kernel<32, 8>), dim3(2, B), dim3(256), 0, st, save, whh, dout, dxg, T);
   else return SFM_ERR_SHAPE;
   return SFM_OK;
 }
