@@ -342,6 +342,11 @@ int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
 int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
                          float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
                          void* stream);
+/* the same, also writing next16 [M, D] (format `dtype`, contiguous rows) = next_alpha * dropout(dx; next_p, next_seed) with the
+ * counters of sfm_ew_train mode 4: the 16-bit operand the next backward node of the residual chain starts from */
+int sfm_layernorm_bwd_next(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
+                           float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
+                           void* next16, float next_alpha, float next_p, unsigned int next_seed, void* stream);
 /* mode 0 swish fwd, 1 swish bwd, 2 GLU fwd, 3 GLU bwd, 4 alpha*g*dropout; counter-based dropout (p, seed) */
 int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                  float alpha, float p, unsigned int seed, int dtype, void* stream);

@@ -16,8 +16,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const void* __restrict__ dyv, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int M, int D, int ldx, int ldy, int ld,
-                                                            float eps) {
+                                                            float eps, u16* __restrict__ nxt, float nalpha, float np_,
+                                                            uint32_t nseed, int nfmt) {
+  // nxt (optional): the 16-bit operand the NEXT backward node starts from, nalpha * dropout(dx; np_, nseed) as [M, D] contiguous
+  // rows (counter m * D + d, the one sfm_ew_train mode 4 uses) - that node's own pass over dx (read 4 B + write 2 B per
+  // element, 24 launches per training step) is folded into this store.  nfmt: 1 bf16, 2 fp16.
   constexpr int NI = 4 * NH;
+  const float nik = (np_ > 0.f) ? 1.0f / (1.0f - np_) : 1.0f;
+  const uint32_t nthr = sfm_keep_threshold(np_);
   __shared__ float red[4][2][256 * NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // VEC: lane owns columns 4*lane..4*lane+3 of each 256-column half (16-byte loads); else column lane + 64*i
@@ -109,13 +115,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
               for (int j = 0; j < 4; ++j) o[j] = rstd * (g[r][4 * h + j] - a - v[r][4 * h + j] * bsum) + dr[r][4 * h + j];
               *reinterpret_cast<f32x4*>(dx + (long long)row * ld + d) = o;
+              if (nxt) {
+                const unsigned long long e0 = (unsigned long long)row * D + d;      // d % 4 == 0: the four share one 8-element group
+                float q[4];
+                if (np_ > 0.f) {
+                  const uint32_t gh = sfm_hash(nseed, e0 >> 3);
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) q[j] = nalpha * o[j] * sfm_keep_from_group(gh, (uint32_t)(e0 & 7ull) + j, nthr, nik);
+                } else {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) q[j] = nalpha * o[j];
+                }
+                u32x2 pk;
+                if (nfmt == 2) { pk[0] = F16::pack(q[0], q[1]); pk[1] = F16::pack(q[2], q[3]); }
+                else { pk[0] = BF16::pack(q[0], q[1]); pk[1] = BF16::pack(q[2], q[3]); }
+                *reinterpret_cast<u32x2*>(nxt + e0) = pk;
+              }
             }
           }
         } else {
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
             const int d = LN_COL(i);
-            if (d < D) dx[(long long)row * ld + d] = rstd * (g[r][i] - a - v[r][i] * bsum) + dr[r][i];
+            if (d < D) {
+              const float o = rstd * (g[r][i] - a - v[r][i] * bsum) + dr[r][i];
+              dx[(long long)row * ld + d] = o;
+              if (nxt) {
+                const unsigned long long e = (unsigned long long)row * D + d;
+                const float q = nalpha * o * (np_ > 0.f ? sfm_keep_scale(nseed, e, np_, nik) : 1.0f);
+                nxt[e] = (nfmt == 2) ? F16::from_f32(q) : BF16::from_f32(q);
+              }
+            }
           }
         }
       }
@@ -135,11 +165,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #undef LN_COL
 
 // dy_16: 0 = dy fp32, 1 = dy in the 16-bit format `dtype`; ldy = row stride of dy (elements), ld = row stride of dres and dx
-extern "C" int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
-                                    float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
-                                    void* stream) {
+static int layernorm_bwd_go(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
+                            float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
+                            void* next16, float next_alpha, float next_p, unsigned int next_seed, void* stream) {
   if (!x || !gamma || !dy || !dx || !dgamma || !dbeta) return SFM_ERR_ARG;
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
+  if (next16 && (next_p < 0.f || next_p >= 1.f || ((uintptr_t)next16 % 8) != 0)) return SFM_ERR_SHAPE;
+  u16* nxt = (u16*)next16;
+  const int nfmt = dtype == SFM_DT_F16 ? 2 : 1;
   constexpr int LNB_R = 2;
   int nb = (M + 4 * LNB_R - 1) / (4 * LNB_R);
   if (nb > 1024) nb = 1024;                                  // 1024 x 512 contended atomics at the end: measured best of 512..4096
@@ -148,13 +181,29 @@ extern "C" int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const vo
                    ((((uintptr_t)x | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0) && (((uintptr_t)dy) % (4 * dyb)) == 0;
   const int f = dy_16 ? (dtype == SFM_DT_F16 ? 2 : 1) : 0;
   hipStream_t st = (hipStream_t)stream;
-#define LNB_GO2(V, F, H) SFM_LAUNCH((layernorm_bwd_kernel<V, F, H, LNB_R>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps)
+#define LNB_GO2(V, F, H) SFM_LAUNCH((layernorm_bwd_kernel<V, F, H, LNB_R>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, nxt, next_alpha, next_p, next_seed, nfmt)
 #define LNB_GO(V, F) do { if (D <= 256) LNB_GO2(V, F, 1); else LNB_GO2(V, F, 2); } while (0)
   if (vec) { if (f == 0) LNB_GO(true, 0); else if (f == 1) LNB_GO(true, 1); else LNB_GO(true, 2); }
   else { if (f == 0) LNB_GO(false, 0); else if (f == 1) LNB_GO(false, 1); else LNB_GO(false, 2); }
 #undef LNB_GO
 #undef LNB_GO2
   return SFM_OK;
+}
+
+extern "C" int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
+                                    float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
+                                    void* stream) {
+  return layernorm_bwd_go(x, gamma, dy, dy_16, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, dtype, nullptr, 1.f, 0.f, 0u, stream);
+}
+
+// the same, also writing next16 [M, D] (16-bit format `dtype`, contiguous) = next_alpha * dropout(dx; next_p, next_seed) with the
+// counters of sfm_ew_train mode 4 (m * D + d): the operand the next backward node of a residual chain starts from
+extern "C" int sfm_layernorm_bwd_next(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
+                                      float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
+                                      void* next16, float next_alpha, float next_p, unsigned int next_seed, void* stream) {
+  if (!next16) return SFM_ERR_ARG;
+  return layernorm_bwd_go(x, gamma, dy, dy_16, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, dtype, next16, next_alpha, next_p,
+                          next_seed, stream);
 }
 
 extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,

@@ -100,6 +100,8 @@ SIGNATURES = {
     "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
     "sfm_layernorm_bwd_ex": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp],
+    "sfm_layernorm_bwd_next": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_f, c_f,
+                               ctypes.c_uint, c_vp],
     "sfm_ew_train": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_uint, c_i, c_vp],
     "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "sfm_add_cols": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_ll, c_vp],

@@ -967,14 +967,23 @@ def colsum(G, out):
     _call("colsum", L.sfm_colsum, (_p(G), _p(out), M, N, G.stride(0), 1 if G.dtype == torch.float32 else 0, _dt(), _stream()))
 
 
-def layernorm_bwd(x32, gamma, dy, dres32, dgamma, dbeta, eps=1e-5):
-    """dy: fp32, or the 16-bit result of the GEMM that produced it (its own row stride); dres / dx fp32 [M, D]"""
+def layernorm_bwd(x32, gamma, dy, dres32, dgamma, dbeta, eps=1e-5, next_drop=None):
+    """dy: fp32, or the 16-bit result of the GEMM that produced it (its own row stride); dres / dx fp32 [M, D].
+    next_drop = (alpha, p, seed): also returns alpha * dropout(dx; p, seed) [M, D] in the 16-bit compute format, the operand the
+    next backward node of the residual chain starts from (same counters as ew_train(EW_SCALE_DROP)) -> (dx, next16)."""
     L = _lib.load()
     M, D = dy.shape
     dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
     dy16 = 0 if dy.dtype == torch.float32 else 1
     if dy16 and dy.dtype != _state["dtype"]:
         raise RuntimeError("layernorm_bwd: a 16-bit dy must be in the compute format")
+    if next_drop is not None:
+        alpha, p, seed = next_drop
+        nxt = torch.empty(M, D, device=dy.device, dtype=_state["dtype"])
+        _call("layernorm_bwd", L.sfm_layernorm_bwd_next, (_p(x32), _p(gamma), _p(dy), dy16, _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
+                                                          x32.stride(0), dy.stride(0), D, eps, _dt(), _p(nxt), float(alpha), float(p),
+                                                          int(seed) & 0xffffffff, _stream()))
+        return dx, nxt
     _call("layernorm_bwd", L.sfm_layernorm_bwd_ex, (_p(x32), _p(gamma), _p(dy), dy16, _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
                                                     x32.stride(0), dy.stride(0), D, eps, _dt(), _stream()))
     return dx

@@ -85,12 +85,30 @@ def _ffn_fwd(x, P, pre, p, seeds):
     return y, dict(x=x, lw=lw, h16=h16, z1=z1, u=u, b1=b1, b2=b2, s1=s1, s2=s2, p=p)
 
 
-def _ffn_bwd(dy, c, G, pre):
+FUSE_NEXT_DROP = os.environ.get("SFM_FUSE_NEXT_DROP", "1") != "0"     # A/B knob: the LayerNorm backward also writes the next node's 16-bit operand
+
+
+def _branch_grad(dy, do, alpha, p, seed):
+    """alpha * dropout(dy) in the compute format: handed over by the previous node's LayerNorm backward (`do`), or one pass over dy"""
+    if do is not None:
+        return do
+    do = torch.empty(dy.shape, device=dy.device, dtype=ops.compute_dtype())
+    ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=alpha, p=p, seed=seed)
+    return do
+
+
+def _ln_bwd_chain(x, lw, dh, dy, gw, gb, nxt):
+    """LayerNorm backward at the end of a module's backward; nxt = (alpha, p, seed) of the NEXT node's branch dropout -> (dx, do16)"""
+    if nxt is not None and FUSE_NEXT_DROP:
+        return ops.layernorm_bwd(x, lw, dh, dy, gw, gb, next_drop=nxt)
+    return ops.layernorm_bwd(x, lw, dh, dy, gw, gb), None
+
+
+def _ffn_bwd(dy, c, G, pre, do=None, nxt=None):
     dt = ops.compute_dtype()
     M, D = dy.shape
     FF = c["z1"].shape[1]
-    do = torch.empty(M, D, device=dy.device, dtype=dt)
-    ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=0.5, p=c["p"], seed=c["s2"])
+    do = _branch_grad(dy, do, 0.5, c["p"], c["s2"])
     # input gradient first, weight gradient second: the K = 1024 weight-gradient GEMM launched right behind the streaming
     # ew_train ran 0.28 ms against 0.21 ms behind a GEMM (tools/ffn_bwd_probe.py --variant late; profiles/README.md, round 3)
     if FUSE_FFN_SWISH and FF % 8 == 0:
@@ -102,7 +120,7 @@ def _ffn_bwd(dy, c, G, pre):
     ops.gemm16_tn(do, c["u"], G[pre + "linear2.weight"], G[pre + "linear2.bias"])
     ops.gemm16_tn(dz, c["h16"], G[pre + "linear1.weight"], G[pre + "linear1.bias"])
     dh = ops.linear16(dz, c["b1"])                                          # [M, D] 16-bit: read once, by the LayerNorm backward
-    return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G[pre + "layer_norm.weight"], G[pre + "layer_norm.bias"])
+    return _ln_bwd_chain(c["x"], c["lw"], dh, dy, G[pre + "layer_norm.weight"], G[pre + "layer_norm.bias"], nxt)
 
 
 # ---------------------------------------------------------------------------
@@ -126,11 +144,10 @@ def _mhsa_fwd(x, P, B, T, H, p, seeds):
     return y, dict(x=x, lw=lw, h16=h16, qkv=qkv, O=O, lse=lse, bin=bin_, bout=bout, sa=sa, sd=sd, p=p, qs=qs, B=B, T=T, H=H)
 
 
-def _mhsa_bwd(dy, c, G):
+def _mhsa_bwd(dy, c, G, do=None, nxt=None):
     dt = ops.compute_dtype()
     M, D = dy.shape
-    do = torch.empty(M, D, device=dy.device, dtype=dt)
-    ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=1.0, p=c["p"], seed=c["sd"])
+    do = _branch_grad(dy, do, 1.0, c["p"], c["sd"])
     ops.gemm16_tn(do, c["O"], G["mhsa.attention.out_proj.weight"], G["mhsa.attention.out_proj.bias"])
     dO = ops.linear16(do, c["bout"])                                         # 16-bit [M, D]
     dqkv = ops.attention_bwd(c["qkv"], c["O"], dO, c["lse"], c["B"], c["T"], c["H"], D // c["H"], p_drop=c["p"], seed=c["sa"])
@@ -145,7 +162,7 @@ def _mhsa_bwd(dy, c, G):
         gw += tw
         gb += tb
     dh = ops.linear16(dqkv, c["bin"])
-    return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G["mhsa.layer_norm.weight"], G["mhsa.layer_norm.bias"])
+    return _ln_bwd_chain(c["x"], c["lw"], dh, dy, G["mhsa.layer_norm.weight"], G["mhsa.layer_norm.bias"], nxt)
 
 
 # ---------------------------------------------------------------------------
@@ -188,12 +205,11 @@ def _conv_fwd(x, P, B, T, p, seeds, bn_buffers, momentum=0.1, eps=1e-5, bn_eval=
                    wdw=wdw, KS=KS, sd=sd, p=p, B=B, T=T, bn_eval=bn_eval)
 
 
-def _conv_bwd(dy, c, G):
+def _conv_bwd(dy, c, G, do=None, nxt=None):
     dt = ops.compute_dtype()
     M, D = dy.shape
     B, T, KS = c["B"], c["T"], c["KS"]
-    do = torch.empty(M, D, device=dy.device, dtype=dt)
-    ops.ew_train(ops.EW_SCALE_DROP, do, g=dy, alpha=1.0, p=c["p"], seed=c["sd"])
+    do = _branch_grad(dy, do, 1.0, c["p"], c["sd"])
     ops.gemm16_tn(do, c["s16"], G["conv.pointwise2.weight"].view(D, D), G["conv.pointwise2.bias"])
     ds = ops.linear16(do, c["b2"], out_dtype=torch.float32)
     dyc, dgam, dbet = ops.bn_swish_bwd(ds, c["yc"], c["mean"], c["rstd"], c["gam"], c["bet"], eval_mode=c["bn_eval"])
@@ -212,7 +228,7 @@ def _conv_bwd(dy, c, G):
     ops.ew_train(ops.EW_GLU_BWD, dpre, z=c["pre"], g=dg, N=D)
     ops.gemm16_tn(dpre, c["h16"], G["conv.pointwise1.weight"].view(2 * D, D), G["conv.pointwise1.bias"])
     dh = ops.linear16(dpre, c["b1"])
-    return ops.layernorm_bwd(c["x"], c["lw"], dh, dy, G["conv.layer_norm.weight"], G["conv.layer_norm.bias"])
+    return _ln_bwd_chain(c["x"], c["lw"], dh, dy, G["conv.layer_norm.weight"], G["conv.layer_norm.bias"], nxt)
 
 
 # ---------------------------------------------------------------------------
@@ -246,11 +262,13 @@ def block_train_backward(dy32, ctx, P):
     # the block's weight-gradient GEMMs overlap its input-gradient chain on a second stream (B 256 x T 801: -1 ms of 51.6 per
     # step; at B 64 the extra events cost more than the overlap returns)
     with ops.wgrad_side_stream(enabled=dy32.shape[0] >= 100000):
-        d4 = ops.layernorm_bwd(ctx["x4"], ctx["fw"], dy32, None, G["final_norm.weight"], G["final_norm.bias"])
-        d3 = _ffn_bwd(d4, ctx["c4"], G, "ff2.")
-        d2 = _conv_bwd(d3, ctx["c3"], G)
-        d1 = _mhsa_bwd(d2, ctx["c2"], G)
-        dx = _ffn_bwd(d1, ctx["c1"], G, "ff1.")
+        # every LayerNorm backward of the chain also writes the 16-bit alpha * dropout(dx) the NEXT module's backward starts from
+        c1, c2, c3, c4 = ctx["c1"], ctx["c2"], ctx["c3"], ctx["c4"]
+        d4, o4 = _ln_bwd_chain(ctx["x4"], ctx["fw"], dy32, None, G["final_norm.weight"], G["final_norm.bias"], (0.5, c4["p"], c4["s2"]))
+        d3, o3 = _ffn_bwd(d4, c4, G, "ff2.", do=o4, nxt=(1.0, c3["p"], c3["sd"]))
+        d2, o2 = _conv_bwd(d3, c3, G, do=o3, nxt=(1.0, c2["p"], c2["sd"]))
+        d1, o1 = _mhsa_bwd(d2, c2, G, do=o2, nxt=(0.5, c1["p"], c1["s2"]))
+        dx, _ = _ffn_bwd(d1, c1, G, "ff1.", do=o1)
     return dx, G
 
 
@@ -664,11 +682,11 @@ class SubmoduleFunction(torch.autograd.Function):
         G = _zero_grads({prefix + n: ctx.P[prefix + n].shape for n in names}, dy.device)
         d = dy.detach().float().reshape(B * T, D).contiguous()
         if ctx.kind == "ffn":
-            dx = _ffn_bwd(d, ctx.saved, G, prefix)
+            dx, _ = _ffn_bwd(d, ctx.saved, G, prefix)
         elif ctx.kind == "mhsa":
-            dx = _mhsa_bwd(d, ctx.saved, G)
+            dx, _ = _mhsa_bwd(d, ctx.saved, G)
         else:
-            dx = _conv_bwd(d, ctx.saved, G)
+            dx, _ = _conv_bwd(d, ctx.saved, G)
         grads = [G[prefix + n].to(t) for n, t in zip(names, ctx.param_dtypes)]
         ctx.saved = None
         return (dx.reshape(B, T, D).to(ctx.in_dtype), None) + tuple(grads)

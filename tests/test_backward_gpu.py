@@ -68,6 +68,34 @@ def test_layernorm_bwd(ops, M, D):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,D,p", [(203, 256, 0.1), (64, 256, 0.0), (77, 144, 0.15), (50, 130, 0.1)])
+def test_layernorm_bwd_also_writes_the_next_nodes_operand(ops, dt, M, D, p):
+    """next_drop = (alpha, p, seed): the second output equals ew_train(EW_SCALE_DROP) of the returned dx BIT FOR BIT (same
+    counters m * D + d, same order of the two multiplications) on the vector paths (D 256; D 144 with a ragged second half), to a
+    rounding midpoint on the scalar path (D 130) - and dx / dgamma / dbeta are what the call without it returns"""
+    ops.set_compute_dtype(dt)
+    x, w = arr("nx", (M, D), 31, 2.0).cuda(), (arr("nw", (D,), 32) * 0.1 + 1).cuda()
+    dy, dres = arr("ndy", (M, D), 33).cuda(), arr("ndr", (M, D), 34).cuda()
+    g0, b0 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    g1, b1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx0 = ops.layernorm_bwd(x, w, dy, dres, g0, b0)
+    dx1, nxt = ops.layernorm_bwd(x, w, dy, dres, g1, b1, next_drop=(0.5, p, 12345))
+    assert torch.equal(dx0, dx1)
+    assert maxerr(g0.cpu(), g1.cpu()) < 1e-4 * float(g0.abs().max()) and maxerr(b0.cpu(), b1.cpu()) < 1e-4 * float(b0.abs().max() + 1)
+    want = torch.empty(M, D, device="cuda", dtype=dt)
+    ops.ew_train(ops.EW_SCALE_DROP, want, g=dx0, alpha=0.5, p=p, seed=12345)
+    assert nxt.dtype == dt
+    if D % 4 == 0:
+        assert torch.equal(nxt, want)                                  # the paths the training step takes
+    else:
+        # scalar path: one element of 6500 at an exact rounding midpoint came out one fp16 ulp apart
+        bad = nxt.float() != want.float()
+        assert int(bad.sum()) <= 2 and maxerr(nxt.float().cpu(), want.float().cpu()) < 1e-3
+    if p > 0:
+        assert 0.5 * p < float((nxt == 0).float().mean()) < 1.5 * p + 0.02
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_elementwise_train(ops, dt):
     ops.set_compute_dtype(dt)
     M, N = 200, 256
