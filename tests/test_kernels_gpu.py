@@ -516,6 +516,10 @@ def test_layout_kernels(ops):
     d2 = torch.full((50, 100), 7.0, device="cuda", dtype=torch.float16)
     ops.convert_rows(dev(src), d2, 50, 64, 80, 64, 100)
     assert maxerr(d2[:, :64].float().cpu(), src) < 2e-3 and float(d2[:, 64:80].abs().max()) == 0 and float(d2[0, 80]) == 7.0
+    # the 8-columns-per-thread form (16-byte aligned rows on both sides): same result, padding columns zero, beyond them untouched
+    d3 = torch.full((50, 104), 7.0, device="cuda", dtype=torch.float16)
+    ops.convert_rows(dev(src), d3, 50, 64, 80, 64, 104)
+    assert torch.equal(d3[:, :80], d2[:, :80]) and float(d3[0, 80]) == 7.0 and float(d3[49, 103]) == 7.0
     zz = arr("pz", (B, 100, 512), 72)
     p16 = torch.empty(B, 21, 512, device="cuda", dtype=torch.float16)
     p32 = torch.empty(B, 21, 512, device="cuda")
