@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X (contract: see the round prompt / DESIGN.md section 7).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3p|c1|c5|c3se|c2t|c3t] [--dtype mixed|bf16|f16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3p|c2|c1|c5|c3se|c2t|c3t] [--dtype mixed|bf16|f16]
                     [--streams S]
 
 A step = one forward pass of the north-star path (PerceptionAgent -> pool -> CPEA -> STFT -> MaskSynthesisAgent ->
-apply_mask -> iSTFT) over one batch of synthetic 16 kHz utterances that is already resident in HBM.  Default workload =
-BASELINE.json configs[1]: batch 64 x 4 s (L = 64 000, T = 801 STFT frames / utterance), forward only, 16-bit MFMA operands
-(default policy "mixed": fp16 GEMM operands, bf16 attention core) with fp32 accumulation.
-value = STFT frames/s over all ranks (utterances shard over ranks: no data-path collective).
+apply_mask -> iSTFT) over one batch of synthetic 16 kHz utterances that is already resident in HBM.  Default workload = the
+shape BASELINE.json's metric is quoted on ("512-frame utts", target shape "batch 256 x 512-frame utterances"): c3p = batch
+256 x 512 STFT frames (L = 40 880), forward, 16-bit MFMA operands (default policy "mixed": fp16 GEMM operands, bf16
+attention core) with fp32 accumulation.  value = STFT frames/s over all ranks (utterances shard over ranks: no data-path
+collective).  The default N = 1 line also carries, as sub-records measured after the timed region:
+  `configs1`  BASELINE configs[1] (B 64 x 4 s, T 801) through the same path: ms per step, frames/s, dominant kernel + roofline,
+              the attention kernel inside that pass
+  `train`     BASELINE configs[2] on the north-star composition (c3t: B 256 x 4 s, forward + objective + backward through
+              every module + clip + AdamW, fp16 operands under the device-side dynamic loss scale): ms per step, frames/s,
+              dominant family + roofline, final loss, skipped steps (0 in the timed steps)
+  `headline`  the attention kernel ALONE at B 256 x T 512 x 4 heads x 64, bf16 (north_star's >= 30 % of bf16 MFMA peak)
+  `sustained`, `mask_rmse`, `cpu_baseline` (the oracle on the host cores, bounded sample, N = 1 only).
 
 Launching: `python bench.py --gpus N` with no torchrun environment starts the N ranks itself (child processes, before this
 process touches the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the
 launcher's.  A --gpus that disagrees with WORLD_SIZE is an error.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel family, HIP-event timed inside the timed region, plus the same
-launches in strictly sequential passes), `mask_rmse` (one utterance against the CPU oracle, outside the timed region),
-`headline` (BASELINE's metric shape: batch 256 x 512-frame utterances, and the attention kernel alone at that shape) and
-`cpu_baseline` (the oracle on the host cores, bounded sample, N = 1 only).
+`roofline`: the dominant kernel family, HIP-event timed per launch inside the timed region.  The roof is chosen PER LAUNCH
+from its arithmetic intensity (algorithmic FLOPs / algorithmic bytes against the ridge of the pipe it runs on): a K = 256
+linear of the GEMM family is HBM-bound, a K = 1024 one MFMA-bound; the family's `bound` is the class that takes most of its
+time and achieved / peak / frac are over the launches of that class (`roofline_time_frac` covers all of them).
 """
 import argparse
 import json
@@ -47,14 +55,19 @@ WORKLOADS = {
     "c5": (32, 480000, "B32 x 30 s (L480000, T6001) forward with episodic memory (BASELINE configs[4], fwd)"),
 }
 TRAIN_WORKLOADS = ("c3se", "c2t", "c3t")
-PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "hbm": 8000.0}      # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
-FAMILY_BOUND = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32", "gemm16_tn": "mfma16",
-                "attention_bwd": "mfma16", "conv16": "mfma16", "ffn_fused": "mfma16"}
+PEAKS = {"mfma16": 2500.0, "mfma32": 157.3, "valu32": 157.3, "hbm": 8000.0}   # TFLOP/s x3, GB/s (MI355X_MICROARCH.md)
+# the pipe a family's FLOPs run on (everything else: fp32 vector ALU); WHICH roof binds a launch - that pipe or HBM - is
+# decided per launch from its arithmetic intensity (roofline_of), not per family
+FAMILY_PIPE = {"gemm16": "mfma16", "attention_fwd": "mfma16", "framed_gemm_f32": "mfma32", "gemm16_tn": "mfma16",
+               "attention_bwd": "mfma16", "conv16": "mfma16", "conv16p": "mfma16", "ffn_fused": "mfma16", "sinc_fir16": "mfma16",
+               "framed_gemm_split16": "mfma16", "conv_dgrad16": "mfma16", "conv_wgrad16": "mfma16"}
 METRIC = "audio frames/sec/GPU (16 kHz, 512-frame utts) + mask RMSE vs CPU ref"
 DTYPE_DESC = {
     "mixed": "fp16 MFMA operands (PerceptionAgent, fusion, Conformer GEMMs, heads) + bf16 attention core, fp32 accumulate "
              "(ops.POLICIES['mixed'])",
     "bf16": "bf16", "f16": "fp16",
+    "amp16": "fp16 MFMA operands, fp32 accumulate, dynamic loss scale on the device (optim.DynamicLossScale = the reference's "
+             "fp16 autocast + GradScaler recipe, training/conformer_pipeline.py:442,504,512-517)",
 }
 
 
@@ -226,23 +239,60 @@ def init_ranks(args):
     return rank, world
 
 
-def roofline_of(dominant, dom, traffic_src=None):
-    kind = FAMILY_BOUND.get(dominant, "hbm")
-    secs = dom["ms_avg"] * 1e-3
-    if kind == "hbm":
-        ach, peak, unit, bound = dom["bytes"] / dom["n"] / secs / 1e9, PEAKS["hbm"], "GB/s", "hbm"
+def roofline_of(family, launches, traffic_src=None):
+    """launches: [(ms, algorithmic flops, algorithmic bytes)] of one kernel family, HIP-event timed.  The roof is chosen per
+    LAUNCH: t_mfma = flops / peak of the pipe the family's arithmetic runs on, t_hbm = bytes / 8 TB/s, the larger one binds
+    (= arithmetic intensity against the ridge).  `bound` = the class whose launches take most of the family's time;
+    achieved / peak / frac / launches / avg_ms are over the launches of THAT class; `roofline_time_frac` = sum of the per-launch
+    roofline times over the sum of the measured times, all launches."""
+    pipe = FAMILY_PIPE.get(family, "valu32")
+    cls = {"hbm": [], "mfma": []}
+    t_roof = 0.0
+    for ms, fl, by in launches:
+        tf, tb = fl / (PEAKS[pipe] * 1e12), by / (PEAKS["hbm"] * 1e9)
+        k = "mfma" if (pipe != "valu32" and tf > tb) else "hbm"
+        cls[k].append((ms, fl, by))
+        t_roof += max(tf, tb) if pipe != "valu32" else tb
+    total_ms = sum(l[0] for l in launches)
+    bound = max(cls, key=lambda k: sum(l[0] for l in cls[k]))
+    sel = cls[bound]
+    secs = sum(l[0] for l in sel) * 1e-3
+    if bound == "hbm":
+        ach, peak, unit = sum(l[2] for l in sel) / secs / 1e9, PEAKS["hbm"], "GB/s"
     else:
-        ach, peak, unit, bound = dom["flops"] / dom["n"] / secs / 1e12, PEAKS[kind], "TFLOP/s", "mfma"
-    r = {"bound": bound, "kernel": dominant, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-         "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
-         "algorithmic_flops_per_launch": dom["flops"] / dom["n"], "launches": dom["n"], "avg_ms": dom["ms_avg"]}
+        ach, peak, unit = sum(l[1] for l in sel) / secs / 1e12, PEAKS[pipe], "TFLOP/s"
+    n = len(sel)
+    r = {"bound": bound, "kernel": family, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+         "algorithmic_bytes_per_launch": sum(l[2] for l in sel) / n, "algorithmic_flops_per_launch": sum(l[1] for l in sel) / n,
+         "launches": n, "avg_ms": secs * 1e3 / n,
+         "roof_choice": "per launch: max(flops / %s peak, bytes / HBM peak)" % pipe,
+         "roofline_time_frac": t_roof * 1e3 / total_ms if total_ms > 0 else None, "family_launches": len(launches),
+         "family_ms": total_ms}
+    other = "mfma" if bound == "hbm" else "hbm"
+    if cls[other]:
+        o = cls[other]
+        osec = sum(l[0] for l in o) * 1e-3
+        if other == "hbm":
+            oa, op, ou = sum(l[2] for l in o) / osec / 1e9, PEAKS["hbm"], "GB/s"
+        else:
+            oa, op, ou = sum(l[1] for l in o) / osec / 1e12, PEAKS[pipe], "TFLOP/s"
+        r["other_bound"] = {"bound": other, "launches": len(o), "ms": osec * 1e3, "achieved": oa, "peak": op, "unit": ou, "frac": oa / op}
     if traffic_src and os.path.exists(os.path.join(ROOT, traffic_src)):
-        t = json.load(open(os.path.join(ROOT, traffic_src))).get(dominant, {}).get("hbm_bytes_per_launch")
+        t = json.load(open(os.path.join(ROOT, traffic_src))).get(family, {}).get("hbm_bytes_per_launch")
         if t is not None:
             r.update({"traffic": t, "traffic_unit": "HBM bytes/launch",
                       "traffic_source": "NOT measured in this run: read from %s = committed rocprofv3 --pmc FETCH_SIZE / "
                                         "WRITE_SIZE passes of this command (FETCH_SIZE doubled per the gfx950 note)" % traffic_src})
     return r
+
+
+def refuse_variant_overrides():
+    """the kernel-selection knobs (ops.set_gemm_variant / set_attention_variant / SFM_GEMM_VARIANT) are A/B test tools: nothing
+    is timed while one is away from its default"""
+    from sincformer_metacog_speech_enhancement_amd import ops
+    ov = ops.variant_overrides()
+    if ov:
+        raise SystemExit("bench.py: kernel variant override active %r - refusing to time anything" % (ov,))
 
 
 def traffic_file(workload):
@@ -257,14 +307,26 @@ def traffic_file(workload):
 # ---------------------------------------------------------------------------------------------------------------
 # training workloads
 # ---------------------------------------------------------------------------------------------------------------
+def train_dtype(args):
+    """operand recipe of the training workloads: the default ("mixed") is the reference's AMP recipe - fp16 operands (ops'
+    default training format) under the device-side dynamic loss scale; --dtype bf16 / f16 force one format WITHOUT a loss scale
+    (diagnostics)."""
+    return "amp16" if args.dtype == "mixed" else args.dtype
+
+
 def build_train_step(workload, dtype, rank, batch=0):
     """model + flat optimiser (+ gradient synchroniser over the default process group) + synthetic shard of one training
-    workload; returns (step, opt, sd, B, L, T, desc, whole_path)."""
+    workload; returns (step, opt, scaler, sd, B, L, T, desc, whole_path)."""
     import torch
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
-    from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW
+    from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW, DynamicLossScale
     from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import SpeechEnhancer, batch_stft, compute_loss
-    ops.set_compute_dtype(dtype)
+    if dtype == "amp16":
+        ops.reset_precision()                                       # base (training) format fp16
+        scaler = DynamicLossScale("cuda")                           # GradScaler defaults: S = 65536, x0.5 / x2 every 2000
+    else:
+        ops.set_compute_dtype(dtype)
+        scaler = None
     B, L, desc = WORKLOADS[workload]
     if batch:
         B = batch
@@ -272,7 +334,7 @@ def build_train_step(workload, dtype, rank, batch=0):
     whole_path = workload in ("c2t", "c3t")
     if whole_path:
         from sincformer_metacog_speech_enhancement_amd.training.conformer_pipeline import compute_path_loss
-        model, sd = build_path(dtype, seed=4321)
+        model, sd = build_path("mixed" if dtype == "amp16" else dtype, seed=4321)
     else:
         model = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.15)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -288,71 +350,51 @@ def build_train_step(workload, dtype, rank, batch=0):
     torch.manual_seed(1000 + rank)                                  # dropout seeds
 
     def step():
+        # training/conformer_pipeline.py:496-532 in its call order; no host synchronisation anywhere in it
         opt.zero_grad()
         if whole_path:
             total, _ = compute_path_loss(model, noisy, clean)
+        else:
+            nr, ni = batch_stft(noisy, 256, 80, 160)
+            cr, ci = batch_stft(clean, 256, 80, 160)
+            total, _ = compute_loss(model, nr, ni, clean, cr, ci)
+        if scaler is not None:
+            scaler.scale(total).backward()
+            scaler.unscale_(opt)
+            scaler.step(opt, loss=total)
+            scaler.update()
+        else:
             total.backward()
             opt.step(loss=total)
-            return total
-        nr, ni = batch_stft(noisy, 256, 80, 160)
-        cr, ci = batch_stft(clean, 256, 80, 160)
-        total, _ = compute_loss(model, nr, ni, clean, cr, ci)
-        total.backward()
-        opt.step(loss=total)
         return total
 
-    return step, opt, sd, B, L, T, desc, whole_path
+    return step, opt, scaler, sd, B, L, T, desc, whole_path
 
 
-def dp_train_record(args, rank, world):
-    """N > 1, default workload: the data-parallel TRAINING step beside the forward shard, in the same line - the c3se step
-    (training/conformer_pipeline.py:496-532: forward, objective, backward, bucketed all-reduce of the flat fp32 gradient over
-    RCCL overlapped with backward, global-norm clip, AdamW), weak scaling.  Every rank calls this; rank 0 returns the record."""
-    import torch
-    import torch.distributed as dist
-    from sincformer_metacog_speech_enhancement_amd import ops
-    dtype = "bf16" if args.dtype == "mixed" else args.dtype
-    step, opt, _, B, L, T, desc, _ = build_train_step("c3se", dtype, rank, batch=args.dp_batch)
-    opt.sync.time_exposed = True
-    for _ in range(max(args.dp_warmup, 1)):
+def settle_loss_scale(step, opt, scaler, min_steps, barrier=None):
+    """warm-up of a training workload: at least `min_steps` steps, and on until the dynamic loss scale has settled (the last two
+    steps were applied, not skipped: GradScaler starts at 65536 and halves on every overflow), so that every step of the timed
+    region is a full step.  The decision is taken from rank-consistent state (the skip flag is computed from the all-reduced
+    gradients).  Returns the number of warm-up steps run."""
+    n, clean = 0, 0
+    while n < min_steps or (scaler is not None and clean < 2):
         step()
-    opt.sync.exposed_ms()                                           # (drops the warm-up events; host sync)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.dp_steps):
-        loss = step()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    exposed = opt.sync.exposed_ms()
-    rec = None
-    if rank == 0:
-        frames = world * B * T * args.dp_steps
-        rec = {"workload": desc, "batch_per_gpu": B, "steps": args.dp_steps, "warmup": args.dp_warmup,
-               "ms_per_step": elapsed / args.dp_steps * 1e3, "frames_per_s": frames / elapsed, "scaling": "weak",
-               "allreduce_bytes_per_step": opt.sync.bytes_per_step(), "allreduce_buckets": len(opt.sync.buckets),
-               "exposed_allreduce_ms_per_step": exposed, "overlap": bool(opt.sync.overlap),
-               "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
-               "final_loss": float(loss.detach()), "optimizer_state": opt.stats(),
-               "note": "time = max over ranks between barriers; exposed = HIP events around the wait for the bucketed "
-                       "all-reduce on the compute stream (the part of the exchange that did not overlap backward)"}
-    ops.reset_precision()
-    return rec
+        n += 1
+        if scaler is not None:
+            clean = 0 if opt.stats()["skipped"] else clean + 1
+        if n >= min_steps + 40:
+            raise SystemExit("bench.py: the loss scale did not settle within %d steps: %r" % (n, scaler.stats()))
+    return n
 
 
-def main_train(args):
-    """--workload c3se / c2t / c3t: one training step of training/conformer_pipeline.py per bench step (c3se: the reference's
-    SpeechEnhancer; c2t / c3t: the north-star SincNet + Conformer composition at B 64 / B 256)."""
+def train_leg(args, workload, rank, world, steps, warmup, batch=0, profile=True):
+    """warm-up (incl. settling the loss scale), one instrumented step alone on the device (per-family breakdown), then `steps`
+    timed steps between barriers with the dominant family event-timed per launch.  Every rank calls it; returns a dict."""
     import torch
     import torch.distributed as dist
-    rank, world = init_ranks(args)
     from sincformer_metacog_speech_enhancement_amd import ops
-    dtype = "bf16" if args.dtype == "mixed" else args.dtype          # training runs in ONE base format
-    step, opt, sd, B, L, T, desc, whole_path = build_train_step(args.workload, dtype, rank, batch=args.batch)
+    dtype = train_dtype(args)
+    step, opt, scaler, sd, B, L, T, desc, whole_path = build_train_step(workload, dtype, rank, batch=batch)
     opt.sync.time_exposed = world > 1
 
     def barrier():
@@ -362,55 +404,129 @@ def main_train(args):
 
     if rank == 0:
         print("[bench] %s, dtype %s, world %d, batch/GPU %d" % (desc, dtype, world, B), file=sys.stderr, flush=True)
-    for i in range(max(args.warmup, 1)):
-        if i == max(args.warmup, 1) - 1:
-            torch.cuda.synchronize()                                # the instrumented step runs alone on the device
-            ops.profiler.enable(None)
-        loss = step()
-    breakdown = ops.profiler.summary()
-    ops.profiler.disable()
-    dominant = max(breakdown, key=lambda k: breakdown[k]["ms_total"])
-    ops.profiler.enable({dominant})
+    n_warm = settle_loss_scale(step, opt, scaler, max(warmup, 1))
+    breakdown, dominant, launches = {}, None, []
+    if profile:
+        torch.cuda.synchronize()                                    # the instrumented step runs alone on the device
+        ops.profiler.enable(None)
+        step()
+        breakdown = ops.profiler.summary()
+        ops.profiler.disable()
+        dominant = max(breakdown, key=lambda k: breakdown[k]["ms_total"])
+        ops.profiler.enable({dominant})
+    if world > 1:
+        opt.sync.exposed_ms()                                       # (drops the warm-up events; host sync)
+    refuse_variant_overrides()
+    skipped0 = scaler.stats() if scaler is not None else None
+    step0 = opt.stats()["step"]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    dom = ops.profiler.summary()[dominant]
-    ops.profiler.disable()
+    if profile:
+        launches = ops.profiler.launches(dominant)
+        ops.profiler.disable()
     tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    frames = world * B * T * args.steps
+    st = opt.stats()
+    rec = {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T, "steps": steps, "warmup": n_warm,
+           "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "frames_per_s": world * B * T * steps / elapsed,
+           "dtype": DTYPE_DESC[dtype], "final_loss": float(loss.detach()), "optimizer_state": st,
+           "applied_steps_in_timed_region": st["step"] - step0, "whole_path": whole_path, "sd": sd,
+           "allreduce_bytes_per_step": opt.sync.bytes_per_step() if world > 1 else 0,
+           "allreduce_buckets": len(opt.sync.buckets), "overlap": bool(opt.sync.overlap),
+           "exposed_allreduce_ms_per_step": opt.sync.exposed_ms() if world > 1 else None,
+           "breakdown": breakdown, "dominant": dominant, "launches": launches}
+    if scaler is not None:
+        s1 = scaler.stats()
+        rec["loss_scale"] = {"scale": s1["scale"], "init_scale": 65536.0,
+                             "skipped_in_timed_region": (s1["skipped_inf"] - skipped0["skipped_inf"]) +
+                                                        (s1["skipped_loss"] - skipped0["skipped_loss"]),
+                             "skipped_in_warmup": skipped0["skipped_inf"] + skipped0["skipped_loss"],
+                             "rule": "x0.5 after a step with Inf / NaN gradients (step skipped), x2 after 2000 clean steps; on the device"}
+        if rec["loss_scale"]["skipped_in_timed_region"] != 0 or rec["applied_steps_in_timed_region"] != steps:
+            raise SystemExit("bench.py: %d of the %d timed training steps were skipped - not a valid measurement: %r" %
+                             (steps - rec["applied_steps_in_timed_region"], steps, rec["loss_scale"]))
+    ops.reset_precision()
+    return rec
+
+
+def dp_train_record(args, rank, world):
+    """N > 1, default workload: the data-parallel TRAINING step beside the forward shard, in the same line - the c3se step
+    (training/conformer_pipeline.py:496-532: forward, objective, backward, bucketed all-reduce of the flat fp32 gradient over
+    RCCL overlapped with backward, global-norm clip, AdamW under the dynamic loss scale), weak scaling.  Every rank calls this;
+    rank 0 returns the record."""
+    import torch.distributed as dist
+    r = train_leg(args, "c3se", rank, world, args.dp_steps, args.dp_warmup, batch=args.dp_batch, profile=False)
+    if rank != 0:
+        return None
+    rec = {k: r[k] for k in ("workload", "batch_per_gpu", "steps", "warmup", "ms_per_step", "frames_per_s", "dtype",
+                             "allreduce_bytes_per_step", "allreduce_buckets", "exposed_allreduce_ms_per_step", "overlap",
+                             "final_loss", "optimizer_state", "applied_steps_in_timed_region")}
+    if "loss_scale" in r:
+        rec["loss_scale"] = r["loss_scale"]
+    rec.update({"scaling": "weak", "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                "note": "time = max over ranks between barriers; exposed = HIP events around the wait for the bucketed "
+                        "all-reduce on the compute stream (the part of the exchange that did not overlap backward)"})
+    return rec
+
+
+def train_subrecord(r, workload):
+    """the `train` object of the default N = 1 line (and the body of a --workload c3t / c3se / c2t line) from a train_leg record"""
+    roof = roofline_of(r["dominant"], r["launches"], traffic_file(workload))
+    rec = {k: r[k] for k in ("workload", "batch_per_gpu", "steps", "warmup", "ms_per_step", "frames_per_s", "dtype", "final_loss",
+                             "optimizer_state", "applied_steps_in_timed_region")}
+    if "loss_scale" in r:
+        rec["loss_scale"] = r["loss_scale"]
+    rec["roofline"] = roof
+    rec["breakdown_ms_per_step"] = {k: round(v["ms_total"], 4) for k, v in
+                                    sorted(r["breakdown"].items(), key=lambda kv: -kv[1]["ms_total"])}
+    rec["breakdown_note"] = ("one instrumented step alone on the device (HIP events per launch); weight gradients run on a side "
+                             "stream, so the per-family times overlap and can sum to more than the step")
+    return rec
+
+
+def main_train(args):
+    """--workload c3se / c2t / c3t: one training step of training/conformer_pipeline.py per bench step (c3se: the reference's
+    SpeechEnhancer; c2t / c3t: the north-star SincNet + Conformer composition at B 64 / B 256)."""
+    import torch.distributed as dist
+    rank, world = init_ranks(args)
+    r = train_leg(args, args.workload, rank, world, args.steps, args.warmup, batch=args.batch)
     if rank == 0:
-        st = opt.stats()
+        sub = train_subrecord(r, args.workload)
         line = {
             "metric": METRIC,
-            "value": frames / elapsed, "unit": "STFT frames/s trained (whole job)", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_DESC[dtype], "data": "synthetic",
-            "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
+            "value": r["frames_per_s"], "unit": "STFT frames/s trained (whole job)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "warmup_run": r["warmup"], "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic",
+            "config": {"workload": r["workload"], "batch_per_gpu": r["batch_per_gpu"], "samples": r["samples"],
+                       "frames_per_utt": r["frames_per_utt"],
                        "sharding": "utterances over ranks; one bucketed all-reduce (RCCL) of the flat fp32 gradient per step, "
                                    "overlapped with backward", "optimizer": "AdamW lr 5e-4 betas (0.9, 0.98) wd 0.01, clip 5.0",
-                       "dropout": "module defaults (0.1 / 0.15)" if whole_path else 0.15},
-            "roofline": roofline_of(dominant, dom, traffic_file(args.workload)),
-            "frames_per_s_per_gpu": frames / elapsed / world,
-            "final_loss": float(loss.detach()), "optimizer_state": st,
-            "allreduce_bytes_per_step": opt.sync.bytes_per_step() if world > 1 else 0,
-            "exposed_allreduce_ms_per_step": opt.sync.exposed_ms() if world > 1 else None,
+                       "dropout": "module defaults (0.1 / 0.15)" if r["whole_path"] else 0.15},
+            "roofline": sub["roofline"],
+            "frames_per_s_per_gpu": r["frames_per_s"] / world,
+            "final_loss": r["final_loss"], "optimizer_state": r["optimizer_state"],
+            "applied_steps_in_timed_region": r["applied_steps_in_timed_region"],
+            "allreduce_bytes_per_step": r["allreduce_bytes_per_step"],
+            "exposed_allreduce_ms_per_step": r["exposed_allreduce_ms_per_step"],
             "rccl_ranks": world,
-            "breakdown_ms_per_step": {k: round(v["ms_total"], 4) for k, v in
-                                      sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
+            "breakdown_ms_per_step": sub["breakdown_ms_per_step"],
         }
+        if "loss_scale" in r:
+            line["loss_scale"] = r["loss_scale"]
         print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
-              (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
+              (line["ms_per_step"], line["value"], r["dominant"]), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_path_train(sd, L) if whole_path else cpu_baseline_train(sd, L)
+            line["cpu_baseline"] = cpu_baseline_path_train(r["sd"], r["samples"]) if r["whole_path"] else \
+                cpu_baseline_train(r["sd"], r["samples"])
         if args.breakdown:
             with open(args.breakdown, "w") as fh:
-                json.dump(breakdown, fh, indent=1)
+                json.dump(r["breakdown"], fh, indent=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -419,27 +535,14 @@ def main_train(args):
 # ---------------------------------------------------------------------------------------------------------------
 # the headline shape of BASELINE's metric, measured after the timed region (rank 0)
 # ---------------------------------------------------------------------------------------------------------------
-def headline_shape(path, passes=4):
-    """B 256 x 512-frame utterances through the same path (frames/s), and the attention kernel ALONE at that shape
-    (batch 256 x 512 frames x 4 heads x 64, bf16 operands: the north-star's >= 30 % of bf16 MFMA peak target), each launch
-    timed by HIP events with nothing else on the device."""
+def headline_attention():
+    """the attention kernel ALONE at B 256 x T 512 x 4 heads x 64 in the attention stage's format (bf16: the north-star's >= 30 %
+    of bf16 MFMA peak target), each launch timed by HIP events with nothing else on the device."""
     import torch
-    from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
+    from sincformer_metacog_speech_enhancement_amd import ops
     B, L, desc = WORKLOADS["c3p"]
     T = 1 + L // 80
-    noisy, _ = syn.synth_wave(B, L, 4242)
-    wave = torch.from_numpy(noisy).cuda()
-    out = {"workload": desc}
-    with torch.no_grad():
-        path(wave)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(passes):
-            path(wave)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / passes
-    out.update({"frames_per_s": B * T / dt, "ms_per_step": dt * 1e3, "passes_in_flight": 1})
-    del wave
+    out = {}
     H, hd = 4, 64
     with ops.stage("attn"):
         adt = ops.compute_dtype()
@@ -492,78 +595,48 @@ def headline_shape(path, passes=4):
 # ---------------------------------------------------------------------------------------------------------------
 # forward workloads
 # ---------------------------------------------------------------------------------------------------------------
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2 (BASELINE configs[1]); with --gpus N > 1 and no --workload the line also carries a "
-                         "`dp_train` sub-record: the c3se training step with the RCCL gradient all-reduce (BASELINE configs[3])")
-    ap.add_argument("--dp-batch", type=int, default=0, help="per-GPU batch of the dp_train sub-record (default: the workload's 256)")
-    ap.add_argument("--dp-steps", type=int, default=5)
-    ap.add_argument("--dp-warmup", type=int, default=2)
-    ap.add_argument("--no-dp-train", action="store_true", help="N > 1, default workload: skip the dp_train sub-record")
-    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained loop after the timed region")
-    ap.add_argument("--dtype", default="mixed", choices=["mixed", "bf16", "f16"],
-                    help="16-bit operand formats: mixed = the default per-stage policy (ops.POLICIES['mixed']; training: bf16)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-headline", action="store_true", help="skip the B256 x 512-frame extra measurements")
-    ap.add_argument("--breakdown", default=None, help="write the per-kernel-family breakdown JSON here")
-    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload")
-    ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound small batches)")
-    ap.add_argument("--streams", type=int, default=0, help="forward passes in flight: consecutive steps alternate over this many "
-                    "HIP streams (each step is still one whole pass over its own buffers; 1 = strictly one pass at a time; "
-                    "0 = auto: a short calibration during warm-up picks the fastest of 1, 2 and 3 on this machine)")
-    args = ap.parse_args()
-    if args.gpus < 1:
-        raise SystemExit("bench.py: --gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args))                          # before anything in this process touches the GPU
-    dp_sub = args.workload is None and args.gpus > 1 and not args.no_dp_train
-    if args.workload is None:
-        args.workload = "c2"
-    if args.workload in TRAIN_WORKLOADS:
-        return main_train(args)
-
+def forward_leg(args, workload, rank, world, steps, warmup, streams_req, batch=0, sustained=True, graph=False, tags=False):
+    """one forward workload: calibration of the passes in flight, warm-up, one instrumented pass alone on the device, `steps`
+    timed steps between barriers with the dominant family event-timed per launch, three strictly sequential passes (exclusive
+    launch durations, single-pass step), optionally the >= 2 s sustained loop.  Every rank calls it; returns a dict."""
     import torch
     import torch.distributed as dist
-    rank, world = init_ranks(args)
-
     from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn
-    B, L, desc = WORKLOADS[args.workload]
-    if args.batch:
-        B = args.batch
+    B, L, desc = WORKLOADS[workload]
+    if batch:
+        B = batch
     T = 1 + L // 80
-    use_memory = args.workload == "c5"
+    use_memory = workload == "c5"
     path, weights = build_path(args.dtype, use_memory=use_memory)
     path = path.cuda().eval()
     noisy, _ = syn.synth_wave(B, L, 1234 + rank)          # each rank enhances its own utterance shard
     wave = torch.from_numpy(noisy).cuda()
+    n_streams = streams_req
 
-    if args.graph:
+    if graph:
         from sincformer_metacog_speech_enhancement_amd.graph import GraphedForward
         # one captured graph (with its own static buffers) per pass in flight: a graph is never replayed concurrently with itself
-        graphs = [GraphedForward(lambda w: path(w)) for _ in range(max(args.streams, 1))]
+        graphs = [GraphedForward(lambda w: path(w)) for _ in range(max(n_streams, 1))]
         for g_ in graphs:
             g_(wave)                                      # capture outside the timed region
         graphed = graphs[0]
 
-    auto_streams = args.streams == 0
+    auto_streams = n_streams == 0
     if auto_streams:
-        args.streams = 2
+        n_streams = 2
     # the current (default) stream + S-1 new ones: as few HIP streams as possible, so that they never have to share one of
     # the process's hardware queues (5 streams on 4 queues ran SLOWER than a single stream: 12.9 vs 11.0 ms)
-    streams = ([torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(args.streams - 1)]) if args.streams > 1 else None
-    counter = [0]
+    box = {"streams": ([torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]) if n_streams > 1 else None,
+           "counter": 0}
 
     def step():
+        streams = box["streams"]
         if streams is not None:
-            st = streams[counter[0] % len(streams)]
-            counter[0] += 1
+            st = streams[box["counter"] % len(streams)]
+            box["counter"] += 1
             with torch.cuda.stream(st):
-                return graphs[(counter[0] - 1) % len(streams)](wave) if args.graph else path(wave)
-        return graphed(wave) if args.graph else path(wave)
+                return graphs[(box["counter"] - 1) % len(streams)](wave) if graph else path(wave)
+        return graphed(wave) if graph else path(wave)
 
     def barrier():
         if world > 1:
@@ -574,7 +647,7 @@ def main():
         print("[bench] %s, dtype %s, world %d" % (desc, args.dtype, world), file=sys.stderr, flush=True)
     with torch.no_grad():
         calib = None
-        if auto_streams and not args.graph:
+        if auto_streams and not graph:
             # calibration (untimed, part of the warm-up): 6 passes each with 1, 2 and 3 passes in flight; the fastest wins
             # (more streams than the process has hardware queues run SLOWER than one: never assume, measure)
             def timed(n):
@@ -587,44 +660,46 @@ def main():
             pool = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
             res = {}
             for cand in (3, 2, 1):
-                streams = pool[:cand] if cand > 1 else None
+                box["streams"] = pool[:cand] if cand > 1 else None
                 for _ in range(cand):
                     step()
                 res[cand] = timed(6)
             best = min(res, key=lambda c: res[c] * (1.0 + 0.01 * c))          # prefer fewer passes in flight on a tie
-            args.streams = best
-            streams = pool[:best] if best > 1 else None
+            n_streams = best
+            box["streams"] = pool[:best] if best > 1 else None
             calib = {str(c): res[c] * 1e3 for c in (1, 2, 3)}
             if rank == 0:
                 print("[bench] calibration (ms/pass): %s -> --streams %d" %
                       (", ".join("%d in flight %.2f" % (c, res[c] * 1e3) for c in (1, 2, 3)), best), file=sys.stderr, flush=True)
         # warm-up; then ONE instrumented pass, alone on the device (everything enqueued before it has finished), to find the
         # dominant kernel family and the exclusive per-family times
-        for i in range(max(args.warmup, 1)):
+        for i in range(max(warmup, 1)):
             step()
         torch.cuda.synchronize()
-        ops.profiler.enable(None, tags=bool(args.breakdown))
+        ops.profiler.enable(None, tags=tags)
         out_one = path(wave)                              # eager, so the per-launch events exist even with --graph
         breakdown = ops.profiler.summary()
+        launches_one = {k: ops.profiler.launches(k) for k in breakdown if "[" not in k}
         ops.profiler.disable()
         gpu_masks = (out_one["mask_real"][:1].cpu(), out_one["mask_imag"][:1].cpu()) if rank == 0 else None
         del out_one
         dominant = max((k for k in breakdown if "[" not in k), key=lambda k: breakdown[k]["ms_total"])
-        if not args.graph:
+        refuse_variant_overrides()
+        if not graph:
             ops.profiler.enable({dominant})
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         barrier()
         elapsed = time.perf_counter() - t0
-        dom = breakdown[dominant] if args.graph else ops.profiler.summary()[dominant]
+        launches = launches_one[dominant] if graph else ops.profiler.launches(dominant)
         ops.profiler.disable()
         # with several passes in flight the live per-launch durations include the time a kernel shares the chip with the
         # other stream's kernels; strictly sequential passes AFTER the timed region give the exclusive durations and the
         # single-pass step time
-        dom_excl, single_ms = None, None
-        if not args.graph:
+        launches_excl, single_ms = None, None
+        if not graph:
             torch.cuda.synchronize()
             ops.profiler.enable({dominant})
             t1 = time.perf_counter()
@@ -632,18 +707,13 @@ def main():
                 path(wave)
             torch.cuda.synchronize()
             single_ms = (time.perf_counter() - t1) / 3 * 1e3
-            dom_excl = ops.profiler.summary()[dominant]
+            launches_excl = ops.profiler.launches(dominant)
             ops.profiler.disable()
-        # (the headline shape comes BEFORE the 2-second loop: it is specified like the timed region - the kernel on a chip that
-        #  has just run the K steps - and the other ranks simply wait at the next barrier)
-        headline = None
-        if rank == 0 and not args.no_headline and args.workload == "c2":
-            headline = headline_shape(path)
         # sustained figure: the same step() loop for >= 2 s of wall time and >= 250 steps (the timed region above is K steps
         # as the contract says - a burst of a fraction of a second at the default K), dominant family timed live
-        sustained = None
-        if not args.no_sustained:
-            if not args.graph:
+        sus = None
+        if sustained:
+            if not graph:
                 ops.profiler.enable({dominant})
             barrier()
             t2 = time.perf_counter()
@@ -661,75 +731,173 @@ def main():
                     break
             barrier()
             dt_s = time.perf_counter() - t2
-            sustained = {"steps": n_s, "seconds": dt_s, "ms_per_step": dt_s / n_s * 1e3, "frames_per_s": world * B * T * n_s / dt_s}
-            if not args.graph:
+            sus = {"steps": n_s, "seconds": dt_s, "ms_per_step": dt_s / n_s * 1e3, "frames_per_s": world * B * T * n_s / dt_s}
+            if not graph:
                 ds = ops.profiler.summary()[dominant]
-                sustained.update({"dominant_kernel": dominant, "dominant_avg_ms": ds["ms_avg"], "dominant_launches": ds["n"]})
+                sus.update({"dominant_kernel": dominant, "dominant_avg_ms": ds["ms_avg"], "dominant_launches": ds["n"]})
                 ops.profiler.disable()
-    dp_rec = None
-    if dp_sub:
-        del path, wave
-        torch.cuda.empty_cache()
-        dp_rec = dp_train_record(args, rank, world)
-
     tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    frames = world * B * T * args.steps
+    del path, wave
+    torch.cuda.empty_cache()
+    return {"workload": workload, "desc": desc, "B": B, "L": L, "T": T, "elapsed": elapsed, "steps": steps, "streams": n_streams,
+            "calib": calib, "breakdown": breakdown, "launches_one": launches_one, "dominant": dominant, "launches": launches,
+            "launches_excl": launches_excl, "single_ms": single_ms, "sustained": sus, "gpu_masks": gpu_masks, "weights": weights,
+            "noisy": noisy, "use_memory": use_memory, "policy": ops.policy_name()}
+
+
+def forward_roofline(r, passes_in_flight):
+    roof = roofline_of(r["dominant"], r["launches"], traffic_file(r["workload"]))
+    if r["launches_excl"]:
+        ex = roofline_of(r["dominant"], r["launches_excl"])
+        roof.update({"passes_in_flight": passes_in_flight, "exclusive_achieved": ex["achieved"], "exclusive_frac": ex["frac"],
+                     "exclusive_avg_ms": ex["avg_ms"], "exclusive_bound": ex["bound"],
+                     "note": "achieved / avg_ms are live in the timed region, where %d pass(es) share the chip; "
+                             "exclusive_* are the same launches in 3 strictly sequential passes right after "
+                             "it" % passes_in_flight})
+    return roof
+
+
+def attention_in_pass(r):
+    att = r["breakdown"].get("attention_fwd")
+    if not att:
+        return None
+    tf = att["flops"] / att["n"] / (att["ms_avg"] * 1e-3) / 1e12
+    return {"tflops": tf, "frac_bf16_mfma_peak": tf / PEAKS["mfma16"], "avg_ms": att["ms_avg"],
+            "shape": "B%d x T%d x 4 heads x 64 (this workload), instrumented pass alone on the device" % (r["B"], r["T"])}
+
+
+def breakdown_of(r):
+    return {k: round(v["ms_total"], 4) for k, v in sorted(r["breakdown"].items(), key=lambda kv: -kv[1]["ms_total"]) if "[" not in k}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3p = the shape BASELINE's metric names (B 256 x 512-frame utterances); the default line also "
+                         "carries `configs1` (BASELINE configs[1], B 64 x 4 s) and `train` (configs[2] on the north-star composition) "
+                         "at N = 1, and with --gpus N > 1 a `dp_train` sub-record: the c3se training step with the RCCL gradient "
+                         "all-reduce (BASELINE configs[3])")
+    ap.add_argument("--dp-batch", type=int, default=0, help="per-GPU batch of the dp_train sub-record (default: the workload's 256)")
+    ap.add_argument("--dp-steps", type=int, default=5)
+    ap.add_argument("--dp-warmup", type=int, default=2)
+    ap.add_argument("--no-dp-train", action="store_true", help="N > 1, default workload: skip the dp_train sub-record")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed steps of the `train` sub-record (default line, N = 1)")
+    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--train-batch", type=int, default=0, help="per-GPU batch of the `train` sub-record (default: c3t's 256)")
+    ap.add_argument("--no-train", action="store_true", help="default line, N = 1: skip the `train` sub-record")
+    ap.add_argument("--no-configs1", action="store_true", help="default line: skip the `configs1` sub-record")
+    ap.add_argument("--configs1-batch", type=int, default=0, help="per-GPU batch of the `configs1` sub-record (default 64)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained loop after the timed region")
+    ap.add_argument("--dtype", default="mixed", choices=["mixed", "bf16", "f16"],
+                    help="16-bit operand formats: mixed = the default per-stage policy (ops.POLICIES['mixed']; training: fp16 + "
+                         "dynamic loss scale)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-headline", action="store_true", help="skip the attention-kernel-alone measurement at B256 x T512")
+    ap.add_argument("--breakdown", default=None, help="write the per-kernel-family breakdown JSON here")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (launch-bound small batches)")
+    ap.add_argument("--streams", type=int, default=0, help="forward passes in flight: consecutive steps alternate over this many "
+                    "HIP streams (each step is still one whole pass over its own buffers; 1 = strictly one pass at a time; "
+                    "0 = auto: a short calibration during warm-up picks the fastest of 1, 2 and 3 on this machine)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                          # before anything in this process touches the GPU
+    default_line = args.workload is None
+    if default_line:
+        args.workload = "c3p"
+    if args.workload in TRAIN_WORKLOADS:
+        return main_train(args)
+
+    import torch
+    import torch.distributed as dist
+    rank, world = init_ranks(args)
+    dp_sub = default_line and world > 1 and not args.no_dp_train
+    train_sub = default_line and world == 1 and not args.no_train
+    c1_sub = default_line and not args.no_configs1
+
+    r = forward_leg(args, args.workload, rank, world, args.steps, args.warmup, args.streams, batch=args.batch,
+                    sustained=not args.no_sustained, graph=args.graph, tags=bool(args.breakdown))
+    # the attention kernel alone comes right after the primary workload: it is specified like the timed region - the kernel on
+    # a chip that has just run the K steps - and the other ranks simply wait at the next barrier
+    headline = None
+    if rank == 0 and not args.no_headline and default_line:
+        headline = headline_attention()
+    c1 = None
+    if c1_sub:
+        c1 = forward_leg(args, "c2", rank, world, 10, 3, args.streams, batch=args.configs1_batch, sustained=False)
+    tr = None
+    if train_sub:
+        tr = train_leg(args, "c3t", rank, world, args.train_steps, args.train_warmup, batch=args.train_batch)
+    dp_rec = dp_train_record(args, rank, world) if dp_sub else None
+
+    frames = world * r["B"] * r["T"] * r["steps"]
     if rank == 0:
-        roof = roofline_of(dominant, dom, traffic_file(args.workload))
-        peak = roof["peak"]
-        kind = FAMILY_BOUND.get(dominant, "hbm")
+        elapsed = r["elapsed"]
         line = {
             "metric": METRIC,
             "value": frames / elapsed, "unit": "STFT frames/s (whole job)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_DESC[args.dtype], "data": "synthetic",
-            "config": {"workload": desc, "batch_per_gpu": B, "samples": L, "frames_per_utt": T,
+            "config": {"workload": r["desc"], "batch_per_gpu": r["B"], "samples": r["L"], "frames_per_utt": r["T"],
                        "sharding": "utterances over ranks, no data-path collective",
                        "launch": "one hipGraph replay per step" if args.graph else "eager launches",
-                       "streams": args.streams, "precision_policy": ops.policy_name()},
-            "roofline": roof,
+                       "streams": r["streams"], "precision_policy": r["policy"]},
+            "roofline": forward_roofline(r, r["streams"]),
             "frames_per_s_per_gpu": frames / elapsed / world,
         }
-        if calib:
-            line["config"]["calibration_ms_per_pass"] = calib
-        if dom_excl is not None:
-            ex = (dom_excl["bytes"] if kind == "hbm" else dom_excl["flops"]) / dom_excl["n"] / (dom_excl["ms_avg"] * 1e-3) / \
-                (1e9 if kind == "hbm" else 1e12)
-            line["roofline"].update({"passes_in_flight": args.streams, "exclusive_achieved": ex, "exclusive_frac": ex / peak,
-                                     "exclusive_avg_ms": dom_excl["ms_avg"],
-                                     "note": "achieved / avg_ms are live in the timed region, where %d pass(es) share the chip; "
-                                             "exclusive_* are the same launches in 3 strictly sequential passes right after "
-                                             "it" % args.streams})
-            line["single_pass_ms_per_step"] = single_ms
-        att = breakdown.get("attention_fwd")
+        if default_line:
+            line["config"]["why_this_workload"] = ("the shape BASELINE.json's metric and north_star target are quoted on (batch 256 x "
+                                                   "512-frame utterances); BASELINE configs[1] (B 64 x 4 s) is the `configs1` sub-record, "
+                                                   "configs[2] the `train` sub-record")
+        if r["calib"]:
+            line["config"]["calibration_ms_per_pass"] = r["calib"]
+        if r["single_ms"] is not None:
+            line["single_pass_ms_per_step"] = r["single_ms"]
+        att = attention_in_pass(r)
         if att:
-            tf = att["flops"] / att["n"] / (att["ms_avg"] * 1e-3) / 1e12
-            line["attention"] = {"tflops": tf, "frac_bf16_mfma_peak": tf / PEAKS["mfma16"], "avg_ms": att["ms_avg"],
-                                 "shape": "B%d x T%d x 4 heads x 64 (this workload), instrumented pass alone on the device" % (B, T)}
-        line["breakdown_ms_per_step"] = {k: round(v["ms_total"], 4) for k, v in
-                                         sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]) if "[" not in k}
+            line["attention"] = att
+        line["breakdown_ms_per_step"] = breakdown_of(r)
         line["breakdown_note"] = "one instrumented pass alone on the device (HIP events per launch); sums to the single-pass step"
-        if sustained:
-            sustained["vs_timed_region"] = sustained["ms_per_step"] / line["ms_per_step"]
-            sustained["note"] = ("`value` / `ms_per_step` are the K timed steps of the contract; this is the same loop kept up "
-                                 "for >= 2 s and >= 250 steps (clock and thermal steady state)")
-            line["sustained"] = sustained
+        if r["sustained"]:
+            sus = r["sustained"]
+            sus["vs_timed_region"] = sus["ms_per_step"] / line["ms_per_step"]
+            sus["note"] = ("`value` / `ms_per_step` are the K timed steps of the contract; this is the same loop kept up "
+                           "for >= 2 s and >= 250 steps (clock and thermal steady state)")
+            line["sustained"] = sus
         if headline:
             line["headline"] = headline
+        if c1:
+            fr1 = world * c1["B"] * c1["T"] * c1["steps"]
+            line["configs1"] = {"workload": c1["desc"], "batch_per_gpu": c1["B"], "steps": c1["steps"], "warmup": 3,
+                                "ms_per_step": c1["elapsed"] / c1["steps"] * 1e3, "frames_per_s": fr1 / c1["elapsed"],
+                                "streams": c1["streams"], "single_pass_ms_per_step": c1["single_ms"],
+                                "roofline": forward_roofline(c1, c1["streams"]), "attention": attention_in_pass(c1),
+                                "breakdown_ms_per_step": breakdown_of(c1)}
+            if c1["calib"]:
+                line["configs1"]["calibration_ms_per_pass"] = c1["calib"]
+        if tr:
+            line["train"] = train_subrecord(tr, "c3t")
         if dp_rec:
             line["dp_train"] = dp_rec
         print("[bench] gpu leg done: %.1f ms/step, %.3e frames/s; dominant kernel %s" %
-              (line["ms_per_step"], line["value"], dominant), file=sys.stderr, flush=True)
+              (line["ms_per_step"], line["value"], r["dominant"]), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], rm = cpu_baseline(weights, L, noisy, gpu_masks=gpu_masks, use_memory=use_memory)
+            line["cpu_baseline"], rm = cpu_baseline(r["weights"], r["L"], r["noisy"], gpu_masks=r["gpu_masks"],
+                                                    use_memory=r["use_memory"])
             line["mask_rmse"] = {"value": rm, "bound": 1e-3, "what": "RMSE of (mask_real | mask_imag) of utterance 0 of the bench "
                                  "batch, HIP path (this dtype) vs the CPU oracle (fp32), outside the timed region"}
         if args.breakdown:
             with open(args.breakdown, "w") as fh:
-                json.dump(breakdown, fh, indent=1)
+                json.dump({"breakdown": r["breakdown"],
+                           "launches": {k: v for k, v in r["launches_one"].items()}}, fh, indent=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

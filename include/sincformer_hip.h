@@ -325,6 +325,16 @@ int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* 
 int sfm_adamw_step_masked(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
                           float eps, float wd, float inv_scale, float max_norm, int write_back_grad, const long long* spans,
                           const float* touched, int n_params, void* stream);
+/* The same step under the reference's AMP recipe (training/conformer_pipeline.py:442 torch.amp.GradScaler, :504
+ * scaler.scale(loss).backward(), :512-517 unscale_ / clip_grad_norm_ / scaler.step / scaler.update) with the loss scale kept on the
+ * device: loss_scale = 4 floats {S, clean steps since S last changed, steps skipped for Inf / NaN gradients, steps skipped for a
+ * non-finite loss}.  g holds S (x world; inv_world = 1 / world) times the gradient: the prepare thread unscales, takes the
+ * clip / skip decision, halves S (backoff_factor) after a step with Inf / NaN gradients, multiplies it by growth_factor after
+ * growth_interval clean steps - GradScaler.update() without a host round trip.  spans / touched may both be NULL. */
+int sfm_adamw_step_scaled(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
+                          float eps, float wd, float inv_world, float max_norm, int write_back_grad, const long long* spans,
+                          const float* touched, int n_params, float* loss_scale, float growth_factor, float backoff_factor,
+                          int growth_interval, void* stream);
 /* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
 /* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); db (optional):
  * db[n] += sum_m G[m,n] in the same launch; sfm_colsum = the stand-alone bias gradient */

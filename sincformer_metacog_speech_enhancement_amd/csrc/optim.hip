@@ -41,6 +41,52 @@ __global__ void adamw_prepare_kernel(double* __restrict__ ctl, double inv_scale,
   ctl[2] = 0.0;
 }
 
+// The reference trains under fp16 autocast with torch.amp.GradScaler (training/conformer_pipeline.py:442, 504, 512-517): the loss is
+// multiplied by a scale S before backward, unscale_ divides the gradients by S and looks for Inf / NaN, step is skipped when one is
+// found, update() halves S after such a step and doubles it after `growth_interval` clean ones.  Here all of that is this one
+// thread: ls[0] = S (fp32, the tensor the host multiplies the loss with - read by that multiply BEFORE this kernel runs, in stream
+// order), ls[1] = clean steps since the last change, ls[2] = steps skipped for Inf / NaN gradients (total), ls[3] = steps skipped
+// for a non-finite loss (total).  A non-finite LOSS skips the whole iteration in the reference (:509 `continue`): no update of S.
+__global__ void adamw_prepare_scaled_kernel(double* __restrict__ ctl, float* __restrict__ ls, double inv_world, double max_norm,
+                                            double beta1, double beta2, float growth, float backoff, float interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double S = (double)ls[0];
+  const double inv_scale = inv_world / S;
+  const double norm = sqrt(ctl[1]) * inv_scale;
+  const bool bad_grad = !(norm == norm) || norm > 1.7e308;
+  const bool bad_loss = ctl[2] > 0.0;
+  const bool bad = bad_grad || bad_loss;
+  double coef = 1.0;
+  if (max_norm > 0.0 && norm > max_norm) coef = max_norm / (norm + 1e-6);
+  ctl[7] = norm;
+  ctl[4] = bad ? 1.0 : 0.0;
+  ctl[3] = inv_scale * coef;
+  if (!bad) {
+    const double step = ctl[0] + 1.0;
+    ctl[0] = step;
+    ctl[5] = 1.0 - pow(beta1, step);
+    ctl[6] = 1.0 - pow(beta2, step);
+  }
+  if (bad_loss) {
+    ls[3] += 1.f;
+  } else if (bad_grad) {                                                       // GradScaler.update(): found_inf
+    ls[0] = fmaxf(ls[0] * backoff, 1.17549435e-38f);
+    ls[1] = 0.f;
+    ls[2] += 1.f;
+  } else {
+    const float t = ls[1] + 1.f;
+    if (t >= interval) {
+      const float grown = ls[0] * growth;
+      ls[0] = (grown == grown && grown < 3.0e38f) ? grown : ls[0];
+      ls[1] = 0.f;
+    } else {
+      ls[1] = t;
+    }
+  }
+  ctl[1] = 0.0;
+  ctl[2] = 0.0;
+}
+
 // spans / touched (optional): spans[k] = first element of parameter k in the flat buffers (n_params + 1 entries, ascending),
 // touched[k] > 0 when some rank's backward pass produced a gradient for parameter k in this step.  Elements of parameters
 // with touched == 0 are left alone - p, m AND v - as torch.optim.AdamW leaves a parameter whose grad is None; the decision is
@@ -92,12 +138,19 @@ extern "C" int sfm_sumsq(const float* g, long long n, double* out, void* stream)
 
 static int adamw_step_impl(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,
                            float beta2, float eps, float wd, float inv_scale, float max_norm, int write_back_grad,
-                           const long long* spans, const float* touched, int n_params, void* stream) {
+                           const long long* spans, const float* touched, int n_params, void* stream, float* loss_scale = nullptr,
+                           float growth = 2.f, float backoff = 0.5f, int interval = 2000) {
   if (!p || !g || !m || !v || !ctl) return SFM_ERR_ARG;
   if (n <= 0) return SFM_ERR_SHAPE;
   if ((spans != nullptr) != (touched != nullptr) || (spans && n_params <= 0)) return SFM_ERR_ARG;
-  SFM_LAUNCH(adamw_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, (double)inv_scale, (double)max_norm,
-             (double)beta1, (double)beta2);
+  if (loss_scale) {
+    if (!(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f) || interval < 1) return SFM_ERR_ARG;
+    SFM_LAUNCH(adamw_prepare_scaled_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, loss_scale, (double)inv_scale,
+               (double)max_norm, (double)beta1, (double)beta2, growth, backoff, (float)interval);
+  } else {
+    SFM_LAUNCH(adamw_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, (double)inv_scale, (double)max_norm,
+               (double)beta1, (double)beta2);
+  }
   long long nb = (n + 255) / 256;
   if (nb > 8192) nb = 8192;
   SFM_LAUNCH(adamw_apply_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ctl, lr, beta1, beta2,
@@ -118,4 +171,17 @@ extern "C" int sfm_adamw_step_masked(float* p, float* g, float* m, float* v, lon
   if (!spans || !touched) return SFM_ERR_ARG;
   return adamw_step_impl(p, g, m, v, n, ctl, lr, beta1, beta2, eps, wd, inv_scale, max_norm, write_back_grad, spans, touched,
                          n_params, stream);
+}
+
+// AdamW step under the reference's AMP recipe (training/conformer_pipeline.py:504, 512-517: scaler.scale(loss).backward();
+// scaler.unscale_; clip_grad_norm_; scaler.step; scaler.update) with the scale kept ON THE DEVICE: loss_scale = 4 floats
+// {S, clean steps since the last change of S, steps skipped for Inf / NaN gradients, steps skipped for a non-finite loss}.
+// The gradients in g are S times (and, data parallel, world times: inv_world = 1 / world) the true ones.
+extern "C" int sfm_adamw_step_scaled(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,
+                                     float beta2, float eps, float wd, float inv_world, float max_norm, int write_back_grad,
+                                     const long long* spans, const float* touched, int n_params, float* loss_scale,
+                                     float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+  if (!loss_scale) return SFM_ERR_ARG;
+  return adamw_step_impl(p, g, m, v, n, ctl, lr, beta1, beta2, eps, wd, inv_world, max_norm, write_back_grad, spans, touched,
+                         n_params, stream, loss_scale, growth_factor, backoff_factor, growth_interval);
 }

@@ -129,6 +129,11 @@ class FlatGradSynchronizer:
             return
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
+        if self._pending[b] < 0 or self._launched[b]:
+            # a second backward() before step(): the buckets of the first one are already on the wire (or reduced in place), a
+            # second micro-batch accumulated into them would be summed over ranks twice or not at all
+            raise RuntimeError("FlatGradSynchronizer(overlap=True): a gradient arrived for a bucket that has already been "
+                               "all-reduced in this step - gradient accumulation over several backward() calls needs overlap=False")
         # Buckets go out in ONE fixed order on every rank - last bucket first, bucket 0 (flag + touched mask) last, from
         # finish() - whatever the order in which their gradients complete: a rank whose graph never reaches some parameter
         # (data-dependent routing) simply stops launching from hooks at that bucket and finish() sends the rest, in the same

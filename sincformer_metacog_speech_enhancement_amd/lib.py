@@ -95,6 +95,8 @@ SIGNATURES = {
     "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp],
     "sfm_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp],
     "sfm_adamw_step_masked": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_vp, c_i, c_vp],
+    "sfm_adamw_step_scaled": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_vp, c_i, c_vp,
+                              c_f, c_f, c_i, c_vp],
     "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_conv_wgrad16": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_vp],
     "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],

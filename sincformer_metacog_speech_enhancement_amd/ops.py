@@ -12,7 +12,8 @@ EPI_NONE, EPI_SWISH, EPI_GELU, EPI_RESID, EPI_GLU, EPI_SIGMOID, EPI_TANH_SCALE, 
 
 _DT_ID = {torch.bfloat16: 0, torch.float16: 1}
 import os as _os
-_state = {"dtype": torch.bfloat16, "gemm_variant": int(_os.environ.get("SFM_GEMM_VARIANT", "0"))}
+TRAIN_DTYPE = torch.float16         # base (training) operand format: the reference's own AMP recipe, see reset_precision
+_state = {"dtype": TRAIN_DTYPE, "gemm_variant": int(_os.environ.get("SFM_GEMM_VARIANT", "0"))}
 
 
 def set_gemm_variant(v):
@@ -40,13 +41,16 @@ POLICIES = {
     "mixed": {"pa": torch.float16, "front": torch.float16, "block": torch.float16, "attn": torch.bfloat16,
               "tail": torch.float16},
 }
-_state["policy"] = dict(POLICIES["mixed"])          # inference default; training uses the base dtype (bf16)
+_state["policy"] = dict(POLICIES["mixed"])          # inference default; training uses the base dtype (fp16 + loss scale)
 _state["policy_name"] = "mixed"
 
 
 def reset_precision():
-    """the defaults: base (training) format bf16, inference stages per POLICIES["mixed"]"""
-    _state["dtype"] = torch.bfloat16
+    """the defaults: inference stages per POLICIES["mixed"]; base (training) format fp16 - what the reference trains in
+    (fp16 autocast + torch.amp.GradScaler, training/conformer_pipeline.py:442, 504, 512-517), used with optim.DynamicLossScale.
+    A uniform bf16 step stays available (set_compute_dtype) as a diagnostic: its 8-bit mantissas make this objective's
+    gradient a quarter noise (training error budget)."""
+    _state["dtype"] = TRAIN_DTYPE
     _state["policy"] = dict(POLICIES["mixed"])
     _state["policy_name"] = "mixed"
 
@@ -189,6 +193,12 @@ class KernelProfiler:
         for d in out.values():
             d["ms_avg"] = d["ms_total"] / max(d["n"], 1)
         return out
+
+
+    def launches(self, name):
+        """[(ms, flops, bytes)] of every recorded launch of family `name`, in launch order — synchronises."""
+        torch.cuda.synchronize()
+        return [(e0.elapsed_time(e1), fl, by) for n, e0, e1, fl, by in self.records if n == name]
 
 
 profiler = KernelProfiler()
@@ -492,6 +502,17 @@ def set_attention_variant(v):
 
 
 _ATTN_VARIANT = [0]
+
+
+def variant_overrides():
+    """the kernel-selection test knobs that are NOT at their default (set_gemm_variant, set_attention_variant, SFM_GEMM_VARIANT):
+    bench.py refuses to time anything while one is active"""
+    out = {}
+    if _state["gemm_variant"] != 0:
+        out["gemm_variant"] = _state["gemm_variant"]
+    if _ATTN_VARIANT[0] != 0:
+        out["attention_variant"] = _ATTN_VARIANT[0]
+    return out
 
 
 def attention(qkv16, B, T, H, hd, out=None, prescaled=False, out_dtype=None):

@@ -266,7 +266,8 @@ class EnhancementPath(HipModule):
 
 
 class ConformerPipeline:
-    """Inference half of training/conformer_pipeline.py:308-685 (load_model :628, enhance_signal :653)."""
+    """training/conformer_pipeline.py:308-685 without its data loading: the training step (_train_epoch :484, _validate :574,
+    _compute_loss :539), model I/O (:611-649) and enhance_signal (:653)."""
 
     def __init__(self, fs=None, device=None):
         self.fs = fs or config.SAMPLE_RATE
@@ -275,6 +276,7 @@ class ConformerPipeline:
             raise RuntimeError("ConformerPipeline (HIP build) needs an MI355X; there is no CPU fallback")
         self.device = torch.device(device or "cuda")
         self.model = None
+        self.use_amp = True           # :334 `use_amp = device.type == 'cuda'`: fp16 operands + dynamic loss scale (make_optimizer)
         self.use_graph = False        # True: enhance_signal replays one hipGraph per signal length (graph.GraphedForward)
         self._graphed = None
 
@@ -295,6 +297,62 @@ class ConformerPipeline:
         loss_mag = train.L1MagnitudeFunction.apply(enh_real, enh_imag, clean_real[:, :T], clean_imag[:, :T])
         loss_stft = mr_stft_fn(enh_wav, clean_wav)
         return loss_sisnr + 0.5 * loss_mag + loss_stft, loss_sisnr
+
+    # -- the training step (training/conformer_pipeline.py:424-429, 442, 484-537) -----------------------------------------
+    def make_optimizer(self, params=None, sync=None):
+        """(optimizer, scaler) of ConformerPipeline.train: AdamW(lr 5e-4, betas (0.9, 0.98), weight_decay 0.01) with the
+        gradient clip 5.0 of :514 folded in (optim.FlatAdamW), and torch.amp.GradScaler('cuda') of :442 when `use_amp`
+        (optim.DynamicLossScale: the same scale / growth / backoff rule, kept on the device)."""
+        from ..optim import FlatAdamW, DynamicLossScale
+        opt = FlatAdamW(list(params if params is not None else self.model.parameters()), lr=5e-4, betas=(0.9, 0.98),
+                        weight_decay=0.01, max_norm=5.0, sync=sync)
+        return opt, (DynamicLossScale(self.device) if self.use_amp else None)
+
+    def _train_epoch(self, loader, optimizer, mr_stft_fn, scaler):
+        """training/conformer_pipeline.py:484-537 with the reference's call order; `optimizer` = optim.FlatAdamW, `scaler` =
+        optim.DynamicLossScale or None.  What the reference does on the host per step happens on the device here: the
+        `torch.isnan(loss) or torch.isinf(loss): continue` of :509 is the optimiser's skip flag, clip_grad_norm_(5.0) its clip
+        coefficient, `loss.item()` a device-side accumulation that is read ONCE at the end of the epoch."""
+        self.model.train()
+        acc = torch.zeros(3, device=self.device, dtype=torch.float64)           # sum loss, sum SI-SNR, batches counted
+        for noisy, clean in loader:
+            noisy = noisy.to(self.device, non_blocking=True)
+            clean = clean.to(self.device, non_blocking=True)
+            optimizer.zero_grad()
+            noisy_real, noisy_imag = batch_stft(noisy, self.fft_size, self.hop_size, self.frame_size)
+            clean_real, clean_imag = batch_stft(clean, self.fft_size, self.hop_size, self.frame_size)
+            loss, neg_sisnr = self._compute_loss(noisy_real, noisy_imag, clean, clean_real, clean_imag, mr_stft_fn)
+            if scaler is not None:
+                scaler.scale(loss).backward()
+                scaler.unscale_(optimizer)
+                scaler.step(optimizer, loss=loss)            # NaN / Inf loss -> skipped on the device (:509), clip 5.0 (:514)
+                scaler.update()
+            else:
+                loss.backward()
+                optimizer.step(loss=loss)
+            with torch.no_grad():
+                ok = torch.isfinite(loss.detach()).double()
+                acc += torch.stack([torch.nan_to_num(loss.detach().double()) * ok,
+                                    -torch.nan_to_num(neg_sisnr.detach().double()) * ok, ok])
+        a = acc.cpu()
+        n = max(float(a[2]), 1.0)
+        return float(a[0]) / n, float(a[1]) / n
+
+    @torch.no_grad()
+    def _validate(self, loader, mr_stft_fn):
+        """training/conformer_pipeline.py:574-609: the objective in eval() mode, averaged over the batches."""
+        self.model.eval()
+        acc = torch.zeros(3, device=self.device, dtype=torch.float64)
+        for noisy, clean in loader:
+            noisy, clean = noisy.to(self.device, non_blocking=True), clean.to(self.device, non_blocking=True)
+            noisy_real, noisy_imag = batch_stft(noisy, self.fft_size, self.hop_size, self.frame_size)
+            clean_real, clean_imag = batch_stft(clean, self.fft_size, self.hop_size, self.frame_size)
+            loss, neg_sisnr = self._compute_loss(noisy_real, noisy_imag, clean, clean_real, clean_imag, mr_stft_fn)
+            ok = torch.isfinite(loss).double()                                  # :601 non-finite batches are not counted
+            acc += torch.stack([torch.nan_to_num(loss.double()) * ok, -torch.nan_to_num(neg_sisnr.double()) * ok, ok])
+        a = acc.cpu()
+        n = max(float(a[2]), 1.0)
+        return float(a[0]) / n, float(a[1]) / n
 
     # -- model I/O (training/conformer_pipeline.py:611-649): {'model_state', 'model_class'} checkpoints ----------------
     def _checkpoint(self):

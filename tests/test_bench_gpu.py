@@ -3,6 +3,7 @@ it (python -m torch.distributed.run, one rank per 'GPU') rehearsed on the single
 collectives run over gloo (SFM_SINGLE_DEVICE / SFM_DIST_BACKEND), which exercises rank handling, the utterance sharding, the
 max-over-ranks timing, the gradient all-reduce of the training step and rank 0's aggregate line."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -45,16 +46,41 @@ def test_bench_single_gpu_line():
     assert sum(d["breakdown_ms_per_step"].values()) <= 1.1 * d["single_pass_ms_per_step"]
 
 
-def test_bench_default_workload_carries_the_headline_shape():
-    """configs[1] line + the extra keys for BASELINE's metric shape (B 256 x 512-frame utterances) and the attention kernel
-    alone at that shape"""
-    d = _json_line(_run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]))
-    assert "B64 x 4 s" in d["config"]["workload"] and d["roofline"]["traffic"] is None or "NOT measured" in d["roofline"]["traffic_source"]
+def test_bench_default_line_is_on_the_metrics_shape_and_carries_configs1_and_train():
+    """the driver's one command: primary workload = the shape BASELINE's metric names (B 256 x 512-frame utterances), with
+    BASELINE configs[1] (`configs1`), configs[2] on the north-star composition (`train`: fp16 operands under the device-side
+    dynamic loss scale, no skipped step inside its timed steps) and the attention kernel alone (`headline`) as sub-records;
+    the roof of the dominant family is chosen per launch"""
+    d = _json_line(_run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--train-batch", "16",
+                         "--train-steps", "2", "--train-warmup", "1"]))
+    assert "B256 x 512-frame" in d["config"]["workload"] and d["config"]["frames_per_utt"] == 512
+    assert abs(d["value"] - 256 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert d["roofline"]["traffic"] is None or "NOT measured" in d["roofline"]["traffic_source"]
     assert sum(d["breakdown_ms_per_step"].values()) <= 1.1 * d["single_pass_ms_per_step"]
-    h = d["headline"]
-    assert "B256 x 512-frame" in h["workload"] and h["frames_per_s"] > 1e6
-    a = h["attention"]
+    r = d["roofline"]
+    assert "per launch" in r["roof_choice"] and 0 < r["roofline_time_frac"] <= 1 and r["family_launches"] >= r["launches"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    a = d["headline"]["attention"]
     assert a["operands"] == "bf16" and a["tflops"] > 300 and abs(a["frac_bf16_mfma_peak"] - a["tflops"] / 2500.0) < 1e-9
+    assert len(a["window_avg_ms"]) == 5
+    c = d["configs1"]
+    assert "B64 x 4 s" in c["workload"] and c["frames_per_s"] > 1e6 and c["roofline"]["frac"] > 0
+    assert "T801" in c["attention"]["shape"] and c["attention"]["tflops"] > 100
+    t = d["train"]
+    assert "B256 x 4 s" in t["workload"] and t["batch_per_gpu"] == 16 and t["steps"] == 2
+    assert t["applied_steps_in_timed_region"] == 2 and t["loss_scale"]["skipped_in_timed_region"] == 0
+    assert 0 < t["loss_scale"]["scale"] <= 65536.0 and "dynamic loss scale" in t["dtype"]
+    assert abs(t["frames_per_s"] - 16 * 801 / (t["ms_per_step"] * 1e-3)) < 1e-3 * t["frames_per_s"]
+    assert t["roofline"]["bound"] in ("hbm", "mfma") and 0 < t["roofline"]["frac"] <= 1 and math.isfinite(t["final_loss"])
+    assert not t["optimizer_state"]["skipped"]
+
+
+def test_bench_refuses_to_time_with_a_variant_override():
+    e = dict(os.environ)
+    e["SFM_GEMM_VARIANT"] = "9"
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "c1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-sustained"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "variant override" in (r.stderr + r.stdout)
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
@@ -97,9 +123,10 @@ def test_bench_default_two_ranks_carry_the_dp_train_record():
     env = {"SFM_SINGLE_DEVICE": "1", "SFM_DIST_BACKEND": "gloo"}
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-headline",
-                "--dp-batch", "4", "--dp-steps", "2", "--dp-warmup", "1"], env)
+                "--configs1-batch", "2", "--dp-batch", "4", "--dp-steps", "2", "--dp-warmup", "1"], env)
     d = _json_line(out)
-    assert all(k in d for k in REQUIRED) and d["n_gpus"] == 2 and "B64 x 4 s" in d["config"]["workload"]
+    assert all(k in d for k in REQUIRED) and d["n_gpus"] == 2 and "B256 x 512-frame" in d["config"]["workload"]
+    assert "train" not in d and "B64 x 4 s" in d["configs1"]["workload"]
     assert "no data-path collective" in d["config"]["sharding"]
     s = d["sustained"]
     # (two timed steps of two ranks sharing one card: the ratio to the timed region is only checked for sanity)
@@ -109,4 +136,5 @@ def test_bench_default_two_ranks_carry_the_dp_train_record():
     assert t["allreduce_bytes_per_step"] > 20e6 and t["allreduce_buckets"] >= 2          # SpeechEnhancer: 24.9 MB of fp32 gradients
     assert t["ms_per_step"] > 0 and abs(t["frames_per_s"] - 2 * 4 * 801 / (t["ms_per_step"] * 1e-3)) < 1e-3 * t["frames_per_s"]
     assert t["exposed_allreduce_ms_per_step"] is not None and 0 <= t["exposed_allreduce_ms_per_step"] <= t["ms_per_step"]
-    assert t["optimizer_state"]["step"] == 3 and not t["optimizer_state"]["skipped"]
+    assert t["applied_steps_in_timed_region"] == 2 and not t["optimizer_state"]["skipped"]
+    assert t["loss_scale"]["skipped_in_timed_region"] == 0
