@@ -227,9 +227,14 @@ int sfm_framed_gemm_split16(const float* sig, const void* Whi, const void* Wlo, 
                             int Ls, long long sig_batch_stride, int hop, int padl, int K, int Kpad, int N, int Npad,
                             int nsplit, int col2_off, long long o_batch_stride, long long ldm, int mode, void* stream);
 /* Forward of the training objective (training/conformer_pipeline.py:52-108, 539-572): reductions in fp64.
- * S buffers must be zero-filled by the caller (kernels accumulate with f64 atomics). */
-int sfm_wave_moments(const float* est, const float* tgt, double* S, int B, int L, void* stream);
-int sfm_spec_sums(const float* pr, const float* pi, const float* tr, const float* ti, double* S, long long n,
+ * S buffers must be zero-filled by the caller (the kernels accumulate into them).
+ * ORDERED REDUCTIONS (every entry point of the training step that sums over workgroups takes an optional workspace `ws`): with
+ * it, each workgroup writes its partial into ws and a second pass folds the partials in workgroup order - the step is then
+ * bit-reproducible, like the reference's CPU step (training/conformer_pipeline.py:496-532); ws == NULL selects fp32 / f64
+ * atomics.  Sizes: sfm_*_ws_floats, or as stated; ws contents are scratch (destroyed), 16-byte aligned.
+ * here: ws >= 64 * B * 5 doubles (wave_moments), >= 2048 * 4 doubles (spec_sums). */
+int sfm_wave_moments(const float* est, const float* tgt, double* S, int B, int L, double* ws, void* stream);
+int sfm_spec_sums(const float* pr, const float* pi, const float* tr, const float* ti, double* S, long long n, double* ws,
                   void* stream);
 int sfm_enhancer_loss_finalize(const double* Sw, const double* Sm, const double* Sr, const long long* nr, int B,
                                int L, long long n_mag, int R, float* out, void* stream);
@@ -276,7 +281,8 @@ int sfm_sinc_wgrad(const float* x, const void* dy, int dy_f32, float* dfilt, flo
  * 251..255 are scratch), dW zeroed by the caller. */
 long long sfm_sinc_shift_len(int L);
 int sfm_sinc_shift_pack(const float* x, void* xs, int B, int L, int dtype, void* stream);
-int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, void* stream);
+int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, float* ws, long long ws_floats,
+                     void* stream);                       /* ws: sfm_tn_ws_floats(B * L, C, 256) */
 /* Backward of the PerceptionAgent's GroupNorm nodes out = act(GN(x1) [+ GN(x2)]) (agents/perception.py:121-129, 157,
  * 192-206), channels-last [B, L, C], C a power of two in [64, 2048].  sc / sh [B, C] fp32: the forward's scale and shift;
  * mean / rstd [B, G].  reduce: S [B][3][C] += { sum dp, sum dp xhat1, sum dp xhat2 } with dp = dout * act'(p) (S zeroed by
@@ -285,8 +291,10 @@ int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, in
 int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
                       const float* mean1, const float* rstd1, const void* x2, int x2_f32, const float* sc2,
                       const float* sh2, const float* mean2, const float* rstd2, float* S, int B, int L, int C, int G,
-                      int act, int dtype, void* stream);
-int sfm_gn_bwd_coefs(const float* S, const float* gamma1, const float* rstd1, const float* gamma2, const float* rstd2,
+                      int act, int dtype, float* ws, void* stream);
+long long sfm_gn_bwd_reduce_ws_floats(int B, int L, int C);
+/* (S is DESTROYED: after the coefficient tables it is the scratch of the ordered fold over b that produces dparam) */
+int sfm_gn_bwd_coefs(float* S, const float* gamma1, const float* rstd1, const float* gamma2, const float* rstd2,
                      float* coef1, float* coef2, float* dparam, int B, int L, int C, int G, void* stream);
 int sfm_gn_bwd_apply(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
                      const float* mean1, const float* rstd1, const float* coef1, void* dx1, int dx1_f32, const void* x2,
@@ -315,7 +323,7 @@ int sfm_vq_backward(const float* x, const long long* idx, const float* centroids
 /* Optimiser step (training/conformer_pipeline.py:424-429 AdamW, :509 NaN/Inf skip, :514 clip_grad_norm_) on flat fp32
  * buffers.  ctl = 8 doubles: [0] step count, [1] sum of squares (sfm_sumsq accumulates; zeroed by the step), [2] flag > 0
  * forces a skip, [3] applied gradient scale, [4] skipped (0/1), [5],[6] bias corrections, [7] gradient norm. */
-int sfm_sumsq(const float* g, long long n, double* out, void* stream);
+int sfm_sumsq(const float* g, long long n, double* out, double* ws, void* stream);        /* ws: >= 2048 doubles */
 int sfm_adamw_step(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1, float beta2,
                    float eps, float wd, float inv_scale, float max_norm, int write_back_grad, void* stream);
 /* Same, leaving alone - p, m and v - the parameters that received no gradient in this step (torch.optim.AdamW skips a
@@ -336,32 +344,39 @@ int sfm_adamw_step_scaled(float* p, float* g, float* m, float* v, long long n, d
                           const float* touched, int n_params, float* loss_scale, float growth_factor, float backoff_factor,
                           int growth_interval, void* stream);
 /* ---- training path of the ConformerBlock (backward of models/conformer.py:28-151) ---- */
-/* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; fp32 accumulate with atomics, zero dW first); db (optional):
- * db[n] += sum_m G[m,n] in the same launch; sfm_colsum = the stand-alone bias gradient */
+/* dW[n,k] += sum_m G[m,n] X[m,k] (weight gradient; M is split over workgroups: with ws (>= sfm_tn_ws_floats(M, N, K) floats) every
+ * split writes its partial [N][K] and the partials are added to dW in split order, without ws by fp32 atomics; zero dW first);
+ * db (optional): db[n] += sum_m G[m,n] in the same launch; sfm_colsum = the stand-alone bias gradient */
+long long sfm_tn_ws_floats(int M, int N, int K);
 int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw,
-                  int dtype, void* stream);
+                  int dtype, float* ws, long long ws_floats, void* stream);
 /* Conv1d weight gradient (training of agents/perception.py:121-129, 160-188 convs): G = dY [B*Lout, N] 16-bit, x
  * [B, Lin, Cin] channels-last 16-bit, dW [N, ksize*Cin] tap-major fp32 += G^T im2col(x) with the im2col rows addressed
  * in place (zero padding by range check); db (optional) += column sums of G. */
 int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* db, int B, int Lout, int Lin, int Cin, int N, int ksize,
-                     int stride, int pad, long long x_batch_stride, int ldg, int ldw, int dtype, void* stream);
-int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream);
+                     int stride, int pad, long long x_batch_stride, int ldg, int ldw, int dtype, float* ws, long long ws_floats,
+                     void* stream);                       /* ws: sfm_tn_ws_floats(B * Lout, N, ksize * Cin) */
+long long sfm_colsum_ws_floats(int M, int N);
+int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, float* ws, void* stream);
+/* LayerNorm backward; ws (optional, sfm_layernorm_bwd_ws_floats(M, D) floats): ordered dgamma / dbeta */
+long long sfm_layernorm_bwd_ws_floats(int M, int D);
 int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
-                      float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream);
+                      float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, float* ws, void* stream);
 /* the same with dy in the 16-bit format `dtype` (dy_16 != 0) and its own row stride ldy; ld = row stride of dres and dx */
 int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
                          float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
-                         void* stream);
+                         float* ws, void* stream);
 /* the same, also writing next16 [M, D] (format `dtype`, contiguous rows) = next_alpha * dropout(dx; next_p, next_seed) with the
  * counters of sfm_ew_train mode 4: the 16-bit operand the next backward node of the residual chain starts from */
 int sfm_layernorm_bwd_next(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
                            float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
-                           void* next16, float next_alpha, float next_p, unsigned int next_seed, void* stream);
+                           void* next16, float next_alpha, float next_p, unsigned int next_seed, float* ws, void* stream);
 /* mode 0 swish fwd, 1 swish bwd, 2 GLU fwd, 3 GLU bwd, 4 alpha*g*dropout; counter-based dropout (p, seed) */
 int sfm_ew_train(const void* z, const void* g, void* out, long long M, int N, int mode, int g_f32, int out_f32,
                  float alpha, float p, unsigned int seed, int dtype, void* stream);
-/* BatchNorm1d training statistics / backward (through the following Swish) */
-int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C,
+/* BatchNorm1d training statistics / backward (through the following Swish); ws (optional): sfm_col_stats_ws_floats(M, C) floats */
+long long sfm_col_stats_ws_floats(int M, int C);
+int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C, float* ws,
                   void* stream);
 /* gradient fan-in: out[m, c] = a[m, c] + (c < Cb ? b[m, c] : 0), fp32 rows with strides lda / ldb / ldo (C, Cb multiples of 4) */
 int sfm_add_cols(const float* a, const float* b, float* out, long long M, int C, int Cb, long long lda, long long ldb, long long ldo,
@@ -376,7 +391,7 @@ int sfm_bn_finalize(const float* S, const float* gamma, const float* beta, float
                     void* stream);
 int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float* S, float* dy, int M, int C, int g_f32, int pass, int dtype,
-                     void* stream);
+                     float* ws, void* stream);             /* ws: as sfm_col_stats (pass 0 only) */
 /* depthwise-conv weight/bias gradient: per-(utterance, span) partial sums go to `scratch`
  * (sfm_dwconv_wgrad_scratch_floats floats, need not be zeroed) and are reduced into dw [C, KS] / db [C] (accumulated). */
 long long sfm_dwconv_wgrad_scratch_floats(int B, int T, int C, int KS);
@@ -403,9 +418,11 @@ int sfm_memory_fwd(const float* emb, const float* params, float* bias_out, float
                    float* sim_out, int B, int key_dim, int value_dim, int slots, float temperature, void* stream);
 /* Backward of sfm_memory_fwd (EpisodicMemory in train() mode): d_out = gradient of the gated bias [B, value_dim], d_gate = of
  * the gate [B] (or NULL); d_emb [B, key_dim] (or NULL) and dparams = a ZERO-FILLED blob with the layout of `params`
- * (gradients of key_proj, keys, values, value_proj, gate are accumulated over the rows with fp32 atomics). */
+ * (gradients of key_proj, keys, values, value_proj, gate, accumulated over the rows: with ws - B x sfm_memory_param_floats floats -
+ * every row writes its own copy of the blob and the copies are folded in row order; ws == NULL: fp32 atomics). */
+long long sfm_memory_param_floats(int key_dim, int value_dim, int slots);
 int sfm_memory_bwd(const float* emb, const float* params, const float* d_out, const float* d_gate, float* d_emb,
-                   float* dparams, int B, int key_dim, int value_dim, int slots, float temperature, void* stream);
+                   float* dparams, int B, int key_dim, int value_dim, int slots, float temperature, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int M, int D, int ldx, int ldy, int ld,
                                                             float eps, u16* __restrict__ nxt, float nalpha, float np_,
-                                                            uint32_t nseed, int nfmt) {
+                                                            uint32_t nseed, int nfmt, float* __restrict__ ws) {
   // nxt (optional): the 16-bit operand the NEXT backward node starts from, nalpha * dropout(dx; np_, nseed) as [M, D] contiguous
   // rows (counter m * D + d, the one sfm_ew_train mode 4 uses) - that node's own pass over dx (read 4 B + write 2 B per
   // element, 24 launches per training step) is folded into this store.  nfmt: 1 bf16, 2 fp16.
@@ -158,8 +158,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += 256) {
-    atomicAdd(&dgamma[d], red[0][0][d] + red[1][0][d] + red[2][0][d] + red[3][0][d]);
-    atomicAdd(&dbeta[d], red[0][1][d] + red[1][1][d] + red[2][1][d] + red[3][1][d]);
+    const float sg = red[0][0][d] + red[1][0][d] + red[2][0][d] + red[3][0][d];
+    const float sb = red[0][1][d] + red[1][1][d] + red[2][1][d] + red[3][1][d];
+    if (ws) {                                                // this workgroup's partial row [dgamma | dbeta]: folded in block order
+      ws[(long long)blockIdx.x * 2 * D + d] = sg;
+      ws[(long long)blockIdx.x * 2 * D + D + d] = sb;
+    } else {
+      atomicAdd(&dgamma[d], sg);
+      atomicAdd(&dbeta[d], sb);
+    }
   }
 }
 #undef LN_COL
@@ -167,8 +174,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // dy_16: 0 = dy fp32, 1 = dy in the 16-bit format `dtype`; ldy = row stride of dy (elements), ld = row stride of dres and dx
 static int layernorm_bwd_go(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
                             float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
-                            void* next16, float next_alpha, float next_p, unsigned int next_seed, void* stream) {
+                            void* next16, float next_alpha, float next_p, unsigned int next_seed, float* ws, void* stream) {
   if (!x || !gamma || !dy || !dx || !dgamma || !dbeta) return SFM_ERR_ARG;
+  if (ws && (((uintptr_t)ws) % 16) != 0) return SFM_ERR_ARG;
   if (M <= 0 || D <= 0 || D > 512) return SFM_ERR_SHAPE;
   if (next16 && (next_p < 0.f || next_p >= 1.f || ((uintptr_t)next16 % 8) != 0)) return SFM_ERR_SHAPE;
   u16* nxt = (u16*)next16;
@@ -181,34 +189,44 @@ static int layernorm_bwd_go(const float* x, const float* gamma, const void* dy, 
                    ((((uintptr_t)x | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0) && (((uintptr_t)dy) % (4 * dyb)) == 0;
   const int f = dy_16 ? (dtype == SFM_DT_F16 ? 2 : 1) : 0;
   hipStream_t st = (hipStream_t)stream;
-#define LNB_GO2(V, F, H) SFM_LAUNCH((layernorm_bwd_kernel<V, F, H, LNB_R>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, nxt, next_alpha, next_p, next_seed, nfmt)
+#define LNB_GO2(V, F, H) SFM_LAUNCH((layernorm_bwd_kernel<V, F, H, LNB_R>), dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, nxt, next_alpha, next_p, next_seed, nfmt, ws)
 #define LNB_GO(V, F) do { if (D <= 256) LNB_GO2(V, F, 1); else LNB_GO2(V, F, 2); } while (0)
   if (vec) { if (f == 0) LNB_GO(true, 0); else if (f == 1) LNB_GO(true, 1); else LNB_GO(true, 2); }
   else { if (f == 0) LNB_GO(false, 0); else if (f == 1) LNB_GO(false, 1); else LNB_GO(false, 2); }
 #undef LNB_GO
 #undef LNB_GO2
-  return SFM_OK;
+  return ws ? sfm_fold_partials2(ws, dgamma, dbeta, D, 2 * D, nb, 1, stream) : SFM_OK;
+}
+
+// floats of the optional workspace `ws` of the three entry points below: with it, dgamma / dbeta are accumulated from one partial
+// row per workgroup folded in a fixed order (bit-reproducible); without it (NULL), with fp32 atomics
+extern "C" long long sfm_layernorm_bwd_ws_floats(int M, int D) {
+  long long nb = ((long long)M + 7) / 8;
+  if (nb > 1024) nb = 1024;
+  return nb * 2 * (D > 0 ? D : 0);
 }
 
 extern "C" int sfm_layernorm_bwd_ex(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
                                     float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
-                                    void* stream) {
-  return layernorm_bwd_go(x, gamma, dy, dy_16, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, dtype, nullptr, 1.f, 0.f, 0u, stream);
+                                    float* ws, void* stream) {
+  return layernorm_bwd_go(x, gamma, dy, dy_16, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, dtype, nullptr, 1.f, 0.f, 0u, ws,
+                          stream);
 }
 
 // the same, also writing next16 [M, D] (16-bit format `dtype`, contiguous) = next_alpha * dropout(dx; next_p, next_seed) with the
 // counters of sfm_ew_train mode 4 (m * D + d): the operand the next backward node of a residual chain starts from
 extern "C" int sfm_layernorm_bwd_next(const float* x, const float* gamma, const void* dy, int dy_16, const float* dres, float* dx,
                                       float* dgamma, float* dbeta, int M, int D, int ldx, int ldy, int ld, float eps, int dtype,
-                                      void* next16, float next_alpha, float next_p, unsigned int next_seed, void* stream) {
+                                      void* next16, float next_alpha, float next_p, unsigned int next_seed, float* ws,
+                                      void* stream) {
   if (!next16) return SFM_ERR_ARG;
   return layernorm_bwd_go(x, gamma, dy, dy_16, dres, dx, dgamma, dbeta, M, D, ldx, ldy, ld, eps, dtype, next16, next_alpha, next_p,
-                          next_seed, stream);
+                          next_seed, ws, stream);
 }
 
 extern "C" int sfm_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
-                                 float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, void* stream) {
-  return sfm_layernorm_bwd_ex(x, gamma, dy, 0, dres, dx, dgamma, dbeta, M, D, ldx, ld, ld, eps, SFM_DT_BF16, stream);
+                                 float* dgamma, float* dbeta, int M, int D, int ldx, int ld, float eps, float* ws, void* stream) {
+  return sfm_layernorm_bwd_ex(x, gamma, dy, 0, dres, dx, dgamma, dbeta, M, D, ldx, ld, ld, eps, SFM_DT_BF16, ws, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -417,7 +435,8 @@ extern "C" int sfm_ew_train(const void* z, const void* g, void* out, long long M
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, const float* __restrict__ aux,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        float* __restrict__ S, int M, int C, int rows_per_block) {
+                                                        float* __restrict__ S, int M, int C, int rows_per_block,
+                                                        float* __restrict__ ws) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
@@ -436,8 +455,13 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
       s1 += d * (aux[(long long)m * C + c] - mu) * rs;
     }
   }
-  atomicAdd(&S[2 * c], s0);
-  atomicAdd(&S[2 * c + 1], s1);
+  if (ws) {
+    ws[(long long)blockIdx.y * 2 * C + 2 * c] = s0;
+    ws[(long long)blockIdx.y * 2 * C + 2 * c + 1] = s1;
+  } else {
+    atomicAdd(&S[2 * c], s0);
+    atomicAdd(&S[2 * c + 1], s1);
+  }
 }
 
 // Vector form (C % 4 == 0, C / 4 divides 256): a thread owns 4 neighbouring columns (16-byte loads) and one of 1024 / C row lanes
@@ -445,7 +469,8 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
 // 4-byte loads, 256 dependent trips: 1.5 TB/s on [205 056, 256].)
 __global__ __launch_bounds__(256) void col_stats_vec_kernel(const float* __restrict__ y, const float* __restrict__ aux,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ S, int M, int C, int rows_per_block) {
+                                                            float* __restrict__ S, int M, int C, int rows_per_block,
+                                                            float* __restrict__ ws) {
   __shared__ float red[2048];                            // [row lane][2][C]
   const int nv = C >> 2, rl = 256 / nv;
   const int tv = threadIdx.x % nv, tr = threadIdx.x / nv, c0 = tv * 4;
@@ -481,24 +506,31 @@ __global__ __launch_bounds__(256) void col_stats_vec_kernel(const float* __restr
     float a = 0.f;
     for (int r = 0; r < rl; ++r) a += red[r * 2 * C + i];
     const int k = i / C, c = i - k * C;
-    atomicAdd(&S[2 * c + k], a);
+    if (ws) ws[(long long)blockIdx.x * 2 * C + 2 * c + k] = a;
+    else atomicAdd(&S[2 * c + k], a);
   }
 }
 
+// floats of the optional workspace of sfm_col_stats and of pass 0 of sfm_bn_swish_bwd (one partial row [C][2] per row block,
+// folded in block order: bit-reproducible statistics; NULL = fp32 atomics)
+extern "C" long long sfm_col_stats_ws_floats(int M, int C) { return (long long)((M + 127) / 128 + 1) * 2 * (C > 0 ? C : 0); }
+
 extern "C" int sfm_col_stats(const float* y, const float* aux, const float* mean, const float* rstd, float* S, int M, int C,
-                             void* stream) {
+                             float* ws, void* stream) {
   if (!y || !S || (aux && (!mean || !rstd))) return SFM_ERR_ARG;
   if (M <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  if (ws && (((uintptr_t)ws) % 16) != 0) return SFM_ERR_ARG;
   if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 &&
       (((uintptr_t)y | (uintptr_t)aux | (uintptr_t)mean | (uintptr_t)rstd) % 16) == 0) {
     const int rpbv = 128;
-    SFM_LAUNCH(col_stats_vec_kernel, dim3((M + rpbv - 1) / rpbv), dim3(256), 0, (hipStream_t)stream, y, aux, mean, rstd, S, M, C, rpbv);
-    return SFM_OK;
+    SFM_LAUNCH(col_stats_vec_kernel, dim3((M + rpbv - 1) / rpbv), dim3(256), 0, (hipStream_t)stream, y, aux, mean, rstd, S, M, C, rpbv,
+               ws);
+    return ws ? sfm_fold_partials(ws, S, 1, 2 * C, 2 * C, (M + rpbv - 1) / rpbv, 1, stream) : SFM_OK;
   }
   const int rpb = 256;
   SFM_LAUNCH(col_stats_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, y, aux, mean,
-             rstd, S, M, C, rpb);
-  return SFM_OK;
+             rstd, S, M, C, rpb, ws);
+  return ws ? sfm_fold_partials(ws, S, 1, 2 * C, 2 * C, (M + rpb - 1) / rpb, 1, stream) : SFM_OK;
 }
 
 // Gradient fan-in of a tensor whose first Cb columns also fed a second consumer: out[m, c] = a[m, c] + (c < Cb ? b[m, c] : 0)
@@ -613,7 +645,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_kernel(const void* __restric
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ S, float* __restrict__ dy, int M, int C,
-                                                           int g_f32, int pass, int rows_per_block) {
+                                                           int g_f32, int pass, int rows_per_block, float* __restrict__ ws) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
@@ -632,8 +664,13 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_kernel(const void* __restric
     else dy[e] = ga * rs * (dt - a0 - xh * a1);
   }
   if (!pass) {
-    atomicAdd(&S[2 * c], s0);
-    atomicAdd(&S[2 * c + 1], s1);
+    if (ws) {
+      ws[(long long)blockIdx.y * 2 * C + 2 * c] = s0;
+      ws[(long long)blockIdx.y * 2 * C + 2 * c + 1] = s1;
+    } else {
+      atomicAdd(&S[2 * c], s0);
+      atomicAdd(&S[2 * c + 1], s1);
+    }
   }
 }
 
@@ -643,7 +680,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_vec_kernel(const void* __res
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ S, float* __restrict__ dy, int M, int C,
-                                                               int g_f32, int rows_per_block) {
+                                                               int g_f32, int rows_per_block, float* __restrict__ ws) {
   __shared__ float red[PASS ? 1 : 2048];
   const int nv = C >> 2, rl = 256 / nv;
   const int tv = threadIdx.x % nv, tr = threadIdx.x / nv, c0 = tv * 4;
@@ -690,37 +727,40 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_vec_kernel(const void* __res
       float a = 0.f;
       for (int r = 0; r < rl; ++r) a += red[r * 2 * C + i];
       const int k = i / C, c = i - k * C;
-      atomicAdd(&S[2 * c + k], a);
+      if (ws) ws[(long long)blockIdx.x * 2 * C + 2 * c + k] = a;
+      else atomicAdd(&S[2 * c + k], a);
     }
   }
 }
 
 extern "C" int sfm_bn_swish_bwd(const void* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, float* S, float* dy, int M, int C, int g_f32, int pass, int dtype,
-                                void* stream) {
+                                float* ws, void* stream) {
   if (!g || !y || !mean || !rstd || !gamma || !beta || !S || (pass && !dy)) return SFM_ERR_ARG;
   if (M <= 0 || C <= 0) return SFM_ERR_SHAPE;
+  if (pass) ws = nullptr;                                    // (only pass 0 reduces)
+  if (ws && (((uintptr_t)ws) % 16) != 0) return SFM_ERR_ARG;
   if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 &&
       (((uintptr_t)y | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)dy) % 16) == 0 &&
       ((uintptr_t)g % (g_f32 ? 16 : 8)) == 0) {
     const int rpbv = 128;
     dim3 gridv((M + rpbv - 1) / rpbv), blockv(256);
     hipStream_t st = (hipStream_t)stream;
-#define BNV_GO(T, P) SFM_LAUNCH((bn_swish_bwd_vec_kernel<T, P>), gridv, blockv, 0, st, g, y, mean, rstd, gamma, beta, S, dy, M, C, g_f32, rpbv)
+#define BNV_GO(T, P) SFM_LAUNCH((bn_swish_bwd_vec_kernel<T, P>), gridv, blockv, 0, st, g, y, mean, rstd, gamma, beta, S, dy, M, C, g_f32, rpbv, ws)
     if (dtype == SFM_DT_F16) { if (pass) BNV_GO(F16, 1); else BNV_GO(F16, 0); }
     else { if (pass) BNV_GO(BF16, 1); else BNV_GO(BF16, 0); }
 #undef BNV_GO
-    return SFM_OK;
+    return ws ? sfm_fold_partials(ws, S, 1, 2 * C, 2 * C, (int)gridv.x, 1, stream) : SFM_OK;
   }
   const int rpb = 256;
   dim3 grid((C + 255) / 256, (M + rpb - 1) / rpb), block(256);
   if (dtype == SFM_DT_F16)
     SFM_LAUNCH((bn_swish_bwd_kernel<F16>), grid, block, 0, (hipStream_t)stream, g, y, mean, rstd, gamma, beta, S, dy, M, C,
-               g_f32, pass, rpb);
+               g_f32, pass, rpb, ws);
   else
     SFM_LAUNCH((bn_swish_bwd_kernel<BF16>), grid, block, 0, (hipStream_t)stream, g, y, mean, rstd, gamma, beta, S, dy, M, C,
-               g_f32, pass, rpb);
-  return SFM_OK;
+               g_f32, pass, rpb, ws);
+  return ws ? sfm_fold_partials(ws, S, 1, 2 * C, 2 * C, (int)grid.y, 1, stream) : SFM_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -870,18 +910,32 @@ __global__ __launch_bounds__(256) void dwconv_wgrad31_lds_kernel(const u16* __re
   pp[(long long)KS * C] = sb;
 }
 
-// dw[c][k] += sum_parts part[p][k][c] ; db[c] += sum_parts part[p][KS][c]
-__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+// dw[c][k] += sum_parts part[p][k][c] ; db[c] += sum_parts part[p][KS][c], in a FIXED order (bit-reproducible): chunks of
+// `parts_per_block` consecutive partials (partial p at part + p * stride) are summed by one thread per element; final == 0: the chunk
+// sum replaces the chunk's first partial (in place), final == 1 (one chunk left): it is added to dw / db
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(float* __restrict__ part, float* __restrict__ dw,
                                                                   float* __restrict__ db, int nparts, int C, int KS,
-                                                                  int parts_per_block) {
+                                                                  int parts_per_block, long long stride, int final) {
   const int e = blockIdx.x * 256 + threadIdx.x;                 // e = k * C + c
   if (e >= (KS + 1) * C) return;
   const int p0 = blockIdx.y * parts_per_block, p1 = min(nparts, p0 + parts_per_block);
-  float s = 0.f;
-  for (int p = p0; p < p1; ++p) s += part[(long long)p * (KS + 1) * C + e];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = p0;
+  for (; p + 4 <= p1; p += 4) {
+    s0 += part[(long long)(p + 0) * stride + e];
+    s1 += part[(long long)(p + 1) * stride + e];
+    s2 += part[(long long)(p + 2) * stride + e];
+    s3 += part[(long long)(p + 3) * stride + e];
+  }
+  for (; p < p1; ++p) s0 += part[(long long)p * stride + e];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (!final) {
+    part[(long long)p0 * stride + e] = s;
+    return;
+  }
   const int k = e / C, c = e - k * C;
-  if (k < KS) atomicAdd(&dw[c * KS + k], s);
-  else atomicAdd(&db[c], s);
+  if (k < KS) dw[c * KS + k] += s;
+  else db[c] += s;
 }
 
 extern "C" long long sfm_dwconv_wgrad_scratch_floats(int B, int T, int C, int KS) {
@@ -913,9 +967,16 @@ extern "C" int sfm_dwconv_wgrad(const void* x, const float* dy, float* dw, float
     else { if (KS == 31) GO(BF16, 31); else GO(BF16, 7); }
 #undef GO
   }
-  const int nparts = B * ny;
-  const int ppb = 64;
-  dim3 g2(((KS + 1) * C + 255) / 256, (nparts + ppb - 1) / ppb);
-  SFM_LAUNCH(dwconv_wgrad_reduce_kernel, g2, dim3(256), 0, st, scratch, dw, db, nparts, C, KS, ppb);
+  int nparts = B * ny;
+  const int ppb = 32;
+  long long stride = (long long)(KS + 1) * C;
+  while (true) {
+    const int final = nparts <= ppb;
+    dim3 g2(((KS + 1) * C + 255) / 256, final ? 1 : (nparts + ppb - 1) / ppb);
+    SFM_LAUNCH(dwconv_wgrad_reduce_kernel, g2, dim3(256), 0, st, scratch, dw, db, nparts, C, KS, ppb, stride, final);
+    if (final) break;
+    nparts = (int)g2.y;
+    stride *= ppb;
+  }
   return SFM_OK;
 }

@@ -26,7 +26,8 @@ struct TnConv {
 template <class T>
 __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
                                                         float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                        int K, int ldg, int ldx, int ldw, int rows_per_split, TnConv cv) {
+                                                        int K, int ldg, int ldx, int ldw, int rows_per_split, TnConv cv,
+                                                        float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) u16 Gs[64 * TN_ROW];
   __shared__ __attribute__((aligned(16))) u16 Xs[64 * TN_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,12 +167,19 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + mfma_row(r, lane);
-        if (n < N && k < K) atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+        if (n < N && k < K) {
+          // ws: this M-split's partial [N][K] (folded in split order by sfm_fold_partials: deterministic); else fp32 atomics
+          if (ws) ws[((long long)bz * N + n) * K + k] = acc[i][j][r];
+          else atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+        }
       }
     }
   if (do_bias) {
     const int n = n0 + (tid & 127);
-    if (n < N) atomicAdd(&db[n], bsum);
+    if (n < N) {
+      if (ws) ws[(long long)gridDim.z * N * K + (long long)bz * N + n] = bsum;
+      else atomicAdd(&db[n], bsum);
+    }
   }
 }
 
@@ -182,7 +190,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
 template <class T>
 __global__ __launch_bounds__(1024) void gemm16_tn_wide_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
                                                               float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                              int K, int ldg, int ldx, int ldw, int rows_per_split) {
+                                                              int K, int ldg, int ldx, int ldw, int rows_per_split,
+                                                              float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) u16 tn_smem[];
   u16* Gs = tn_smem;                                   // [2][64][TN_ROW]
   u16* Xs = tn_smem + 2 * 64 * TN_ROW;                 // [2][64][TN_ROW]
@@ -290,16 +299,20 @@ __global__ __launch_bounds__(1024) void gemm16_tn_wide_kernel(const u16* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + mfma_row(r, lane);
-        atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+        if (ws) ws[((long long)bz * N + n) * K + k] = acc[i][j][r];
+        else atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
       }
     }
-  if (do_bias && tid < 256) atomicAdd(&db[n0 + tid], bsum);
+  if (do_bias && tid < 256) {
+    if (ws) ws[(long long)gridDim.z * N * K + (long long)bz * N + n0 + tid] = bsum;
+    else atomicAdd(&db[n0 + tid], bsum);
+  }
 }
 
 // out[n] += sum_m G[m, n]   (bias gradient); G fp32 or 16-bit
 template <class T>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, float* __restrict__ out, int M, int N,
-                                                     int ldg, int g_f32, int rows_per_block) {
+                                                     int ldg, int g_f32, int rows_per_block, float* __restrict__ ws) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
@@ -311,13 +324,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G,
     const u16* g = reinterpret_cast<const u16*>(G);
     for (int m = m0; m < m1; ++m) s += T::to_f32(g[(long long)m * ldg + n]);
   }
-  atomicAdd(&out[n], s);
+  if (ws) ws[(long long)blockIdx.y * N + n] = s;
+  else atomicAdd(&out[n], s);
 }
 
 // vector form: 256 columns x 256 rows per workgroup, 16-byte loads, LDS reduction over the row lanes
 template <class T, int F32>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const void* __restrict__ G, float* __restrict__ out, int M, int N,
-                                                         int ldg) {
+                                                         int ldg, float* __restrict__ ws) {
   constexpr int VW = F32 ? 4 : 8;                 // columns per 16-byte load
   constexpr int TX = 256 / VW;                    // threads across the 256 columns
   constexpr int TY = 256 / TX;                    // row lanes
@@ -352,17 +366,39 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const void* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < TY; ++j) s += red[j][threadIdx.x];
-    atomicAdd(&out[n], s);
+    if (ws) ws[(long long)blockIdx.y * N + n] = s;
+    else atomicAdd(&out[n], s);
   }
 }
 
 // gemm16_tn2.hip: the LDS-DMA ring form (SFM_ERR_SHAPE = not a shape it takes)
 int sfm_tn2_launch(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw, int dtype,
-                   void* stream, const TnConv& cv, long long x_elems, int variant);
+                   void* stream, const TnConv& cv, long long x_elems, int variant, float* ws, long long ws_floats);
+
+// deterministic mode (ws != NULL): every M-split writes its partial dW [N][K] (+ db [N]) into ws and sfm_fold_partials adds the
+// partials to dW / db in split order.  An upper bound of the floats any of the kernels below needs for (M, N, K):
+extern "C" long long sfm_tn_ws_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const long long t128 = (long long)((N + 127) / 128) * ((K + 127) / 128), t256 = (long long)((N + 255) / 256) * ((K + 255) / 256);
+  long long s = 768 / t128;
+  if (256 / t256 > s) s = 256 / t256;
+  if (s < 1) s = 1;
+  const long long max_splits = (M + 255) / 256;
+  if (s > max_splits) s = max_splits;
+  return (s + 1) * ((long long)N * K + N);
+}
+
+// second pass of the deterministic mode
+int tn_fold(float* ws, float* dW, float* db, int N, int K, int ldw, int splits, void* stream) {
+  int rc = sfm_fold_partials(ws, dW, N, K, ldw, splits, 1, stream);
+  if (rc == SFM_OK && db) rc = sfm_fold_partials(ws + (long long)splits * N * K, db, 1, N, N, splits, 1, stream);
+  return rc;
+}
 
 static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw,
-                            int dtype, void* stream, TnConv cv, long long x_elems) {
+                            int dtype, void* stream, TnConv cv, long long x_elems, float* ws, long long ws_floats) {
   if (!G || !X || !dW) return SFM_ERR_ARG;
+  if (ws && (((uintptr_t)ws) % 16) != 0) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (ldg % 8) != 0 || (cv.Lout == 0 && (ldx % 8) != 0)) return SFM_ERR_SHAPE;
   // The LDS-DMA ring kernel (gemm16_tn2.hip) takes the Conv1d / sinc-FIR weight gradients (M = 1 .. 16 M im2col rows: 1.3-1.4x the first
   // kernel, profiles/README.md round 3); on the plain K = 256 / 1024 linears the 256 x 256-tile kernel below stays ahead.
@@ -370,7 +406,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
   static const int tn2 = getenv("SFM_TN2") ? atoi(getenv("SFM_TN2")) : -1;
   const bool tn2_auto = (tn2 < 0) && cv.Lout > 0;              // conv and the sinc bank's Toeplitz form (2.6 -> 1.8 ms at B 256 x 4 s)
   if ((tn2 > 0 || tn2_auto) && M >= 4096) {
-    const int rc = sfm_tn2_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv, x_elems, tn2 > 0 ? tn2 : 2);
+    const int rc = sfm_tn2_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv, x_elems, tn2 > 0 ? tn2 : 2, ws, ws_floats);
     if (rc != SFM_ERR_SHAPE) return rc;
   }
   static const int wide_on = getenv("SFM_TN_WIDE") ? atoi(getenv("SFM_TN_WIDE")) : 1;          // A/B knob
@@ -383,6 +419,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
     int rows = (M + splits - 1) / splits;
     rows = (rows + 63) / 64 * 64;
     splits = (M + rows - 1) / rows;
+    if (ws && (long long)splits * ((long long)N * K + N) > ws_floats) return SFM_ERR_ARG;
     dim3 grid(N / 256, K / 256, splits), block(1024);
     const size_t lds = 4 * 64 * TN_ROW * sizeof(u16);
     static bool attr_set_dev[64] = {false};        // hipFuncSetAttribute is per device
@@ -397,11 +434,11 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
     }
     if (dtype == SFM_DT_F16)
       SFM_LAUNCH((gemm16_tn_wide_kernel<F16>), grid, block, lds, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
-                 ldg, ldx, ldw, rows);
+                 ldg, ldx, ldw, rows, ws);
     else
       SFM_LAUNCH((gemm16_tn_wide_kernel<BF16>), grid, block, lds, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
-                 ldg, ldx, ldw, rows);
-    return SFM_OK;
+                 ldg, ldx, ldw, rows, ws);
+    return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, stream) : SFM_OK;
   }
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // 142 registers -> 3 workgroups per CU: aim at ONE full round of 768 resident workgroups (1024 was 1.3 rounds: the
@@ -414,32 +451,33 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
   int rows = (M + splits - 1) / splits;
   rows = (rows + 63) / 64 * 64;
   splits = (M + rows - 1) / rows;
+  if (ws && (long long)splits * ((long long)N * K + N) > ws_floats) return SFM_ERR_ARG;
   dim3 grid((N + 127) / 128, (K + 127) / 128, splits), block(256);
   if (dtype == SFM_DT_F16)
     SFM_LAUNCH((gemm16_tn_kernel<F16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
-               ldg, ldx, ldw, rows, cv);
+               ldg, ldx, ldw, rows, cv, ws);
   else
     SFM_LAUNCH((gemm16_tn_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
-               ldg, ldx, ldw, rows, cv);
-  return SFM_OK;
+               ldg, ldx, ldw, rows, cv, ws);
+  return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, stream) : SFM_OK;
 }
 
 // db (optional): bias gradient out[n] += sum_m G[m, n], computed from the G tiles the k-tile-0 workgroups stage anyway
 extern "C" int sfm_gemm16_tn(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx,
-                             int ldw, int dtype, void* stream) {
+                             int ldw, int dtype, float* ws, long long ws_floats, void* stream) {
   TnConv cv = {0, 0, 0, 0, 0, 0, 0};
-  return gemm16_tn_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv, (long long)(M - 1) * ldx + K);
+  return gemm16_tn_launch(G, X, dW, db, M, N, K, ldg, ldx, ldw, dtype, stream, cv, (long long)(M - 1) * ldx + K, ws, ws_floats);
 }
 
 // Conv1d weight gradient: G = dY [B*Lout, N] (16-bit), x [B, Lin, Cin] channels-last 16-bit;
 // dW [N, ksize*Cin] (tap-major, the layout of the packed conv weight) += sum_m G[m, n] * im2col(x)[m, k]
 extern "C" int sfm_conv_wgrad16(const void* G, const void* x, float* dW, float* db, int B, int Lout, int Lin, int Cin, int N,
                                 int ksize, int stride, int pad, long long x_batch_stride, int ldg, int ldw, int dtype,
-                                void* stream) {
+                                float* ws, long long ws_floats, void* stream) {
   if (B <= 0 || Lout <= 0 || Lin <= 0 || Cin <= 0 || (Cin % 8) != 0 || ksize <= 0 || stride <= 0) return SFM_ERR_SHAPE;
   TnConv cv = {Lout, Lin, Cin, stride, pad, x_batch_stride, 0};
   return gemm16_tn_launch(G, x, dW, db, B * Lout, N, ksize * Cin, ldg, 0, ldw, dtype, stream, cv,
-                          (long long)(B - 1) * x_batch_stride + (long long)Lin * Cin);
+                          (long long)(B - 1) * x_batch_stride + (long long)Lin * Cin, ws, ws_floats);
 }
 
 // Tap gradient of the sinc FIR bank (agents/perception.py:115-118 backward) on the matrix cores.
@@ -468,28 +506,33 @@ extern "C" int sfm_sinc_shift_pack(const float* x, void* xs, int B, int L, int d
   return SFM_OK;
 }
 
-extern "C" int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, void* stream) {
+extern "C" int sfm_sinc_wgrad16(const void* dy, const void* xs, float* dW, int B, int L, int C, int dtype, float* ws,
+                                long long ws_floats, void* stream) {
   if (B <= 0 || L <= 0 || C <= 0 || (C % 8) != 0 || (long long)B * L > 2000000000LL) return SFM_ERR_SHAPE;
   TnConv cv = {L, L, 1, 1, 128 - 125, sfm_sinc_shift_len(L), 1};
-  return gemm16_tn_launch(dy, xs, dW, nullptr, B * L, C, 256, C, 0, 256, dtype, stream, cv, (long long)B * 8 * sfm_sinc_shift_len(L));
+  return gemm16_tn_launch(dy, xs, dW, nullptr, B * L, C, 256, C, 0, 256, dtype, stream, cv, (long long)B * 8 * sfm_sinc_shift_len(L),
+                          ws, ws_floats);
 }
 
-extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, void* stream) {
+// ws (optional, >= sfm_colsum_ws_floats): one partial row per row-block, folded in block order (deterministic) instead of atomics
+extern "C" long long sfm_colsum_ws_floats(int M, int N) { return (long long)((M + 255) / 256 + 1) * (N > 0 ? N : 0); }
+
+extern "C" int sfm_colsum(const void* G, float* out, int M, int N, int ldg, int g_f32, int dtype, float* ws, void* stream) {
   if (!G || !out) return SFM_ERR_ARG;
   if (M <= 0 || N <= 0) return SFM_ERR_SHAPE;
   const int vw = g_f32 ? 4 : 8;
   if (N % vw == 0 && ldg % vw == 0 && ((uintptr_t)G % 16) == 0) {
     dim3 grid((N + 255) / 256, (M + 255) / 256), block(256);
-    if (g_f32) SFM_LAUNCH((colsum_vec_kernel<BF16, 1>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg);
-    else if (dtype == SFM_DT_F16) SFM_LAUNCH((colsum_vec_kernel<F16, 0>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg);
-    else SFM_LAUNCH((colsum_vec_kernel<BF16, 0>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg);
-    return SFM_OK;
+    if (g_f32) SFM_LAUNCH((colsum_vec_kernel<BF16, 1>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, ws);
+    else if (dtype == SFM_DT_F16) SFM_LAUNCH((colsum_vec_kernel<F16, 0>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, ws);
+    else SFM_LAUNCH((colsum_vec_kernel<BF16, 0>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, ws);
+    return ws ? sfm_fold_partials(ws, out, 1, N, N, (int)grid.y, 1, stream) : SFM_OK;
   }
   int rpb = 512;
   dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb), block(256);
   if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((colsum_kernel<F16>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, g_f32, rpb);
+    SFM_LAUNCH((colsum_kernel<F16>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, g_f32, rpb, ws);
   else
-    SFM_LAUNCH((colsum_kernel<BF16>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, g_f32, rpb);
-  return SFM_OK;
+    SFM_LAUNCH((colsum_kernel<BF16>), grid, block, 0, (hipStream_t)stream, G, out, M, N, ldg, g_f32, rpb, ws);
+  return ws ? sfm_fold_partials(ws, out, 1, N, N, (int)grid.y, 1, stream) : SFM_OK;
 }

@@ -31,7 +31,8 @@ template <class T, int WNW, int WKW, int STAGES>
 __global__ __launch_bounds__(WNW * WKW * 64) void gemm16_tn2_kernel(const u16* __restrict__ G, const u16* __restrict__ X,
                                                                     float* __restrict__ dW, float* __restrict__ db, int M, int N,
                                                                     int K, int ldg, int ldx, int ldw, int rows_per_split,
-                                                                    unsigned g_records, unsigned x_records, TnConv cv) {
+                                                                    unsigned g_records, unsigned x_records, TnConv cv,
+                                                                    float* __restrict__ ws) {
   constexpr int NW = WNW * WKW;
   constexpr int TNc = 64 * WNW, TKc = 64 * WKW;               // tile columns of G (n) and X (k)
   constexpr int GROW = TNc * 2, XROW = TKc * 2;                 // LDS row bytes
@@ -226,18 +227,26 @@ __global__ __launch_bounds__(WNW * WKW * 64) void gemm16_tn2_kernel(const u16* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + mfma_row(r, lane);
-        if (n < N && k < K) atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+        if (n < N && k < K) {
+          if (ws) ws[((long long)bz * N + n) * K + k] = acc[i][j][r];        // this M-split's partial (gemm16_tn.hip: tn_fold)
+          else atomicAdd(&dW[(long long)n * ldw + k], acc[i][j][r]);
+        }
       }
     }
   if (do_bias) {
     const int n = n0 + tid % TNc;
-    if (n < N) atomicAdd(&db[n], bsum);
+    if (n < N) {
+      if (ws) ws[(long long)gridDim.z * N * K + (long long)bz * N + n] = bsum;
+      else atomicAdd(&db[n], bsum);
+    }
   }
 }
 
+int tn_fold(float* ws, float* dW, float* db, int N, int K, int ldw, int splits, void* stream);
+
 template <class T, int WNW, int WKW, int STAGES>
 static int tn2_go(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw, unsigned g_rec,
-                  unsigned x_rec, hipStream_t st, const TnConv& cv, int n_cu) {
+                  unsigned x_rec, hipStream_t st, const TnConv& cv, int n_cu, float* ws, long long ws_floats) {
   constexpr int TNc = 64 * WNW, TKc = 64 * WKW;
   constexpr int lds = STAGES * 64 * (TNc + TKc) * 2;
   static bool attr_set_dev[64] = {false};                      // hipFuncSetAttribute is per device
@@ -259,15 +268,16 @@ static int tn2_go(const void* G, const void* X, float* dW, float* db, int M, int
   rows = (rows + 63) / 64 * 64;
   splits = (M + rows - 1) / rows;
   dim3 grid((N + TNc - 1) / TNc, (K + TKc - 1) / TKc, splits), block(WNW * WKW * 64);
+  if (ws && (long long)splits * ((long long)N * K + N) > ws_floats) return SFM_ERR_ARG;
   SFM_LAUNCH((gemm16_tn2_kernel<T, WNW, WKW, STAGES>), grid, block, lds, st, (const u16*)G, (const u16*)X, dW, db, M, N, K, ldg, ldx,
-             ldw, rows, g_rec, x_rec, cv);
-  return SFM_OK;
+             ldw, rows, g_rec, x_rec, cv, ws);
+  return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, (void*)st) : SFM_OK;
 }
 
 // called by gemm16_tn.hip's launcher; returns SFM_ERR_SHAPE when the shape is not one this kernel takes (the caller then
 // uses the first kernel).  variant: 1 = 128 x 128 tiles, 2 = 128 (n) x 256 (k) tiles.
 int sfm_tn2_launch(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw, int dtype,
-                   void* stream, const TnConv& cv, long long x_elems, int variant) {
+                   void* stream, const TnConv& cv, long long x_elems, int variant, float* ws, long long ws_floats) {
   if ((N % 8) != 0 || (K % 8) != 0 || (ldg % 8) != 0) return SFM_ERR_SHAPE;
   if (cv.Lout == 0 && (ldx % 8) != 0) return SFM_ERR_SHAPE;
   if (cv.Lout > 0 && !cv.toeplitz && (cv.Cin % 8) != 0) return SFM_ERR_SHAPE;
@@ -287,9 +297,9 @@ int sfm_tn2_launch(const void* G, const void* X, float* dW, float* db, int M, in
   hipStream_t st = (hipStream_t)stream;
   const unsigned gr = (unsigned)g_bytes, xr = (unsigned)x_bytes;
   if (variant == 2) {
-    if (dtype == SFM_DT_F16) return tn2_go<F16, 2, 4, 3>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu);
-    return tn2_go<BF16, 2, 4, 3>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu);
+    if (dtype == SFM_DT_F16) return tn2_go<F16, 2, 4, 3>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu, ws, ws_floats);
+    return tn2_go<BF16, 2, 4, 3>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu, ws, ws_floats);
   }
-  if (dtype == SFM_DT_F16) return tn2_go<F16, 2, 2, 4>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu);
-  return tn2_go<BF16, 2, 2, 4>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu);
+  if (dtype == SFM_DT_F16) return tn2_go<F16, 2, 2, 4>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu, ws, ws_floats);
+  return tn2_go<BF16, 2, 2, 4>(G, X, dW, db, M, N, K, ldg, ldx, ldw, gr, xr, st, cv, n_cu, ws, ws_floats);
 }

@@ -76,7 +76,8 @@ __device__ __forceinline__ void gn_load_regs(const GnIn& in, long long b, int c0
 // grid (row tiles, B); block 256 = (C/8 channel vectors) x (2048/C row lanes); C in {64, 128, 256, 512, 1024, 2048}
 template <class T, int TWO, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void* __restrict__ dout, int dout_f32, GnIn i1, GnIn i2,
-                                                            float* __restrict__ S, int L, int C, int G, int rows_per_block) {
+                                                            float* __restrict__ S, int L, int C, int G, int rows_per_block,
+                                                            float* __restrict__ ws) {
   extern __shared__ float red[];                       // [rl][3][C]
   const long long b = blockIdx.y;
   const int nv = C >> 3, rl = 256 / nv;
@@ -114,6 +115,16 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void* __restri
   }
   __syncthreads();
   const int nk = TWO ? 3 * C : 2 * C;
+  if (ws) {                                            // partial [row tile][B][3][C], folded over the row tiles in tile order
+    float* mine_ws = ws + ((long long)blockIdx.x * gridDim.y + b) * 3 * C;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) {
+      float a = 0.f;
+      if (i < nk)
+        for (int r = 0; r < rl; ++r) a += red[(long long)r * 3 * C + i];
+      mine_ws[i] = a;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < nk; i += 256) {
     float a = 0.f;
     for (int r = 0; r < rl; ++r) a += red[(long long)r * 3 * C + i];
@@ -121,12 +132,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void* __restri
   }
 }
 
-// grid B, block 256: coefficient tables + parameter gradients.  dparam [3][C] = dbeta, dgamma1, dgamma2 (zeroed by caller)
+// grid B, block 256: coefficient tables.  (The parameter gradients dparam [3][C] = dbeta, dgamma1, dgamma2 = sum_b S[b] are taken
+// afterwards by the ordered fold of reduce.hip - no atomics, the same bits on every run.)
 __global__ __launch_bounds__(256) void gn_bwd_coefs_kernel(const float* __restrict__ S, const float* __restrict__ gamma1,
                                                            const float* __restrict__ rstd1, const float* __restrict__ gamma2,
                                                            const float* __restrict__ rstd2, float* __restrict__ coef1,
-                                                           float* __restrict__ coef2, float* __restrict__ dparam, int B,
-                                                           int C, int G, float inv_n) {
+                                                           float* __restrict__ coef2, int B, int C, int G, float inv_n) {
   __shared__ float gs[4][256];                         // per group: A1, B1, A2, B2
   const long long b = blockIdx.x;
   const int cg = C / G;
@@ -148,14 +159,11 @@ __global__ __launch_bounds__(256) void gn_bwd_coefs_kernel(const float* __restri
     coef1[b * C + c] = r1 * gamma1[c];
     coef1[BC + b * C + c] = r1 * gs[0][g] * inv_n;
     coef1[2 * BC + b * C + c] = r1 * gs[1][g] * inv_n;
-    atomicAdd(&dparam[c], Sb[c]);
-    atomicAdd(&dparam[C + c], Sb[C + c]);
     if (gamma2) {
       const float r2 = rstd2[b * G + g];
       coef2[b * C + c] = r2 * gamma2[c];
       coef2[BC + b * C + c] = r2 * gs[2][g] * inv_n;
       coef2[2 * BC + b * C + c] = r2 * gs[3][g] * inv_n;
-      atomicAdd(&dparam[2 * C + c], Sb[2 * C + c]);
     }
   }
 }
@@ -226,8 +234,9 @@ static int gn_rows_per_block(int C) { return 8 * (2048 / C) > 256 ? 8 * (2048 / 
 extern "C" int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1, int x1_f32, const float* sc1, const float* sh1,
                                  const float* mean1, const float* rstd1, const void* x2, int x2_f32, const float* sc2,
                                  const float* sh2, const float* mean2, const float* rstd2, float* S, int B, int L, int C, int G,
-                                 int act, int dtype, void* stream) {
+                                 int act, int dtype, float* ws, void* stream) {
   if (!dout || !x1 || !sc1 || !sh1 || !mean1 || !rstd1 || !S) return SFM_ERR_ARG;
+  if (ws && (((uintptr_t)ws) % 16) != 0) return SFM_ERR_ARG;
   if (x2 && (!sc2 || !sh2 || !mean2 || !rstd2)) return SFM_ERR_ARG;
   if (!gn_shape_ok(B, L, C, G)) return SFM_ERR_SHAPE;
   const GnIn a = gn_in(x1, x1_f32, sc1, sh1, mean1, rstd1, nullptr, nullptr, 0);
@@ -236,16 +245,24 @@ extern "C" int sfm_gn_bwd_reduce(const void* dout, int dout_f32, const void* x1,
   dim3 grid((L + rpb - 1) / rpb, B), block(256);
   const size_t lds = (size_t)(2048 / C) * 3 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define GNR_GO(T, TWO, ACT) SFM_LAUNCH((gn_bwd_reduce_kernel<T, TWO, ACT>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, rpb)
+#define GNR_GO(T, TWO, ACT) SFM_LAUNCH((gn_bwd_reduce_kernel<T, TWO, ACT>), grid, block, lds, st, dout, dout_f32, a, c, S, L, C, G, rpb, ws)
 #define GNR_T(T) do { if (x2) { if (act) GNR_GO(T, 1, 1); else GNR_GO(T, 1, 0); } else { if (act) GNR_GO(T, 0, 1); else GNR_GO(T, 0, 0); } } while (0)
   if (dtype == SFM_DT_F16) GNR_T(F16); else GNR_T(BF16);
 #undef GNR_T
 #undef GNR_GO
-  return SFM_OK;
+  return ws ? sfm_fold_partials(ws, S, B, 3 * C, 3 * C, (int)grid.x, 1, stream) : SFM_OK;
 }
 
-// coef1 / coef2: [3][B][C] fp32 (a, b, c);  dparam: [3][C] fp32 = dbeta, dgamma1, dgamma2, zero-filled by the caller
-extern "C" int sfm_gn_bwd_coefs(const float* S, const float* gamma1, const float* rstd1, const float* gamma2,
+// floats of the optional workspace of sfm_gn_bwd_reduce (one partial [B][3][C] per row tile, folded in tile order; NULL = atomics)
+extern "C" long long sfm_gn_bwd_reduce_ws_floats(int B, int L, int C) {
+  if (B <= 0 || L <= 0 || C < 64 || C > 2048) return 0;
+  const int rpb = gn_rows_per_block(C);
+  return (long long)((L + rpb - 1) / rpb + 1) * B * 3 * C;
+}
+
+// coef1 / coef2: [3][B][C] fp32 (a, b, c);  dparam: [3][C] fp32 = dbeta, dgamma1, dgamma2, zero-filled by the caller (+=).
+// S [B][3][C] is DESTROYED: after the coefficient tables it is the scratch of the ordered fold over b that produces dparam.
+extern "C" int sfm_gn_bwd_coefs(float* S, const float* gamma1, const float* rstd1, const float* gamma2,
                                 const float* rstd2, float* coef1, float* coef2, float* dparam, int B, int L, int C, int G,
                                 void* stream) {
   if (!S || !gamma1 || !rstd1 || !coef1 || !dparam) return SFM_ERR_ARG;
@@ -253,8 +270,8 @@ extern "C" int sfm_gn_bwd_coefs(const float* S, const float* gamma1, const float
   if (!gn_shape_ok(B, L, C, G)) return SFM_ERR_SHAPE;
   const float inv_n = 1.0f / ((float)L * (float)(C / G));
   SFM_LAUNCH(gn_bwd_coefs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, gamma1, rstd1, gamma2, rstd2, coef1, coef2,
-             dparam, B, C, G, inv_n);
-  return SFM_OK;
+             B, C, G, inv_n);
+  return sfm_fold_partials(S, dparam, 1, 3 * C, 3 * C, B, 1, stream);      // (third block: zeros when there is no second input)
 }
 
 // dx1 / dx2: [B, L, C] 16-bit or fp32

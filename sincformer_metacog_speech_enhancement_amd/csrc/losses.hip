@@ -12,7 +12,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // per utterance b: S[b] = { sum e, sum t, sum e^2, sum t^2, sum e*t }   (accumulated with atomics: zero S first)
 __global__ __launch_bounds__(256) void wave_moments_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
-                                                           double* __restrict__ S, int L) {
+                                                           double* __restrict__ S, int L, double* __restrict__ ws) {
   __shared__ double red[4][5];
   const int b = blockIdx.y;
   const float* e = est + (long long)b * L;
@@ -29,14 +29,18 @@ __global__ __launch_bounds__(256) void wave_moments_kernel(const float* __restri
     if (lane == 0) red[wave][k] = s[k];
   }
   __syncthreads();
-  if (threadIdx.x < 5) atomicAdd(&S[b * 5 + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 5) {
+    const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (ws) ws[((long long)blockIdx.x * gridDim.y + b) * 5 + threadIdx.x] = v;       // partial [block][B][5], folded in block order
+    else atomicAdd(&S[b * 5 + threadIdx.x], v);
+  }
 }
 
 // spectra of prediction (pr, pi) and target (tr, ti), n bins each:
 // S = { sum (|T|-|P|)^2, sum |T|^2, sum |log(|P|+1e-8) - log(|T|+1e-8)|, sum |sqrt(P^2+1e-8) - sqrt(T^2+1e-8)| }
 __global__ __launch_bounds__(256) void spec_sums_kernel(const float* __restrict__ pr, const float* __restrict__ pi,
                                                         const float* __restrict__ tr, const float* __restrict__ ti,
-                                                        double* __restrict__ S, long long n) {
+                                                        double* __restrict__ S, long long n, double* __restrict__ ws) {
   __shared__ double red[4][4];
   double s[4] = {0, 0, 0, 0};
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -56,7 +60,11 @@ __global__ __launch_bounds__(256) void spec_sums_kernel(const float* __restrict_
     if (lane == 0) red[wave][k] = s[k];
   }
   __syncthreads();
-  if (threadIdx.x < 4) atomicAdd(&S[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 4) {
+    const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (ws) ws[(long long)blockIdx.x * 4 + threadIdx.x] = v;
+    else atomicAdd(&S[threadIdx.x], v);
+  }
 }
 
 // out[0] = total, out[1] = neg SI-SNR, out[2] = L1 magnitude, out[3] = MR-STFT
@@ -93,23 +101,26 @@ __global__ void enhancer_loss_finalize_kernel(const double* __restrict__ Sw, con
   out[3] = (float)mr;
 }
 
-extern "C" int sfm_wave_moments(const float* est, const float* tgt, double* S, int B, int L, void* stream) {
+// ws (optional; >= 64 * B * 5 doubles for sfm_wave_moments, >= 2048 * 4 doubles for sfm_spec_sums): one partial per workgroup,
+// folded in workgroup order by reduce.hip - the sums (and with them the loss value and its gradient) are then bit-reproducible;
+// NULL = f64 atomics
+extern "C" int sfm_wave_moments(const float* est, const float* tgt, double* S, int B, int L, double* ws, void* stream) {
   if (!est || !tgt || !S) return SFM_ERR_ARG;
   if (B <= 0 || L <= 0) return SFM_ERR_SHAPE;
   int nb = (L + 255) / 256;
   if (nb > 64) nb = 64;
-  SFM_LAUNCH(wave_moments_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, est, tgt, S, L);
-  return SFM_OK;
+  SFM_LAUNCH(wave_moments_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, est, tgt, S, L, ws);
+  return ws ? sfm_fold_partials_f64(ws, S, B, 5, 5, nb, 1, stream) : SFM_OK;
 }
 
 extern "C" int sfm_spec_sums(const float* pr, const float* pi, const float* tr, const float* ti, double* S, long long n,
-                             void* stream) {
+                             double* ws, void* stream) {
   if (!pr || !pi || !tr || !ti || !S) return SFM_ERR_ARG;
   if (n <= 0) return SFM_ERR_SHAPE;
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
-  SFM_LAUNCH(spec_sums_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pr, pi, tr, ti, S, n);
-  return SFM_OK;
+  SFM_LAUNCH(spec_sums_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pr, pi, tr, ti, S, n, ws);
+  return ws ? sfm_fold_partials_f64(ws, S, 1, 4, 4, (int)nb, 1, stream) : SFM_OK;
 }
 
 extern "C" int sfm_enhancer_loss_finalize(const double* Sw, const double* Sm, const double* Sr, const long long* nr, int B,

@@ -134,7 +134,9 @@ extern "C" int sfm_memory_fwd(const float* emb, const float* params, float* bias
 // Backward of the same function (training: EpisodicMemory in train() mode).  One workgroup per query row recomputes the
 // forward intermediates in LDS (the whole forward is ~0.4 MFLOP per row) and propagates
 //   d(bias * gate) [vd], d(gate) [1]  ->  d(emb) [kd]  and the gradient of every parameter,
-// accumulated over the rows with fp32 atomics into `dparams`, a zero-filled blob with the layout of `params`.
+// accumulated over the rows into `dparams`, a zero-filled blob with the layout of `params`: with a workspace every row writes its
+// own copy of the blob (each element exactly once, plain stores) and reduce.hip folds the rows in order - bit-reproducible, no
+// contention; without one, ~170 k fp32 atomics per row on the same addresses.
 // top_indices / similarity are not differentiable (agents/memory.py:136-146 uses them for bookkeeping only).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const float* d, float* y, int rows, int cols, int tid) {
@@ -145,22 +147,30 @@ __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const floa
     y[k] = acc;
   }
 }
-__device__ __forceinline__ void outer_atomic(float* __restrict__ dW, const float* d, const float* x, int rows, int cols, int tid) {
+// own != 0: dst is this row's private copy of the blob (store); else the shared blob (atomic add)
+__device__ __forceinline__ void mem_acc(float* dst, float v, int own) {
+  if (own) *dst = v;
+  else atomicAdd(dst, v);
+}
+__device__ __forceinline__ void outer_atomic(float* __restrict__ dW, const float* d, const float* x, int rows, int cols, int tid,
+                                             int own) {
   // dW[i][k] += d[i] x[k]
   for (int e = tid; e < rows * cols; e += 256) {
     const int i = e / cols, k = e - i * cols;
-    atomicAdd(dW + e, d[i] * x[k]);
+    mem_acc(dW + e, d[i] * x[k], own);
   }
 }
 
 __global__ __launch_bounds__(256) void memory_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ P,
                                                          const float* __restrict__ d_out, const float* __restrict__ d_gate,
-                                                         float* __restrict__ d_emb, float* __restrict__ dP, int kd, int vd, int S,
-                                                         float temperature) {
+                                                         float* __restrict__ d_emb, float* __restrict__ dP_shared, int kd, int vd,
+                                                         int S, float temperature, float* __restrict__ ws, long long n_params) {
   __shared__ float x[MEM_MAXD], t1[MEM_MAXD], xhat[MEM_MAXD], yv[MEM_MAXD], u[MEM_MAXD], q[MEM_MAXD], cosv[MEM_MAXD], knorm[MEM_MAXD],
       att[MEM_MAXD], ret[MEM_MAXD], tb[MEM_MAXD], da[MEM_MAXD], db[MEM_MAXD], dq[MEM_MAXD], red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
+  const int own = ws != nullptr;
+  float* dP = own ? ws + (long long)b * n_params : dP_shared;
   const long long oW0 = 0, ob0 = oW0 + (long long)kd * kd, olnw = ob0 + kd, olnb = olnw + kd, oW3 = olnb + kd,
                   ob3 = oW3 + (long long)kd * kd, okeys = ob3 + kd, ovals = okeys + (long long)S * kd,
                   oWv = ovals + (long long)S * vd, obv = oWv + (long long)vd * vd, oWg = obv + vd, obg = oWg + kd + vd;
@@ -249,20 +259,20 @@ __global__ __launch_bounds__(256) void memory_bwd_kernel(const float* __restrict
   const float dgate = (d_gate ? d_gate[b] : 0.f) + red[4] + red[5] + red[6] + red[7];
   const float dgpre = dgate * gate * (1.0f - gate);
   // value_proj: dWv += da (x) ret, dbv += da, d ret = Wv^T da (-> db[0..vd))
-  outer_atomic(dP + oWv, da, ret, vd, vd, tid);
-  for (int v = tid; v < vd; v += 256) atomicAdd(dP + obv + v, da[v]);
+  outer_atomic(dP + oWv, da, ret, vd, vd, tid, own);
+  for (int v = tid; v < vd; v += 256) mem_acc(dP + obv + v, da[v], own);
   matvec_t(Wv, da, db, vd, vd, tid);
   // gate: dWg += dgpre * [q | ret], dbg += dgpre, dq = dgpre * Wg[:kd], d ret += dgpre * Wg[kd:]
   for (int k = tid; k < kd; k += 256) {
-    atomicAdd(dP + oWg + k, dgpre * q[k]);
+    mem_acc(dP + oWg + k, dgpre * q[k], own);
     dq[k] = dgpre * Wg[k];
   }
   __syncthreads();
   for (int v = tid; v < vd; v += 256) {
-    atomicAdd(dP + oWg + kd + v, dgpre * ret[v]);
+    mem_acc(dP + oWg + kd + v, dgpre * ret[v], own);
     db[v] += dgpre * Wg[kd + v];
   }
-  if (tid == 0) atomicAdd(dP + obg, dgpre);
+  if (tid == 0) mem_acc(dP + obg, dgpre, own);
   __syncthreads();
   // ret = att @ values: d att[r] = <d ret, values[r]> (-> da[0..S)), dvalues[r] += att[r] d ret
   for (int r = wave; r < S; r += 4) {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) void memory_bwd_kernel(const float* __restrict
   }
   for (int e = tid; e < S * vd; e += 256) {
     const int r = e / vd, v = e - r * vd;
-    atomicAdd(dP + ovals + e, att[r] * db[v]);
+    mem_acc(dP + ovals + e, att[r] * db[v], own);
   }
   __syncthreads();
   // softmax: d sim[r] = att[r] (d att[r] - sum att d att); c[r] = d sim[r] / temperature -> da[r]
@@ -291,14 +301,14 @@ __global__ __launch_bounds__(256) void memory_bwd_kernel(const float* __restrict
     for (int r = 0; r < S; ++r) {
       const float kv = keys[(long long)r * kd + k];
       acc += da[r] * (kv / (qn * knorm[r]) - cosv[r] * q[k] / (qn * qn));
-      atomicAdd(dP + okeys + (long long)r * kd + k, da[r] * (q[k] / (qn * knorm[r]) - cosv[r] * kv / (knorm[r] * knorm[r])));
+      mem_acc(dP + okeys + (long long)r * kd + k, da[r] * (q[k] / (qn * knorm[r]) - cosv[r] * kv / (knorm[r] * knorm[r])), own);
     }
     dq[k] += acc;
   }
   __syncthreads();
   // q = W3 u + b3
-  outer_atomic(dP + oW3, dq, u, kd, kd, tid);
-  for (int k = tid; k < kd; k += 256) atomicAdd(dP + ob3 + k, dq[k]);
+  outer_atomic(dP + oW3, dq, u, kd, kd, tid, own);
+  for (int k = tid; k < kd; k += 256) mem_acc(dP + ob3 + k, dq[k], own);
   matvec_t(W3, dq, db, kd, kd, tid);                      // db = d u
   __syncthreads();
   // u = gelu(y), y = xhat * lnw + lnb, xhat = LayerNorm(t1)
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(256) void memory_bwd_kernel(const float* __restrict
     const float z = yv[i];
     const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
     const float dy = db[i] * (cdf + z * 0.39894228040143267794f * expf(-0.5f * z * z));
-    atomicAdd(dP + olnw + i, dy * xhat[i]);
-    atomicAdd(dP + olnb + i, dy);
+    mem_acc(dP + olnw + i, dy * xhat[i], own);
+    mem_acc(dP + olnb + i, dy, own);
     const float dxh = dy * lnw[i];
     da[i] = dxh;
     p1 += dxh;
@@ -328,21 +338,30 @@ __global__ __launch_bounds__(256) void memory_bwd_kernel(const float* __restrict
   for (int i = tid; i < kd; i += 256) dq[i] = rstd * (da[i] - s1 - xhat[i] * s2);      // dq = d t1
   __syncthreads();
   // t1 = W0 x + b0
-  outer_atomic(dP + oW0, dq, x, kd, kd, tid);
-  for (int k = tid; k < kd; k += 256) atomicAdd(dP + ob0 + k, dq[k]);
+  outer_atomic(dP + oW0, dq, x, kd, kd, tid, own);
+  for (int k = tid; k < kd; k += 256) mem_acc(dP + ob0 + k, dq[k], own);
   matvec_t(W0, dq, db, kd, kd, tid);
   __syncthreads();
   if (d_emb)
     for (int k = tid; k < kd; k += 256) d_emb[(long long)b * kd + k] = db[k];
 }
 
+extern "C" long long sfm_memory_param_floats(int kd, int vd, int S) {
+  return 2LL * kd * kd + 4LL * kd + (long long)S * kd + (long long)S * vd + (long long)vd * vd + vd + kd + vd + 1;
+}
+
+// ws (optional, >= B * sfm_memory_param_floats(key_dim, value_dim, slots) floats): per-row copies of the gradient blob, folded in row order
 extern "C" int sfm_memory_bwd(const float* emb, const float* params, const float* d_out, const float* d_gate, float* d_emb,
-                              float* dparams, int B, int key_dim, int value_dim, int slots, float temperature, void* stream) {
+                              float* dparams, int B, int key_dim, int value_dim, int slots, float temperature, float* ws,
+                              void* stream) {
   if (!emb || !params || !d_out || !dparams) return SFM_ERR_ARG;
+  if (ws && (((uintptr_t)ws) % 16) != 0) return SFM_ERR_ARG;
   if (B <= 0 || key_dim <= 0 || key_dim > MEM_MAXD || value_dim <= 0 || value_dim > MEM_MAXD || slots <= 0 ||
       slots > MEM_MAXD)
     return SFM_ERR_SHAPE;
+  const long long np_ = sfm_memory_param_floats(key_dim, value_dim, slots);
   SFM_LAUNCH(memory_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, params, d_out, d_gate, d_emb, dparams, key_dim,
-             value_dim, slots, temperature);
-  return SFM_OK;
+             value_dim, slots, temperature, ws, np_);
+  // (the blob is one row of np_ floats; the fold takes the scalar path when np_ is odd)
+  return ws ? sfm_fold_partials(ws, dparams, 1, (int)np_, np_, B, 1, stream) : SFM_OK;
 }

@@ -8,7 +8,8 @@
 
 // ctl layout (doubles): [0] step count  [1] sum of squares (input)  [2] flag (>0 -> skip; input)
 //                       [3] gscale (output)  [4] skip (output)  [5] bc1  [6] bc2  [7] grad norm after unscale (output)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ out,
+                                                    double* __restrict__ ws) {
   __shared__ double red[4];
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -19,7 +20,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    if (ws) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // folded in workgroup order: the same norm on every run
+    else atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  }
 }
 
 __global__ void adamw_prepare_kernel(double* __restrict__ ctl, double inv_scale, double max_norm, double beta1, double beta2) {
@@ -127,13 +131,14 @@ __global__ __launch_bounds__(256) void adamw_apply_kernel(float* __restrict__ p,
   }
 }
 
-extern "C" int sfm_sumsq(const float* g, long long n, double* out, void* stream) {
+// ws (optional, >= 2048 doubles): one partial per workgroup folded in workgroup order (reduce.hip) instead of an f64 atomic each
+extern "C" int sfm_sumsq(const float* g, long long n, double* out, double* ws, void* stream) {
   if (!g || !out) return SFM_ERR_ARG;
   if (n <= 0) return SFM_ERR_SHAPE;
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
-  SFM_LAUNCH(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, n, out);
-  return SFM_OK;
+  SFM_LAUNCH(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, n, out, ws);
+  return ws ? sfm_fold_partials_f64(ws, out, 1, 1, 1, (int)nb, 1, stream) : SFM_OK;
 }
 
 static int adamw_step_impl(float* p, float* g, float* m, float* v, long long n, double* ctl, float lr, float beta1,

@@ -205,3 +205,9 @@ __device__ __forceinline__ float wave_sum16_transpose(const float (&v)[16], int 
     if (hipGetLastError() != hipSuccess) return SFM_ERR_LAUNCH;                \
   } while (0)
 #define SFM_CHECK_LAUNCH() do { } while (0)
+
+// reduce.hip: the ordered second pass of the split reductions (deterministic training step).  ws [S][rows][cols] compact.
+// (ws is used as scratch by the multi-level fold: its contents are destroyed)
+int sfm_fold_partials(float* ws, float* out, long long rows, int cols, long long ldo, int S, int accumulate, void* stream);
+int sfm_fold_partials2(float* ws, float* out, float* out2, int cols1, int cols, int S, int accumulate, void* stream);
+int sfm_fold_partials_f64(double* ws, double* out, long long rows, int cols, long long ldo, int S, int accumulate, void* stream);

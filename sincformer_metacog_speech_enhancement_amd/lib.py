@@ -65,8 +65,8 @@ SIGNATURES = {
     "sfm_sinc_fir16_ex": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_framed_gemm_split16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll,
                                 c_ll, c_i, c_vp],
-    "sfm_wave_moments": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
-    "sfm_spec_sums": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp],
+    "sfm_wave_moments": [c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp],
+    "sfm_spec_sums": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp],
     "sfm_enhancer_loss_finalize": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_ll, c_i, c_vp, c_vp],
     "sfm_sisnr_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp],
     "sfm_spec_loss_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_ll, c_i, c_i, c_f, c_vp],
@@ -80,10 +80,10 @@ SIGNATURES = {
     "sfm_sinc_wgrad": [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_sinc_shift_len": [c_i],
     "sfm_sinc_shift_pack": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
-    "sfm_sinc_wgrad16": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_sinc_wgrad16": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_ll, c_vp],
     "sfm_gemm16_swish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_i, c_vp],
     "sfm_gn_bwd_reduce": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i,
-                          c_i, c_i, c_i, c_vp],
+                          c_i, c_i, c_i, c_vp, c_vp],
     "sfm_gn_bwd_coefs": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_gn_bwd_apply": [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp,
                          c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
@@ -92,24 +92,29 @@ SIGNATURES = {
     "sfm_maa_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_vp],
     "sfm_vq_forward": [c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_ll, c_vp],
     "sfm_vq_backward": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_vp],
-    "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp],
+    "sfm_sumsq": [c_vp, c_ll, c_vp, c_vp, c_vp],
     "sfm_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp],
     "sfm_adamw_step_masked": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_vp, c_i, c_vp],
     "sfm_adamw_step_scaled": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_vp, c_i, c_vp,
                               c_f, c_f, c_i, c_vp],
-    "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "sfm_conv_wgrad16": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_vp],
-    "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
-    "sfm_layernorm_bwd_ex": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp],
+    "sfm_tn_ws_floats": [c_i, c_i, c_i],
+    "sfm_colsum_ws_floats": [c_i, c_i],
+    "sfm_layernorm_bwd_ws_floats": [c_i, c_i],
+    "sfm_col_stats_ws_floats": [c_i, c_i],
+    "sfm_gn_bwd_reduce_ws_floats": [c_i, c_i, c_i],
+    "sfm_gemm16_tn": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_ll, c_vp],
+    "sfm_conv_wgrad16": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_vp, c_ll, c_vp],
+    "sfm_colsum": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
+    "sfm_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_vp],
+    "sfm_layernorm_bwd_ex": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_vp],
     "sfm_layernorm_bwd_next": [c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_f, c_f,
-                               ctypes.c_uint, c_vp],
+                               ctypes.c_uint, c_vp, c_vp],
     "sfm_ew_train": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_uint, c_i, c_vp],
-    "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "sfm_col_stats": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "sfm_add_cols": [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_ll, c_ll, c_ll, c_vp],
     "sfm_lstm_hprev16": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bn_finalize": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_f, c_f, c_i, c_vp],
-    "sfm_bn_swish_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_bn_swish_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "sfm_dwconv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_dwconv_wgrad_scratch_floats": [c_i, c_i, c_i, c_i],
     "sfm_attention_fwd_train": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_f, c_f,
@@ -120,7 +125,8 @@ SIGNATURES = {
     "sfm_bilstm_layer_train": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "sfm_memory_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
-    "sfm_memory_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
+    "sfm_memory_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_vp],
+    "sfm_memory_param_floats": [c_i, c_i, c_i],
 }
 
 _lib = None
@@ -146,7 +152,7 @@ def load():
         except AttributeError as e:
             raise HipExtensionMissing("symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.argtypes = args
-        fn.restype = c_ll if name.endswith("_scratch_floats") or name == "sfm_sinc_shift_len" else c_i
+        fn.restype = c_ll if name.endswith("_scratch_floats") or name.endswith("_ws_floats") or name in ("sfm_sinc_shift_len", "sfm_memory_param_floats") else c_i
     _lib = lib
     return lib
 

@@ -203,6 +203,37 @@ class KernelProfiler:
 
 profiler = KernelProfiler()
 
+# ---------------------------------------------------------------------------
+# ordered reductions: scratch for the per-workgroup partials
+# ---------------------------------------------------------------------------
+# Every split reduction of the training step (weight-gradient M-splits, bias column sums, LayerNorm / GroupNorm dgamma / dbeta,
+# BatchNorm statistics, the objective's moments, ||g||^2) writes its per-workgroup partials into a workspace and folds them in a
+# fixed order (csrc/reduce.hip) instead of issuing atomics: a step is then bit-reproducible, like the reference's CPU step.
+# SFM_DETERMINISTIC=0 / set_deterministic(False) passes NULL workspaces = the fp32-atomics form (A/B of the cost).
+_DET = {"on": _os.environ.get("SFM_DETERMINISTIC", "1") != "0", "bufs": {}}
+
+
+def set_deterministic(flag):
+    _DET["on"] = bool(flag)
+
+
+def is_deterministic():
+    return _DET["on"]
+
+
+def _ws(n, device, dtype=torch.float32):
+    """scratch of >= n elements for the kernel about to be enqueued on the CURRENT stream (one grow-only buffer per device,
+    stream and dtype: launches of one stream run in order, so the fold of one launch has read the partials before the next
+    launch overwrites them; a replaced buffer goes back to the caching allocator, which hands memory freed on a stream only
+    to later work of that stream).  None when the atomics form is selected."""
+    if not _DET["on"]:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, dtype)
+    t = _DET["bufs"].get(key)
+    if t is None or t.numel() < n:
+        t = _DET["bufs"][key] = torch.empty(max(int(n), 1 << 18), device=device, dtype=dtype)
+    return t
+
 
 def _call(name, fn, args, flops=0.0, nbytes=0.0, tag=None):
     if profiler.active(name):
@@ -728,15 +759,16 @@ def wave_moments(est, tgt):
     L = _lib.load()
     B, Ln = est.shape
     S = torch.zeros(B, 5, device=est.device, dtype=torch.float64)
-    _call("loss_reduce", L.sfm_wave_moments, (_p(est), _p(tgt), _p(S), B, Ln, _stream()), 0.0, 8.0 * B * Ln)
+    _call("loss_reduce", L.sfm_wave_moments, (_p(est), _p(tgt), _p(S), B, Ln, _p(_ws(64 * B * 5, est.device, torch.float64)), _stream()),
+          0.0, 8.0 * B * Ln)
     return S
 
 
 def spec_sums(pr, pi, tr, ti, out=None):
     L = _lib.load()
     S = torch.zeros(4, device=pr.device, dtype=torch.float64) if out is None else out
-    _call("loss_reduce", L.sfm_spec_sums, (_p(pr), _p(pi), _p(tr), _p(ti), _p(S), pr.numel(), _stream()), 0.0,
-          16.0 * pr.numel())
+    _call("loss_reduce", L.sfm_spec_sums, (_p(pr), _p(pi), _p(tr), _p(ti), _p(S), pr.numel(),
+                                           _p(_ws(2048 * 4, pr.device, torch.float64)), _stream()), 0.0, 16.0 * pr.numel())
     return S
 
 
@@ -782,6 +814,14 @@ def sum_time(src32, B, T, C, ld_src):
     return out
 
 
+def _tn_ws(L_, M, N, K, device):
+    """(workspace, its size in floats) of the ordered M-split fold of the TN GEMMs, or (None, 0) in the atomics form"""
+    if not _DET["on"]:
+        return None, 0
+    n = int(L_.sfm_tn_ws_floats(M, N, K))
+    return _ws(n, device), n
+
+
 def sinc_wgrad(wave, dy, C, K, exact=False):
     """dfilt [C, K] = sum_{b,l} dy[b, l, c] * wave[b, l + k - K//2]   (dy [B, L, C] 16-bit or fp32).
     A 16-bit dy with the reference's 251 taps runs on the matrix cores (waveform rounded to the compute dtype, like the
@@ -793,8 +833,9 @@ def sinc_wgrad(wave, dy, C, K, exact=False):
         xs = torch.empty(B, 8, Lc, device=wave.device, dtype=dy.dtype)
         _call("sinc_shift_pack", L_.sfm_sinc_shift_pack, (_p(wave), _p(xs), B, L, _dt(), _stream()), 0.0, B * (4.0 * L + 16.0 * Lc))
         dW = torch.zeros(C, 256, device=wave.device, dtype=torch.float32)
-        _call("sinc_wgrad16", L_.sfm_sinc_wgrad16, (_p(dy), _p(xs), _p(dW), B, L, C, _dt(), _stream()), 2.0 * B * L * C * 256,
-              B * L * (2.0 * C + 16.0))
+        ws, wsn = _tn_ws(L_, B * L, C, 256, wave.device)
+        _call("sinc_wgrad16", L_.sfm_sinc_wgrad16, (_p(dy), _p(xs), _p(dW), B, L, C, _dt(), _p(ws), wsn, _stream()),
+              2.0 * B * L * C * 256, B * L * (2.0 * C + 16.0))
         return dW[:, :K].contiguous()
     dfilt = torch.zeros(C, K, device=wave.device, dtype=torch.float32)
     scratch = torch.empty(int(L_.sfm_sinc_wgrad_scratch_floats(B, L, C, K)), device=wave.device, dtype=torch.float32)
@@ -830,9 +871,10 @@ def gn_act_backward(dout, act, G, x1, sc1, sh1, mean1, rstd1, gamma1, x2=None, s
     work = torch.zeros(3 * B * C + 3 * C, device=dev, dtype=torch.float32)       # S [B][3][C] | dparam [3][C]
     S, dparam = work[:3 * B * C], work[3 * B * C:].view(3, C)
     nbytes = float(B * L * C) * ((4 if f32(dout) else 2) + (1 + two) * (4 if f32(x1) else 2))
+    ws = _ws(int(L_.sfm_gn_bwd_reduce_ws_floats(B, L, C)), dev) if _DET["on"] else None
     _call("gn_bwd_reduce", L_.sfm_gn_bwd_reduce, (_p(dout), f32(dout), _p(x1), f32(x1), _p(sc1), _p(sh1), _p(mean1), _p(rstd1), _p(x2),
                                            f32(x2) if two else 0, _p(sc2), _p(sh2), _p(mean2), _p(rstd2), _p(S), B, L, C, G,
-                                           int(act), _dt(), _stream()), 0.0, nbytes)
+                                           int(act), _dt(), _p(ws), _stream()), 0.0, nbytes)
     coef = torch.empty(2, 3, B, C, device=dev, dtype=torch.float32)
     _call("gn_bwd_coefs", L_.sfm_gn_bwd_coefs, (_p(S), _p(gamma1), _p(rstd1), _p(gamma2), _p(rstd2), _p(coef[0]),
                                                 _p(coef[1]) if two else None, _p(dparam), B, L, C, G, _stream()), 0.0,
@@ -914,8 +956,10 @@ def gemm16_tn(G16, X16, dW, db=None):
     L = _lib.load()
     M, N = G16.shape
     K = X16.shape[1]
+    ws, wsn = _tn_ws(L, M, N, K, G16.device)
     _call("gemm16_tn", L.sfm_gemm16_tn, (_p(G16), _p(X16), _p(dW), _p(db), M, N, K, G16.stride(0), X16.stride(0), dW.stride(0),
-                                         _dt(), _stream()), 2.0 * M * N * K, M * (N + K) * 2.0, tag="M%d N%d K%d" % (M, N, K))
+                                         _dt(), _p(ws), wsn, _stream()), 2.0 * M * N * K, M * (N + K) * 2.0,
+          tag="M%d N%d K%d" % (M, N, K))
 
 
 def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
@@ -931,8 +975,9 @@ def conv_wgrad16(dy16, x16, B, Lout, Lin, Cin, N, ksize, stride, pad):
     L = _lib.load()
     buf = torch.zeros(N * ksize * Cin + N, device=x16.device, dtype=torch.float32)       # dW | db: one fill
     dW, db = buf[:N * ksize * Cin].view(N, ksize * Cin), buf[N * ksize * Cin:]
+    ws, wsn = _tn_ws(L, B * Lout, N, ksize * Cin, x16.device)
     _call("gemm16_tn", L.sfm_conv_wgrad16, (_p(dy16), _p(x16), _p(dW), _p(db), B, Lout, Lin, Cin, N, ksize, stride, pad,
-                                            Lin * Cin, dy16.stride(0), dW.stride(0), _dt(), _stream()),
+                                            Lin * Cin, dy16.stride(0), dW.stride(0), _dt(), _p(ws), wsn, _stream()),
           2.0 * B * Lout * N * ksize * Cin, (B * Lout * N + B * Lin * Cin) * 2.0,
           tag="conv M%d N%d K%d s%d" % (B * Lout, N, ksize * Cin, stride))
     return dW.reshape(N, ksize, Cin).permute(0, 2, 1).contiguous(), db
@@ -985,7 +1030,8 @@ def conv_dgrad16(dy16, weight, B, Lout, Lin, stride, pad, accumulate_into=None, 
 def colsum(G, out):
     L = _lib.load()
     M, N = G.shape
-    _call("colsum", L.sfm_colsum, (_p(G), _p(out), M, N, G.stride(0), 1 if G.dtype == torch.float32 else 0, _dt(), _stream()))
+    ws = _ws(int(L.sfm_colsum_ws_floats(M, N)), G.device) if _DET["on"] else None
+    _call("colsum", L.sfm_colsum, (_p(G), _p(out), M, N, G.stride(0), 1 if G.dtype == torch.float32 else 0, _dt(), _p(ws), _stream()))
 
 
 def layernorm_bwd(x32, gamma, dy, dres32, dgamma, dbeta, eps=1e-5, next_drop=None):
@@ -995,6 +1041,7 @@ def layernorm_bwd(x32, gamma, dy, dres32, dgamma, dbeta, eps=1e-5, next_drop=Non
     L = _lib.load()
     M, D = dy.shape
     dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+    ws = _ws(int(L.sfm_layernorm_bwd_ws_floats(M, D)), dy.device) if _DET["on"] else None
     dy16 = 0 if dy.dtype == torch.float32 else 1
     if dy16 and dy.dtype != _state["dtype"]:
         raise RuntimeError("layernorm_bwd: a 16-bit dy must be in the compute format")
@@ -1003,10 +1050,10 @@ def layernorm_bwd(x32, gamma, dy, dres32, dgamma, dbeta, eps=1e-5, next_drop=Non
         nxt = torch.empty(M, D, device=dy.device, dtype=_state["dtype"])
         _call("layernorm_bwd", L.sfm_layernorm_bwd_next, (_p(x32), _p(gamma), _p(dy), dy16, _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
                                                           x32.stride(0), dy.stride(0), D, eps, _dt(), _p(nxt), float(alpha), float(p),
-                                                          int(seed) & 0xffffffff, _stream()))
+                                                          int(seed) & 0xffffffff, _p(ws), _stream()))
         return dx, nxt
     _call("layernorm_bwd", L.sfm_layernorm_bwd_ex, (_p(x32), _p(gamma), _p(dy), dy16, _p(dres32), _p(dx), _p(dgamma), _p(dbeta), M, D,
-                                                    x32.stride(0), dy.stride(0), D, eps, _dt(), _stream()))
+                                                    x32.stride(0), dy.stride(0), D, eps, _dt(), _p(ws), _stream()))
     return dx
 
 
@@ -1027,7 +1074,8 @@ def col_stats(y32, aux=None, mean=None, rstd=None):
     L = _lib.load()
     M, C = y32.shape
     S = torch.zeros(C, 2, device=y32.device, dtype=torch.float32)
-    _call("col_stats", L.sfm_col_stats, (_p(y32), _p(aux), _p(mean), _p(rstd), _p(S), M, C, _stream()))
+    ws = _ws(int(L.sfm_col_stats_ws_floats(M, C)), y32.device) if _DET["on"] else None
+    _call("col_stats", L.sfm_col_stats, (_p(y32), _p(aux), _p(mean), _p(rstd), _p(S), M, C, _p(ws), _stream()))
     return S
 
 
@@ -1064,10 +1112,11 @@ def bn_swish_bwd(g, y32, mean, rstd, gamma, beta, eval_mode=False):
     S = torch.zeros(C, 2, device=y32.device, dtype=torch.float32)
     dy = torch.empty_like(y32)
     gf = 1 if g.dtype == torch.float32 else 0
+    ws = _ws(int(L.sfm_col_stats_ws_floats(M, C)), y32.device) if _DET["on"] else None
     for ps in (0, 1):
         Sx = torch.zeros_like(S) if (eval_mode and ps == 1) else S
         _call("bn_swish_bwd", L.sfm_bn_swish_bwd, (_p(g), _p(y32), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(Sx), _p(dy), M, C, gf,
-                                                   ps, _dt(), _stream()))
+                                                   ps, _dt(), _p(ws), _stream()))
     return dy, S[:, 1].contiguous(), S[:, 0].contiguous()
 
 
@@ -1149,8 +1198,14 @@ def memory_bwd(emb, params, d_out, d_gate, key_dim, value_dim, slots, temperatur
     Bn = emb.shape[0]
     d_emb = torch.empty(Bn, key_dim, device=emb.device, dtype=torch.float32) if want_d_emb else None
     dparams = torch.zeros_like(params)
+    ws = None
+    if _DET["on"]:
+        npar = int(L.sfm_memory_param_floats(key_dim, value_dim, slots))
+        if npar != params.numel():
+            raise RuntimeError("memory_bwd: the parameter blob has %d floats, the kernel's layout %d" % (params.numel(), npar))
+        ws = _ws(Bn * npar, emb.device)
     _call("memory_bwd", L.sfm_memory_bwd, (_p(emb), _p(params), _p(d_out), _p(d_gate), _p(d_emb), _p(dparams), Bn, key_dim, value_dim,
-                                           slots, float(temperature), _stream()))
+                                           slots, float(temperature), _p(ws), _stream()))
     return d_emb, dparams
 
 

@@ -111,7 +111,8 @@ class FlatAdamW:
         self.sync.finish(loss)
         L = ops._lib.load()
         n = self.sync.n
-        ops._call("optim", L.sfm_sumsq, (ops._p(self.sync.flat), n, self.ctl[1:].data_ptr(), ops._stream()), 0.0, 4.0 * n)
+        ops._call("optim", L.sfm_sumsq, (ops._p(self.sync.flat), n, self.ctl[1:].data_ptr(),
+                                         ops._p(ops._ws(2048, self.flat_p.device, torch.float64)), ops._stream()), 0.0, 4.0 * n)
         self.ctl[2:3].copy_(self.sync.flag.double())
         inv = 1.0 / (float(grad_scale) * self.sync.world)
         if scaler is not None and scaler.enabled:

@@ -377,3 +377,90 @@ def test_weight_gradient_gemm_wide_tiles(ops, dt, M, N, K):
     ref = init.double() + G.double().t() @ X.double()
     assert maxerr(dW.cpu(), ref) < 2e-4 * float(ref.abs().max())
     assert maxerr(db.cpu(), G.double().sum(0)) < 2e-4 * float(G.double().sum(0).abs().max())
+
+
+def test_ordered_reductions_repeat_bitwise_and_match_the_atomic_form(ops):
+    """Every split reduction of the training step in its ordered form (per-workgroup partials folded by csrc/reduce.hip: the
+    default) at shapes with hundreds to thousands of partials: two runs give the SAME BITS, and the result agrees with the
+    fp32-atomics form (ops.set_deterministic(False)) to summation-order rounding."""
+    dt = torch.float16
+    ops.set_compute_dtype(dt)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+
+    def cases():
+        M = 40000
+        G16, X16 = (rn(M, 256) * 0.1).to(dt), rn(M, 256).to(dt)
+
+        def tn_wide():                                        # 256 x 256 tiles, 157 M-splits
+            dW, db = torch.zeros(256, 256, device="cuda"), torch.zeros(256, device="cuda")
+            ops.gemm16_tn(G16, X16, dW, db)
+            return dW, db
+        G2, X2 = (rn(M, 136) * 0.1).to(dt), rn(M, 72).to(dt)
+
+        def tn_narrow():                                      # ragged 128 x 128 tiles
+            dW, db = torch.zeros(136, 72, device="cuda"), torch.zeros(136, device="cuda")
+            ops.gemm16_tn(G2, X2, dW, db)
+            return dW, db
+        B, Lin, Cin, N, k = 8, 4000, 64, 128, 7
+        x16, dy16 = rn(B, Lin, Cin).to(dt), (rn(B * (Lin // 2), N) * 0.1).to(dt)
+
+        def conv():                                           # LDS-DMA ring kernel (gemm16_tn2)
+            return ops.conv_wgrad16(dy16, x16, B, Lin // 2, Lin, Cin, N, k, 2, 3)
+        Gf = rn(M, 264)
+
+        def colsum():
+            out = torch.zeros(264, device="cuda")
+            ops.colsum(Gf, out)
+            return (out,)
+        x32, dy32, gam = rn(M, 256), rn(M, 256), rn(256)
+
+        def ln():                                             # 1024 partial rows -> two fold levels
+            dg, dbt = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
+            dx = ops.layernorm_bwd(x32, gam, dy32, None, dg, dbt)
+            return dx, dg, dbt
+
+        def colstats():                                       # 313 row blocks
+            return (ops.col_stats(x32),)
+        mean, rstd = x32.mean(0), 1.0 / x32.std(0)
+
+        def bnbwd():
+            return ops.bn_swish_bwd(dy32, x32, mean, rstd, gam, gam * 0.1)
+        Bg, Lg, Cg, Gg = 4, 6000, 64, 8
+        xg = rn(Bg, Lg, Cg).to(dt)
+        sc, sh = rn(Bg, Cg) * 0.2 + 1.0, rn(Bg, Cg) * 0.1
+        mu, rs = rn(Bg, Gg) * 0.1, rn(Bg, Gg).abs() + 0.5
+        dout = rn(Bg, Lg, Cg).to(dt)
+
+        def gn():
+            return ops.gn_act_backward(dout, 1, Gg, xg, sc, sh, mu, rs, gam[:Cg])
+        est, tgt = rn(6, 64000), rn(6, 64000)
+        pr, pi, tr, ti = rn(100000), rn(100000), rn(100000), rn(100000)
+
+        def moments():
+            return ops.wave_moments(est, tgt), ops.spec_sums(pr, pi, tr, ti)
+        Bd, Td, Cd = 12, 801, 256
+        xd, dyd = rn(Bd, Td, Cd).to(dt), rn(Bd, Td, Cd)
+
+        def dw():
+            return ops.dwconv_wgrad(xd, dyd, Bd, Td, Cd, 31)
+        return [("gemm16_tn wide", tn_wide), ("gemm16_tn narrow", tn_narrow), ("conv_wgrad16", conv), ("colsum", colsum),
+                ("layernorm_bwd", ln), ("col_stats", colstats), ("bn_swish_bwd", bnbwd), ("gn_act_backward", gn),
+                ("objective moments", moments), ("dwconv_wgrad", dw)]
+
+    try:
+        for name, fn in cases():
+            ops.set_deterministic(True)
+            a = [t.clone() for t in fn()]
+            b = [t.clone() for t in fn()]
+            for i, (u, v) in enumerate(zip(a, b)):
+                assert torch.equal(u, v), (name, i, "ordered form is not bit-reproducible")
+            ops.set_deterministic(False)
+            c = fn()
+            for i, (u, v) in enumerate(zip(a, c)):
+                scale = float(v.double().abs().max()) + 1e-30
+                err = float((u.double() - v.double()).abs().max()) / scale
+                print("%-22s output %d: ordered vs atomics max|diff| / max|value| = %.2e" % (name, i, err))
+                assert err < 2e-5, (name, i, err)
+    finally:
+        ops.set_deterministic(True)
