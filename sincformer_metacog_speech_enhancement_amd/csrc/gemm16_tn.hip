@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(const u16* __restrict__ 
   if (do_bias) {
     const int n = n0 + (tid & 127);
     if (n < N) {
-      if (ws) ws[(long long)gridDim.z * N * K + (long long)bz * N + n] = bsum;
+      // (two threads per column, one per row half of the staged tile: two partial rows per split)
+      if (ws) ws[(long long)gridDim.z * N * K + ((long long)bz * 2 + (tid >> 7)) * N + n] = bsum;
       else atomicAdd(&db[n], bsum);
     }
   }
@@ -385,13 +386,13 @@ extern "C" long long sfm_tn_ws_floats(int M, int N, int K) {
   if (s < 1) s = 1;
   const long long max_splits = (M + 255) / 256;
   if (s > max_splits) s = max_splits;
-  return (s + 1) * ((long long)N * K + N);
+  return (s + 1) * ((long long)N * K + 4LL * N);            // (+ up to 4 bias partial rows per split)
 }
 
-// second pass of the deterministic mode
-int tn_fold(float* ws, float* dW, float* db, int N, int K, int ldw, int splits, void* stream) {
+// second pass of the deterministic mode; bias_rows = bias partial rows per split (threads that share a column in the kernel)
+int tn_fold(float* ws, float* dW, float* db, int N, int K, int ldw, int splits, int bias_rows, void* stream) {
   int rc = sfm_fold_partials(ws, dW, N, K, ldw, splits, 1, stream);
-  if (rc == SFM_OK && db) rc = sfm_fold_partials(ws + (long long)splits * N * K, db, 1, N, N, splits, 1, stream);
+  if (rc == SFM_OK && db) rc = sfm_fold_partials(ws + (long long)splits * N * K, db, 1, N, N, splits * bias_rows, 1, stream);
   return rc;
 }
 
@@ -438,7 +439,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
     else
       SFM_LAUNCH((gemm16_tn_wide_kernel<BF16>), grid, block, lds, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
                  ldg, ldx, ldw, rows, ws);
-    return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, stream) : SFM_OK;
+    return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, 1, stream) : SFM_OK;
   }
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // 142 registers -> 3 workgroups per CU: aim at ONE full round of 768 resident workgroups (1024 was 1.3 rounds: the
@@ -451,7 +452,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
   int rows = (M + splits - 1) / splits;
   rows = (rows + 63) / 64 * 64;
   splits = (M + rows - 1) / rows;
-  if (ws && (long long)splits * ((long long)N * K + N) > ws_floats) return SFM_ERR_ARG;
+  if (ws && (long long)splits * ((long long)N * K + 2LL * N) > ws_floats) return SFM_ERR_ARG;
   dim3 grid((N + 127) / 128, (K + 127) / 128, splits), block(256);
   if (dtype == SFM_DT_F16)
     SFM_LAUNCH((gemm16_tn_kernel<F16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
@@ -459,7 +460,7 @@ static int gemm16_tn_launch(const void* G, const void* X, float* dW, float* db, 
   else
     SFM_LAUNCH((gemm16_tn_kernel<BF16>), grid, block, 0, (hipStream_t)stream, (const u16*)G, (const u16*)X, dW, db, M, N, K,
                ldg, ldx, ldw, rows, cv, ws);
-  return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, stream) : SFM_OK;
+  return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, 2, stream) : SFM_OK;
 }
 
 // db (optional): bias gradient out[n] += sum_m G[m, n], computed from the G tiles the k-tile-0 workgroups stage anyway

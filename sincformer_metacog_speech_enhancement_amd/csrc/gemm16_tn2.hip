@@ -236,13 +236,13 @@ __global__ __launch_bounds__(WNW * WKW * 64) void gemm16_tn2_kernel(const u16* _
   if (do_bias) {
     const int n = n0 + tid % TNc;
     if (n < N) {
-      if (ws) ws[(long long)gridDim.z * N * K + (long long)bz * N + n] = bsum;
+      if (ws) ws[(long long)gridDim.z * N * K + ((long long)bz * WKW + tid / TNc) * N + n] = bsum;   // WKW threads per column
       else atomicAdd(&db[n], bsum);
     }
   }
 }
 
-int tn_fold(float* ws, float* dW, float* db, int N, int K, int ldw, int splits, void* stream);
+int tn_fold(float* ws, float* dW, float* db, int N, int K, int ldw, int splits, int bias_rows, void* stream);
 
 template <class T, int WNW, int WKW, int STAGES>
 static int tn2_go(const void* G, const void* X, float* dW, float* db, int M, int N, int K, int ldg, int ldx, int ldw, unsigned g_rec,
@@ -268,10 +268,10 @@ static int tn2_go(const void* G, const void* X, float* dW, float* db, int M, int
   rows = (rows + 63) / 64 * 64;
   splits = (M + rows - 1) / rows;
   dim3 grid((N + TNc - 1) / TNc, (K + TKc - 1) / TKc, splits), block(WNW * WKW * 64);
-  if (ws && (long long)splits * ((long long)N * K + N) > ws_floats) return SFM_ERR_ARG;
+  if (ws && (long long)splits * ((long long)N * K + (long long)WKW * N) > ws_floats) return SFM_ERR_ARG;
   SFM_LAUNCH((gemm16_tn2_kernel<T, WNW, WKW, STAGES>), grid, block, lds, st, (const u16*)G, (const u16*)X, dW, db, M, N, K, ldg, ldx,
              ldw, rows, g_rec, x_rec, cv, ws);
-  return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, (void*)st) : SFM_OK;
+  return ws ? tn_fold(ws, dW, db, N, K, ldw, splits, WKW, (void*)st) : SFM_OK;
 }
 
 // called by gemm16_tn.hip's launcher; returns SFM_ERR_SHAPE when the shape is not one this kernel takes (the caller then
