@@ -50,11 +50,5 @@ class HipModule(torch.nn.Module):
             return False
         return self.__dict__.get("_sfm_eval_autograd", False) or any(t.requires_grad for t in inputs)
 
-    def _require_inference(self):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError(
-                "%s: training-mode forward (dropout / batch statistics / autograd) is not part of this round's HIP "
-                "path; call .eval() or wrap in torch.no_grad()." % type(self).__name__)
-
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)

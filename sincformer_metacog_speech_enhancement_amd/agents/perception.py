@@ -46,7 +46,9 @@ class SincConv1d(HipModule):
     def forward(self, waveform):
         """(batch, 1, samples) -> (batch, out_channels, samples), fp32."""
         self._require_device(waveform)
-        self._require_inference()
+        if self.training and torch.is_grad_enabled() and (self.low_hz_.requires_grad or self.band_hz_.requires_grad):
+            from .. import train                                    # train() mode: tap gradient + chain rule to the cut-offs
+            return train.SincConvFunction.apply(waveform, self, self.low_hz_, self.band_hz_)
         B, _, L = waveform.shape
         C, K = self.out_channels, self.kernel_size
         _, Wt = ops.sinc_filters(self.low_hz_.detach().reshape(-1).contiguous(), self.band_hz_.detach().reshape(-1).contiguous(),

@@ -1205,6 +1205,45 @@ def sinc_filters_autograd(low_hz_, band_hz_, window, n_, sample_rate, min_low_hz
     return bp / (bp.abs().sum(dim=1, keepdim=True) + 1e-8)
 
 
+class SincConvFunction(torch.autograd.Function):
+    """The stand-alone SincConv1d in train() mode (agents/perception.py:79-118): forward = the module's fp32 FIR
+    (framed_gemm_f32, exact); backward = the tap gradient dfilt[c, k] = sum_{b,l} dy[b, c, l] wave[b, l + k - K//2] (fp32 vector
+    kernel sfm_sinc_wgrad, exact) and the chain rule through the analytic filter bank to low_hz_ / band_hz_
+    (sinc_filters_autograd).  The waveform is the network's input: it gets no gradient (as in PerceptionFunction)."""
+
+    @staticmethod
+    def forward(ctx, waveform, mod, low_hz_, band_hz_):
+        B, _, L = waveform.shape
+        C, K = mod.out_channels, mod.kernel_size
+        w = waveform.detach().float().reshape(B, L).contiguous()
+        _, Wt = ops.sinc_filters(low_hz_.detach().reshape(-1).contiguous(), band_hz_.detach().reshape(-1).contiguous(),
+                                 mod.window.contiguous(), mod.n_.reshape(-1).contiguous(), C, K, mod.sample_rate, mod.min_low_hz,
+                                 mod.min_band_hz, want_filt=False)
+        out = torch.empty(B, C, L, device=w.device, dtype=torch.float32)
+        ops.framed_gemm(w, Wt, out, B=B, M=L, Ls=L, sig_batch_stride=L, hop=1, padl=K // 2, K=K, N=C, o_batch_stride=C * L, ldm=1,
+                        ldn=L, mode=0)
+        ctx.mod, ctx.wave = mod, w
+        ctx.save_for_backward(low_hz_, band_hz_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod, w = ctx.mod, ctx.wave
+        lo0, bw0 = ctx.saved_tensors
+        C, K = mod.out_channels, mod.kernel_size
+        dy_cl = torch.empty(dy.shape[0], dy.shape[2], C, device=dy.device, dtype=torch.float32)
+        Bn, Ln = dy.shape[0], dy.shape[2]
+        ops.transpose(dy.float().contiguous(), dy_cl, Bn, C, Ln, C * Ln, Ln, Ln * C, C)   # [B, C, L] -> channels-last [B, L, C]
+        dfilt = ops.sinc_wgrad(w, dy_cl, C, K, exact=True)
+        with torch.enable_grad():
+            lo = lo0.detach().float().clone().requires_grad_(True)
+            bw = bw0.detach().float().clone().requires_grad_(True)
+            filt = sinc_filters_autograd(lo, bw, mod.window.float(), mod.n_.float(), float(mod.sample_rate),
+                                         float(mod.min_low_hz), float(mod.min_band_hz))
+            glo, gbw = torch.autograd.grad(filt, [lo, bw], grad_outputs=dfilt)
+        return None, None, glo.to(lo0.dtype), gbw.to(bw0.dtype)
+
+
 def _pa_param_names(pa):
     return [k for k, _ in pa.named_parameters()]
 
