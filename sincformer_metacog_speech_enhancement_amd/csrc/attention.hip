@@ -768,7 +768,7 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
                               int voff, long long qkv_batch_stride, long long o_batch_stride, float scale, float p_drop,
                               unsigned int seed, int dtype, int out_dtype, int variant, void* stream) {
   if (!qkv || !out) return SFM_ERR_ARG;
-  if (variant < 0 || variant > 5) return SFM_ERR_ARG;
+  if (variant < 0 || variant > 6) return SFM_ERR_ARG;
   const int sfm_attn_variant = (variant == 2) ? 3 : variant;
   if (p_drop < 0.f || p_drop >= 1.f) return SFM_ERR_SHAPE;
   if ((lse || p_drop > 0.f) && (qkv_batch_stride != (long long)T * ldqkv)) return SFM_ERR_SHAPE;
@@ -791,9 +791,9 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
     const bool pipe4_auto = enough && !pipe8_auto && T <= 256 && 100 * T >= 90 * 256;
     const bool ring_auto = pipe8_auto || pipe4_auto;
     if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) &&
-        (sfm_attn_variant == 4 || sfm_attn_variant == 5 || (sfm_attn_variant == 0 && ring_auto)))
+        (sfm_attn_variant >= 4 || (sfm_attn_variant == 0 && ring_auto)))
       return sfm_attn_pipe_launch(qkv, out, lse, B, T, H, ldqkv, ldo, koff, voff, qkv_batch_stride, o_batch_stride, sl2, dtype,
-                                  out_other, (sfm_attn_variant == 5 || (sfm_attn_variant == 0 && pipe4_auto)) ? 4 : 8, st);
+                                  out_other, sfm_attn_variant == 6 ? 44 : ((sfm_attn_variant == 5 || (sfm_attn_variant == 0 && pipe4_auto)) ? 4 : 8), st);
     if (p_drop == 0.f && bytes_q < (1LL << 31) && bytes_o < (1LL << 31) && sfm_attn_variant == 3) {
       const int n_items = nqt5 * H * B;
       // (CU count and the dynamic-LDS attribute are per device: caches keyed by hipGetDevice())

@@ -519,7 +519,7 @@ def attention_kernel_name(B, T, H, variant=None):
         else:
             v = 2 if T >= 1024 else 1
     return {1: "attn_fwd_hd64_kernel", 2: "attn_fwd_hd64x2_kernel", 3: "attn_fwd_hd64r_kernel", 4: "attn_fwd_hd64p8_kernel",
-            5: "attn_fwd_hd64p4_kernel"}[v]
+            5: "attn_fwd_hd64p4_kernel", 6: "attn_fwd_hd64q4_kernel"}[v]
 
 
 def set_attention_variant(v):
@@ -527,7 +527,7 @@ def set_attention_variant(v):
     with one 8-wave / two 4-wave workgroups per CU (A/B measurements).  Host-side state only: the value is passed to
     sfm_attention_fwd_ex with every call (the library keeps no selection state)."""
     v = int(v)
-    if not 0 <= v <= 5:
+    if not 0 <= v <= 6:
         raise ValueError("attention variant %d" % v)
     _ATTN_VARIANT[0] = v
 

@@ -402,7 +402,7 @@ def _attn_ref(qkv, B, T, H, hd):
     return (p @ v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])       # the head_dim-64 kernels: 32 query rows per wave / persistent ring / pipelined persistent
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])    # the head_dim-64 kernels: 32 query rows per wave / persistent ring / pipelined persistent (8 x 64, 4 x 64, 4 x 128 rows)
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,T,H,hd", [(2, 200, 4, 64), (1, 64, 4, 64), (3, 1, 2, 64), (1, 801, 4, 64), (2, 129, 1, 64),
                                       (1, 1100, 2, 64), (2, 20, 4, 16), (1, 37, 2, 32)])
