@@ -86,12 +86,16 @@ __device__ __forceinline__ uint32_t gelu_as_h2p(uint32_t zb) {
 // (A first version passed 8 x 8-row fp32 strips through LDS like gemm16's epilogue: 8 round trips, 9 k cycles per tile - as much
 // as staging the patch and the MFMA loop together.  gemm16_epilogue_strips itself is not used here: it carries every
 // activation / residual / dropout mode of sfm_gemm16 inline, and two instances of it made instruction fetch the bound.)
-template <class T>
-__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], unsigned char* img, const float* bias_s,
-                                               int lane, int b, int colb, int row_base) {
+// Round 4 (the two epilogues of a b0.c1 + skip tile were 2 000 instructions, a third of the tile's cycles): FULL = every row of the
+// wave's 64 x 64 tile is inside the utterance (a wave-uniform choice made by the caller): no row predicates in the statistics;
+// the 16-bit converts are hoisted behind ONE branch on the output format (a select per convert computed both formats and chose:
+// 2 x 64 converts + 128 v_cndmask per tile); the row stores are buffer stores (32-bit offsets against a per-utterance descriptor
+// whose range check drops the rows beyond Lout: no 64-bit address arithmetic, no exec-mask branches).
+template <class T, bool FULL>
+__device__ __forceinline__ void convp_epilogue_impl(const Gemm2Params& g, f32x16 (&acc)[2][2], unsigned char* img, const float* bias_s,
+                                                    int lane, int b, int colb, int row_base) {
   constexpr int ROWB = 144;                            // image row: 64 x 16-bit + 16 bytes of padding (fp32 mode: two passes)
   const int l31 = lane & 31, hl = lane >> 5;
-  const long long obase = (long long)b * g.o_batch_stride;
   // ---- bias, statistics ----
   float ps[2][4], pq[2][4];                            // per (n-block j, 8-channel quad-pair g): sums over this lane's rows
 #pragma unroll
@@ -103,7 +107,7 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
       float s_ = 0.f, q_ = 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const bool rowok = row_base + i * 32 + l31 < g.Lout;
+        const bool rowok = FULL || (row_base + i * 32 + l31 < g.Lout);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = acc[i][j][4 * gq + e] + bv[e];
@@ -141,29 +145,37 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
     }
   }
   // ---- store: 16-bit through one LDS image; fp32 (the latent heads' consumers) as two 32-row halves through the same image ----
+  const int osz = g.out_f32 == 1 ? 4 : 2;
+  // rows >= Lout fall outside the descriptor's range and are dropped by the hardware
+  auto ors = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<unsigned char*>(g.out) + (long long)b * g.o_batch_stride * osz), 0,
+                                               g.Lout * g.ldo * osz, 0x00020000);
   if (g.out_f32 != 1) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          u32x2 w;
-          w[0] = pack2_out<T>(acc[i][j][4 * gq + 0], acc[i][j][4 * gq + 1], g.out_f32 == 2);
-          w[1] = pack2_out<T>(acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3], g.out_f32 == 2);
-          *reinterpret_cast<u32x2*>(img + (i * 32 + l31) * ROWB + (j * 32 + 8 * gq + 4 * hl) * 2) = w;
-        }
+#define CONVP_PACK_IMG(PK)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+  _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                                   \
+    u32x2 w;                                                                                                           \
+    w[0] = PK(acc[i][j][4 * gq + 0], acc[i][j][4 * gq + 1]);                                                           \
+    w[1] = PK(acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);                                                           \
+    *reinterpret_cast<u32x2*>(img + (i * 32 + l31) * ROWB + (j * 32 + 8 * gq + 4 * hl) * 2) = w;                       \
+  }
+    if ((g.out_f32 == 2) == (T::id == SFM_DT_BF16)) { CONVP_PACK_IMG(F16::pack) } else { CONVP_PACK_IMG(BF16::pack) }
+#undef CONVP_PACK_IMG
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
+    u32x4 rv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lane + 64 * k;
+      rv[k] = *reinterpret_cast<const u32x4*>(img + (c >> 3) * ROWB + (c & 7) * 16);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int c = lane + 64 * k;
       const int row = c >> 3, ch = c & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(img + row * ROWB + ch * 16);
-      const int m = row_base + row;
-      if (m < g.Lout) *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(g.out) + obase + (long long)m * g.ldo + colb + ch * 8) = v;
+      __builtin_amdgcn_raw_buffer_store_b128(rv[k], ors, ((row_base + row) * g.ldo + colb + ch * 8) * 2, 0, 0);
     }
   } else {
 #pragma unroll
@@ -182,12 +194,18 @@ __device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&ac
       for (int k = 0; k < 8; ++k) {
         const int c = lane + 64 * k;
         const int row = c >> 4, ch = c & 15;           // 32 rows x 16 chunks of 4 floats
-        const f32x4 v = *reinterpret_cast<const f32x4*>(img + row * 272 + ch * 16);
-        const int m = row_base + i * 32 + row;
-        if (m < g.Lout) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + obase + (long long)m * g.ldo + colb + ch * 4) = v;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(img + row * 272 + ch * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ors, ((row_base + i * 32 + row) * g.ldo + colb + ch * 4) * 4, 0, 0);
       }
     }
   }
+}
+
+template <class T>
+__device__ __forceinline__ void convp_epilogue(const Gemm2Params& g, f32x16 (&acc)[2][2], unsigned char* img, const float* bias_s,
+                                               int lane, int b, int colb, int row_base) {
+  if (row_base + 64 <= g.Lout) convp_epilogue_impl<T, true>(g, acc, img, bias_s, lane, b, colb, row_base);       // wave-uniform
+  else convp_epilogue_impl<T, false>(g, acc, img, bias_s, lane, b, colb, row_base);
 }
 
 #ifdef SFM_CONVP_STAMPS
@@ -501,6 +519,7 @@ extern "C" int sfm_conv16p(const void* x1, const float* sc1, const float* sh1, c
   if (out_f32 < 0 || out_f32 > 2) return SFM_ERR_SHAPE;
   if (gn_partial && gn_group != 8 && gn_group != 16 && gn_group != 32) return SFM_ERR_SHAPE;
   if ((long long)Lin * Cin * 2 >= (1LL << 31) || (long long)N * ksize * Cin * 2 >= (1LL << 31)) return SFM_ERR_SHAPE;
+  if ((long long)((Lin + 2 * pad - ksize) / stride + 1) * N * 4 >= (1LL << 31)) return SFM_ERR_SHAPE;       // 32-bit store offsets per utterance
   const int Lout = (Lin + 2 * pad - ksize) / stride + 1;
   if (Lout <= 0) return SFM_ERR_SHAPE;
   const bool skip = Ws != nullptr;
