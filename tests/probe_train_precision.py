@@ -21,7 +21,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
-from helpers import synth_sd                                       # noqa: E402
+from helpers import synth_sd, arr                                  # noqa: E402
 from oracle import sfm_oracle as orc                               # noqa: E402
 from sincformer_metacog_speech_enhancement_amd import ops, synthetic as syn      # noqa: E402
 from sincformer_metacog_speech_enhancement_amd.optim import FlatAdamW, DynamicLossScale   # noqa: E402
@@ -48,7 +48,18 @@ def summarise(pairs):
             "cosine_of_whole_gradient": dot / (tot_g * tot_r), "norm_ratio": tot_g / tot_r}
 
 
-def enhancer_case(recipe, scale=1.0):
+def waves(kind, B, L, seed):
+    """'test': the pair of tests/test_train_gpu.py (clean N(0, 0.1^2) + N(0, 0.05^2): 6 dB SNR); 'bench': synthetic.synth_wave, the
+    pairs bench.py trains on (SNR cycled over -5 / 0 / 5 / 10 dB: many enhanced STFT bins near zero or near the target's magnitude,
+    where the objective's 1 / |bin| slopes and sign() terms make its gradient discontinuous)"""
+    if kind == "test":
+        clean = arr("cw", (B, L), seed, 0.1)
+        return clean + arr("nw", (B, L), seed + 1, 0.05), clean
+    noisy, clean = syn.synth_wave(B, L, seed)
+    return torch.from_numpy(noisy), torch.from_numpy(clean)
+
+
+def enhancer_case(recipe, scale=1.0, kind="test"):
     B, L = 2, 4000
     sd = synth_sd("SpeechEnhancer", 23)
     if recipe == "bf16":
@@ -58,8 +69,7 @@ def enhancer_case(recipe, scale=1.0):
     m = SpeechEnhancer(n_freq=129, d_model=256, num_blocks=4, num_heads=4, d_ff=1024, kernel_size=31, dropout=0.0)
     m.load_state_dict(sd, strict=True)
     m.cuda().train()
-    noisy, clean = syn.synth_wave(B, L, 80)
-    noisy, clean = torch.from_numpy(noisy), torch.from_numpy(clean)
+    noisy, clean = waves(kind, B, L, 80)
     ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
     ref_total, _, _ = orc.enhancer_loss(ref_sd, noisy, clean, 4, bn_train=True)
     ref_total.backward()
@@ -94,7 +104,7 @@ def enhancer_case(recipe, scale=1.0):
     return out
 
 
-def path_case(recipe):
+def path_case(recipe, kind="test"):
     B, L = 2, 3200
     if recipe == "bf16":
         ops.set_compute_dtype(torch.bfloat16)
@@ -113,8 +123,7 @@ def path_case(recipe):
             mod.dropout = 0.0
     path.cpea.lstm.dropout = 0.0
     path = path.cuda().train()
-    noisy, clean = syn.synth_wave(B, L, 81)
-    noisy, clean = torch.from_numpy(noisy), torch.from_numpy(clean)
+    noisy, clean = waves(kind, B, L, 81)
     ref = {n: {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and
                    k.split(".")[-1] not in ("window", "n_") else v.clone()) for k, v in sd.items()} for n, sd in sds.items()}
     ref_total, _, _ = orc.path_loss(ref, noisy, clean, 16000, bn_train=True)
@@ -138,14 +147,17 @@ def path_case(recipe):
 
 
 def main():
-    res = {"speech_enhancer_step": {}, "path_step": {}}
-    for recipe, scale in (("bf16", 1.0), ("fp16", 1.0), ("fp16", 256.0), ("fp16", 4096.0), ("fp16", 65536.0), ("amp16", None)):
-        key = recipe if scale in (None, 1.0) else "%s x S=%g" % (recipe, scale)
-        res["speech_enhancer_step"][key] = enhancer_case(recipe, scale or 1.0)
-        print(key, json.dumps(res["speech_enhancer_step"][key]), file=sys.stderr, flush=True)
-    for recipe in ("bf16", "fp16", "amp16"):
-        res["path_step"][recipe if recipe != "amp16" else "fp16 x S=65536"] = path_case(recipe)
-        print("path", recipe, json.dumps(res["path_step"][recipe if recipe != "amp16" else "fp16 x S=65536"]), file=sys.stderr, flush=True)
+    res = {}
+    for kind in ("test", "bench"):
+        a, b = res.setdefault("speech_enhancer_step / %s waves" % kind, {}), res.setdefault("path_step / %s waves" % kind, {})
+        for recipe, scale in (("bf16", 1.0), ("fp16", 1.0), ("fp16", 4096.0), ("fp16", 65536.0), ("amp16", None)):
+            key = recipe if scale in (None, 1.0) else "%s x S=%g" % (recipe, scale)
+            a[key] = enhancer_case(recipe, scale or 1.0, kind)
+            print(kind, key, json.dumps(a[key]), file=sys.stderr, flush=True)
+        for recipe in ("bf16", "fp16", "amp16"):
+            key = recipe if recipe != "amp16" else "fp16 x S=65536"
+            b[key] = path_case(recipe, kind)
+            print(kind, "path", key, json.dumps(b[key]), file=sys.stderr, flush=True)
     ops.reset_precision()
     print(json.dumps(res, indent=1))
 
