@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes over tools/conv_bench.py (conv16p on the PerceptionAgent layer shapes), summary per kernel instantiation
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-out=$ROOT/gpurun_out/${SFM_ROUND:-r03}/pmc_conv16p
+out=$ROOT/gpurun_out/${SFM_ROUND:-r04}/pmc_conv16p
 mkdir -p $out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   i=$((i+1))
   rocprofv3 --pmc $set -d $out/p$i -o p$i --output-format csv -- python3 $ROOT/tools/conv_bench.py > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; }
 done
-python3 $ROOT/tools/pmc_kernels.py $out/summary.json "conv16p_kernel<F16, 7, 2, 1, true, false>,conv16p_kernel<F16, 3, 1, 1, false, false>,conv16p_kernel<F16, 7, 2, 1, true, true>,conv16p_kernel<F16, 3, 1, 2,conv16p_kernel<F16, 1, 2, 2" $(find $out -name "*counter_collection.csv") > /dev/null
+python3 $ROOT/tools/pmc_kernels.py $out/summary.json "conv16p_kernel<F16, 7, 2, 1, true, false>;conv16p_kernel<F16, 3, 1, 1, false, false>;conv16p_kernel<F16, 7, 2, 1, true, true>;conv16p_kernel<F16, 7, 2, 2;conv16p_kernel<F16, 3, 1, 2;conv16p_kernel<F16, 5, 2, 2;conv16p_kernel<F16, 1, 2, 2" $(find $out -name "*counter_collection.csv") > /dev/null
 python3 - <<PY
 import json
 d=json.load(open("$out/summary.json"))

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes (separate runs, counter_collection.csv each) per kernel name:
-   python tools/pmc_kernels.py out.json <substring>[,<substring>...] <counter_collection.csv> [...]
+   python tools/pmc_kernels.py out.json <substring>[;<substring>...] <counter_collection.csv> [...]
 Average of every collected counter per dispatch of the kernels whose name contains one of the substrings, plus the
 derived MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), MI355X_MICROARCH.md)."""
 import collections, csv, json, sys
 
-subs = sys.argv[2].split(",")
+subs = sys.argv[2].split(";")          # kernel names contain commas: the separator is ";"
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for path in sys.argv[3:]:
     for r in csv.DictReader(open(path)):
