@@ -98,6 +98,12 @@ __device__ __forceinline__ void attnp_body(const u16* __restrict__ qkv, u16* __r
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(SFM_ATTNP_STAGGER)
+  // timing experiment: the second resident workgroup of a CU starts SFM_ATTNP_STAGGER x 1024 cycles late, so that the two
+  // workgroups' item epilogues do not coincide
+  if (NW == 4 && blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < SFM_ATTNP_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
   const int hl = lane >> 5, l31 = lane & 31;
   const int nkt = (Tlen + 63) >> 6, ngrp = (nkt + GT - 1) / GT, nsteps = (Tlen + 31) >> 5;
   const int rec_bytes = Tlen * ldqkv * 2;                          // keys / queries >= Tlen are out of range: read as zero
