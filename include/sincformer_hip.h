@@ -406,6 +406,10 @@ int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const floa
                       unsigned int seed, int dtype, void* stream);
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
+/* inference only: w16 != 0 runs the recurrent product W_hh h on fp16 operands (weights and h rounded once, fp32 accumulation, gates /
+   cell state / output fp32): half the registers, so two chains share a CU - 1.6 x at batch 256; H 32 keeps the fp32 kernel.
+   (agents/cpea.py:43-50,99: the same nn.LSTM recurrence) */
+int sfm_bilstm_layer_ex(const float* xg, const float* whh, float* out, int B, int T, int H, int w16, void* stream);
 /* training: as sfm_bilstm_layer, also saving the activated gates and cell states [B, T, 2, 5, H] fp32; and the BPTT of
  * the layer: dout [B, T, 2H] -> dxg [B, T, 2, 4H] = gradient w.r.t. the input projection (dW_ih, dW_hh, biases and dx
  * are GEMMs / column sums of dxg afterwards). */

@@ -115,6 +115,93 @@ __global__ __launch_bounds__(LPU * H) void bilstm_layer_kernel(const float* __re
   }
 }
 
+// Inference form with the recurrent product on fp16 operands: W_hh as packed half pairs in registers (64 instead of 128 per lane:
+// the kernel fits 4 waves per SIMD, so TWO chains share a CU - at batch 256 there are 512 chains for 256 CUs and the fp32 form runs
+// them in two rounds), h published in LDS as fp16 (half the LDS bytes of a step), `v_dot2_f32_f16` with fp32 accumulation (half the
+// multiply-add instructions).  c, the gates and the h written to `out` stay fp32; what is rounded is the recurrent operand pair, to
+// the format every MFMA operand of the 16-bit path already has.  No `save`: training keeps the fp32 kernel above.
+typedef _Float16 lstm_h2 __attribute__((ext_vector_type(2)));
+template <int H, int LPU>
+__global__ __launch_bounds__(LPU * H, 4) void bilstm_layer16_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
+                                                                    float* __restrict__ out, int T) {
+  constexpr int KS = H / LPU;                                // h values per lane
+  constexpr int KW = KS / 2;                                 // = dwords (half pairs) per slice
+  constexpr int SLW = KW + 4;                                // dword stride of a slice
+  static_assert(KW % 4 == 0, "16-byte slice reads");
+  __shared__ __attribute__((aligned(16))) uint32_t hs[2][LPU * SLW];
+  const int tid = threadIdx.x;
+  const int j = tid / LPU, ks = tid % LPU;
+  const int dir = blockIdx.x, b = blockIdx.y;
+  lstm_h2 w[4][KW];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* wr = whh + ((long long)dir * 4 * H + g * H + j) * H + ks * KS;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) w[g][i] = lstm_h2{(_Float16)wr[2 * i], (_Float16)wr[2 * i + 1]};
+    __builtin_amdgcn_sched_barrier(0);                       // one gate's fp32 rows in flight at a time (all four at once spill)
+  }
+  if (tid < LPU * SLW) { hs[0][tid] = 0u; hs[1][tid] = 0u; }
+  __syncthreads();
+  float c = 0.f;
+  const int mygate = ks & 3;
+  const float* xb = xg + (long long)b * T * (8 * H) + (long long)dir * 4 * H + mygate * H + j;
+  float* ob = out + (long long)b * T * (2 * H) + dir * H + j;
+  int t = dir ? (T - 1) : 0;
+  const int dt = dir ? -1 : 1;
+  const float gsc = (mygate == 2) ? 2.0f : 1.0f, gof = (mygate == 2) ? -1.0f : 0.0f;
+  // unit j's h as a byte address in LDS.  The 16-bit store is an asm statement: a C++ store through a _Float16 lvalue into the
+  // uint32_t array is an aliasing violation, and the compiler then reads ONE dword per 16-byte group and reuses it
+  const uint32_t hbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&hs[0][0];
+  const uint32_t hslot = hbase + ((j / KS) * SLW * 2 + (j % KS)) * 2;
+  const uint32_t hread = hbase + ks * SLW * 4;                // this lane's slice (the reads are asm too: 16-byte, counted waits)
+  float xnext = xb[(long long)t * (8 * H)];
+  for (int s = 0; s < T; ++s, t += dt) {
+    const float xcur = xnext;
+    if (s + 1 < T) xnext = xb[(long long)(t + dt) * (8 * H)];
+    const uint32_t hc = hread + (uint32_t)((s & 1) * LPU * SLW * 4);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    u32x4 hv[KW / 4];
+#pragma unroll
+    for (int q = 0; q < KW / 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hv[q]) : "v"(hc), "n"(q * 16) : "memory");
+    // every group passes through a wait statement (the compiler may move the dot products across an asm they do not depend on)
+    if constexpr (KW / 4 == 4) {
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(hv[0]), "+v"(hv[1])::"memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hv[2]), "+v"(hv[3])::"memory");
+    } else {
+      static_assert(KW / 4 == 2, "H 128 or 64 with 4 lanes per unit");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hv[0]), "+v"(hv[1])::"memory");
+    }
+#pragma unroll
+    for (int q = 0; q < KW / 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t hd = hv[q][e];                          // (a scalar copy first: __builtin_bit_cast applied to a vector ELEMENT
+        const lstm_h2 hp = __builtin_bit_cast(lstm_h2, hd);    //  reads element 0 with this hipcc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = __builtin_amdgcn_fdot2(w[g][4 * q + e], hp, a[g], false);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      a[g] = dpp_add<DPP_XOR1>(a[g]);
+      a[g] = dpp_add<DPP_XOR2>(a[g]);
+      if (LPU == 8) a[g] = dpp_add<DPP_HALF_MIRROR>(a[g]);
+    }
+    const float pre = ((mygate == 0) ? a[0] : (mygate == 1) ? a[1] : (mygate == 2) ? a[2] : a[3]) + xcur;
+    const float act = gsc * fast_sigmoid(gsc * pre) + gof;
+    const float ig = dpp_get<DPP_Q0>(act), fg = dpp_get<DPP_Q1>(act);
+    const float cg = dpp_get<DPP_Q2>(act), og = dpp_get<DPP_Q3>(act);
+    c = fg * c + ig * cg;
+    const float h = og * (2.0f * fast_sigmoid(2.0f * c) - 1.0f);
+    if (ks == 0) {
+      const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)h);
+      asm volatile("ds_write_b16 %0, %1" ::"v"(hslot + (uint32_t)(((s + 1) & 1) * LPU * SLW * 4)), "v"(hb) : "memory");
+      ob[(long long)t * (2 * H)] = h;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
 // xg [B, T, 2, 4H] fp32 (dir-major gates), whh [2, 4H, H] fp32, out [B, T, 2H] fp32
 // ---------------------------------------------------------------------------
 // BPTT of one BiLSTM layer (training of agents/cpea.py:43-50): same workgroup = chain mapping as the forward.
@@ -203,8 +290,14 @@ __global__ __launch_bounds__(LPU * H) void bilstm_layer_bwd_kernel(const float* 
 }
 
 template <int H>
-static int bilstm_fwd_go(const float* xg, const float* whh, float* out, float* save, int B, int T, hipStream_t st) {
+static int bilstm_fwd_go(const float* xg, const float* whh, float* out, float* save, int B, int T, hipStream_t st, bool w16 = false) {
   constexpr int LPU = H >= 64 ? SFM_LSTM_LPU : 8;           // H 32: 4 x H / 4 = 8-float slices, too short for the float4 reads
+  if constexpr (H >= 64 && (H / LPU) % 8 == 0) {
+    if (w16 && !save) {
+      SFM_LAUNCH((bilstm_layer16_kernel<H, LPU>), dim3(2, B), dim3(LPU * H), 0, st, xg, whh, out, T);
+      return SFM_OK;
+    }
+  }
   SFM_LAUNCH((bilstm_layer_kernel<H, LPU>), dim3(2, B), dim3(LPU * H), 0, st, xg, whh, out, T, save);
   return SFM_OK;
 }
@@ -225,6 +318,17 @@ extern "C" int sfm_bilstm_layer_train(const float* xg, const float* whh, float* 
 extern "C" int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype,
                                 void* stream) {
   return sfm_bilstm_layer_train(xg, whh, out, nullptr, B, T, H, dtype, stream);
+}
+
+// inference, recurrent product on fp16 operands when w16 != 0 (bilstm_layer16_kernel; H 32 keeps the fp32 kernel)
+extern "C" int sfm_bilstm_layer_ex(const float* xg, const float* whh, float* out, int B, int T, int H, int w16, void* stream) {
+  if (!xg || !whh || !out) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0) return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 128) return bilstm_fwd_go<128>(xg, whh, out, nullptr, B, T, st, w16 != 0);
+  if (H == 64) return bilstm_fwd_go<64>(xg, whh, out, nullptr, B, T, st, w16 != 0);
+  if (H == 32) return bilstm_fwd_go<32>(xg, whh, out, nullptr, B, T, st, false);
+  return SFM_ERR_SHAPE;
 }
 
 // save [B, T, 2, 5, H] from sfm_bilstm_layer_train, dout [B, T, 2H] fp32 -> dxg [B, T, 2, 4H] fp32

@@ -540,7 +540,7 @@ def _cpea_forward(z16, pk, B, T, out):
     x16 = z16
     for lp in pk["layers"]:
         xg = ops.linear16(x16, lp["wih"], out_dtype=torch.float32)                  # [M, 8H] = [B,T,2,4H]
-        h = ops.bilstm_layer(xg, lp["whh"], B, T, H)                                # [B, T, 2H] fp32
+        h = ops.bilstm_layer(xg, lp["whh"], B, T, H, w16=ops.lstm_w16())            # [B, T, 2H] fp32
         x16 = torch.empty(M, 2 * H, device=h.device, dtype=dt)
         ops.convert_rows(h, x16, M, 2 * H, 2 * H, 2 * H, 2 * H)
     oc = pk["oc"]

@@ -1160,11 +1160,28 @@ def attention_bwd(qkv16, O16, dO16, lse, B, T, H, hd, p_drop=0.0, seed=0):
     return dqkv
 
 
-def bilstm_layer(xg, whh, B, T, H):
+_LSTM = {"w16": _os.environ.get("SFM_LSTM_W16", "1") != "0"}
+
+
+def set_lstm_w16(flag):
+    """inference BiLSTM recurrence on fp16 operands (sfm_bilstm_layer_ex, default on; SFM_LSTM_W16=0 / False = fp32 W_hh and h)"""
+    _LSTM["w16"] = bool(flag)
+
+
+def lstm_w16():
+    return _LSTM["w16"]
+
+
+def bilstm_layer(xg, whh, B, T, H, w16=False):
+    """one BiLSTM layer's recurrence (inference).  w16: recurrent product on fp16 operands (the fused path passes lstm_w16())"""
     L = _lib.load()
     out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)
-    _call("bilstm_layer", L.sfm_bilstm_layer, (_p(xg), _p(whh), _p(out), B, T, H, _dt(), _stream()),
-          *_cost_of("bilstm_layer", locals()))
+    if w16:
+        _call("bilstm_layer", L.sfm_bilstm_layer_ex, (_p(xg), _p(whh), _p(out), B, T, H, 1, _stream()),
+              *_cost_of("bilstm_layer", locals()))
+    else:
+        _call("bilstm_layer", L.sfm_bilstm_layer, (_p(xg), _p(whh), _p(out), B, T, H, _dt(), _stream()),
+              *_cost_of("bilstm_layer", locals()))
     return out
 
 

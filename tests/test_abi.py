@@ -60,3 +60,4 @@ def test_null_pointers_are_rejected_without_a_gpu(built):
     assert L.sfm_gemm16(one, one, None, one, None, None, 1, 8, 8, 12, 12, 1, 1, 0, 0, 32, 8, 64, 8, 0, 0, 0, 1.0, 0, 1,
                         0, 0, 0, None) == -2       # Cin not a multiple of 8
     assert L.sfm_bilstm_layer(one, one, one, 2, 5, 100, 0, None) == -2   # unsupported hidden size
+    assert L.sfm_bilstm_layer_ex(one, one, one, 2, 5, 100, 1, None) == -2
