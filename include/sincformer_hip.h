@@ -404,6 +404,17 @@ int sfm_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T
 int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv,
                       int B, int T, int H, int hd, int ldqkv, int ldo, int koff, int voff, float p_drop,
                       unsigned int seed, int dtype, void* stream);
+/* Linear layer with K = 256 inputs and a 16-bit result, one 8-wave workgroup per 128 rows for ALL output columns (A tile resident in
+   registers, W streamed through an LDS-DMA ring, epilogue of a 64-row W chunk under the next chunk's MFMAs; csrc/lin256.hip):
+     glu == 0: out[M, NW]     = A[M, 256] W^T + b                       (models/conformer.py:57-59, the Q | K | V projection)
+     glu != 0: out[M, NW / 2] = GLU(A W^T + b), W rows in 64-row groups of 32 values | 32 gates
+                                                                         (models/conformer.py:92-96, pointwise_conv1 + GLU)
+   A rows have stride lda >= 256 (16-bit elements, multiple of 8), W is [NW, 256] row-major, NW % 64 == 0 (% 128 with glu),
+   bias [NW] fp32 or NULL; out_dtype may be the other 16-bit format (one rounding of the fp32 accumulators).  The same contract as
+   sfm_gemm16 on these shapes, and the same bits (same MFMA, same k order, same epilogue expressions). */
+int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M, int NW, int lda, int ldo, int glu, int dtype,
+               int out_dtype, void* stream);
+
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);
 /* inference only: w16 != 0 runs the recurrent product W_hh h on fp16 operands (weights and h rounded once, fp32 accumulation, gates /

@@ -94,6 +94,40 @@ def test_gemm16_result_in_the_other_16bit_format(ops, M, K, N):
         report("gemm16 %s -> %s %dx%dx%d" % (dt, odt, M, K, N), out.float().cpu(), ref, 4 * EPS[odt] * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,glu", [(4096, 768, False), (4133, 768, False), (5000, 64, False), (4224, 512, True), (4101, 256, True),
+                                     (4096, 1024, False)])
+def test_lin256_resident_operand_kernel(ops, dt, M, N, glu):
+    """K = 256 linears with a 16-bit result (Q | K | V projection, pointwise_conv1 + GLU) on csrc/lin256.hip: against the fp32
+    reference on the rounded operands, against sfm_gemm16 on the same pack, into a strided output view, ragged last tile, result
+    in the operands' and in the other 16-bit format"""
+    ops.set_compute_dtype(dt)
+    K = 256
+    x = arr("l2x", (M, K), 21)
+    w, b = arr("l2w", (N, K), 22) / 16.0, arr("l2b", (N,), 23)
+    pw = ops.pack_linear(dev(w), dev(b), glu=glu)
+    h = q16(x, dt) @ q16(w, dt).t() + b
+    ref = h[:, :N // 2] * torch.sigmoid(h[:, N // 2:]) if glu else h
+    epi = ops.EPI_GLU if glu else ops.EPI_NONE
+    xd = dev(x).to(dt).contiguous()
+    other = torch.bfloat16 if dt == torch.float16 else torch.float16
+    for odt in (dt, other):
+        ops.set_lin256(True)
+        ncol = pw.N
+        buf = torch.full((M, ncol + 24), 7.0, device="cuda", dtype=odt)           # a column slice of a wider buffer: ldo > N
+        out = ops.linear16(xd, pw, epi=epi, out=buf[:, 8:8 + ncol])
+        ops.set_lin256(False)
+        old = ops.linear16(xd, pw, epi=epi, out_dtype=odt)
+        ops.set_lin256(True)
+        tol = 4 * EPS[odt] * float(ref.abs().max())
+        report("lin256 %s -> %s M%d N%d glu%d" % (dt, odt, M, N, glu), out.float().cpu(), ref.to(odt).float(), tol)
+        assert torch.equal(out, old), "lin256 and sfm_gemm16 differ in bits"   # same MFMA, k order and epilogue expressions
+        assert float(buf[:, :8].float().min()) == 7.0 and float(buf[:, 8 + ncol:].float().max()) == 7.0
+    # the kernel is the one that ran: below its row threshold linear16 keeps sfm_gemm16, and the results agree to rounding
+    small = ops.linear16(xd[:100], pw, epi=epi)
+    report("small-M path", small.float().cpu(), ref[:100].to(dt).float(), 4 * EPS[dt] * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_gemm16_strided_operand_views(ops, variant):
     """A is a column slice of a wider buffer (lda > K), output goes into a column slice (ldo > N)"""
