@@ -2,6 +2,7 @@
 // mask epilogue, overlap-add, sinc filter synthesis.  All are coalesced
 // streaming kernels (wave = 64 lanes, shuffles for row statistics, LDS halos).
 #include "sfm_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------
 // LayerNorm over the last dim (nn.LayerNorm; models/conformer.py:43,68,107,150,
@@ -458,6 +459,113 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const u16* __restrict__
   }
 }
 
+// fp16 form of the kernel above (KS odd): the taps are summed two at a time with v_dot2_f32_f16 - (w[2j], w[2j+1]) . (x[t+2j], x[t+2j+1]),
+// fp32 accumulation, products of two fp16 values are exact in fp32 - instead of one v_fma_f32 per tap after two converts per input
+// value.  The time pairs of a channel are built from the staged channels-last rows with one v_perm_b32 each (even pairs for the
+// even outputs of a step, odd pairs for the odd ones): per 4 outputs x 2 channels 128 dot products + 68 permutes against 248
+// multiply-adds + 68 converts.  New rounding: the taps, once, to fp16 (the operand format of every MFMA of the path).
+typedef _Float16 dw_h2 __attribute__((ext_vector_type(2)));
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_dot_kernel(const u16* __restrict__ x, const float* __restrict__ wT,
+                                                         const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         void* __restrict__ out, int Tlen, int C, int act, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  u16* xs = reinterpret_cast<u16*>(dsm);                                 // [DW_TT + KS - 1][C]
+  constexpr int padl = (KS - 1) / 2, rows = DW_TT + KS - 1;
+  constexpr int NP = (KS + 1) / 2;                                       // tap pairs (the last one = (w[KS-1], 0))
+  constexpr int NR = KS + 3;                                             // staged rows a step of 4 outputs reads
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * DW_TT, b = blockIdx.y;
+  const u16* xb = x + (long long)b * Tlen * C;
+  const int cpr = C >> 3;
+  // staging in batches of 12 chunks per thread with ALL of a batch's loads issued before its first LDS write (the rolled
+  // load -> write loop of the kernel above pays one memory round trip per 16 bytes: 12 in a row at C = 256, and that latency
+  // chain, not the arithmetic, is most of a workgroup's life)
+  for (int e0 = tid; e0 < rows * cpr; e0 += 256 * 12) {
+    u32x4 v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int e = e0 + 256 * i;
+      const int r = e / cpr, c8 = (e - r * cpr) * 8;
+      const int t = t0 - padl + r;
+      v[i] = u32x4{0u, 0u, 0u, 0u};
+      if (e < rows * cpr && t >= 0 && t < Tlen) v[i] = *reinterpret_cast<const u32x4*>(xb + (long long)t * C + c8);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int e = e0 + 256 * i;
+      const int r = e / cpr, c8 = (e - r * cpr) * 8;
+      if (e < rows * cpr) *reinterpret_cast<u32x4*>(&xs[r * C + c8]) = v[i];
+    }
+  }
+  const int npair = C >> 1;
+  const int p = tid % npair, grp = tid / npair, ngrp = 256 / npair;
+  const int c = 2 * p;
+  dw_h2 w0[NP], w1[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const f32x2 a = *reinterpret_cast<const f32x2*>(wT + (2 * j) * C + c);
+    f32x2 bq = {0.f, 0.f};
+    if (2 * j + 1 < KS) bq = *reinterpret_cast<const f32x2*>(wT + (2 * j + 1) * C + c);
+    w0[j] = dw_h2{(_Float16)a[0], (_Float16)bq[0]};
+    w1[j] = dw_h2{(_Float16)a[1], (_Float16)bq[1]};
+  }
+  const float s0 = sc[c], s1 = sc[c + 1], h0 = sh[c], h1 = sh[c + 1];
+  __syncthreads();
+  const long long obase = (long long)b * Tlen * C;
+  const int per = DW_TT / ngrp;                                          // frames per thread (multiple of 4)
+  for (int tl = grp * per; tl < (grp + 1) * per; tl += 4) {
+    uint32_t d[NR + 1];                                                  // row k of the step: (x[k][c], x[k][c + 1])
+#pragma unroll
+    for (int k = 0; k < NR; ++k) d[k] = *reinterpret_cast<const uint32_t*>(&xs[(tl + k) * C + c]);
+    d[NR] = d[NR - 1];                                                   // (multiplied by the zero of the last tap pair)
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        // time pair (x[o + 2j], x[o + 2j + 1]) of each channel: the low / high halves of two staged rows
+        const uint32_t lo = __builtin_amdgcn_perm(d[o + 2 * j + 1], d[o + 2 * j], 0x05040100u);
+        const uint32_t hi = __builtin_amdgcn_perm(d[o + 2 * j + 1], d[o + 2 * j], 0x07060302u);
+        a0[o] = __builtin_amdgcn_fdot2(w0[j], __builtin_bit_cast(dw_h2, lo), a0[o], false);
+        a1[o] = __builtin_amdgcn_fdot2(w1[j], __builtin_bit_cast(dw_h2, hi), a1[o], false);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int t = t0 + tl + o;
+      if (t < Tlen) {
+        float y0 = a0[o] * s0 + h0, y1 = a1[o] * s1 + h1;
+        if (act) { y0 = swish_f(y0); y1 = swish_f(y1); }
+        const long long off = obase + (long long)t * C + c;
+        if (out_f32) {
+          f32x2 w = {y0, y1};
+          *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(out) + off) = w;
+        } else {
+          *reinterpret_cast<uint32_t*>(reinterpret_cast<u16*>(out) + off) = pack2<F16>(y0, y1);
+        }
+      }
+    }
+  }
+}
+
+template <int KS>
+static int launch_dwconv_dot(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int Tn,
+                             int C, int act, int out_f32, hipStream_t st) {
+  const int lds = (DW_TT + KS - 1) * C * 2;
+  static bool attr_dev[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
+  if (!attr_dev[dev]) {
+    if (hipFuncSetAttribute((const void*)dwconv_dot_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SFM_ERR_LAUNCH;
+    attr_dev[dev] = true;
+  }
+  SFM_LAUNCH((dwconv_dot_kernel<KS>), dim3((Tn + DW_TT - 1) / DW_TT, B), dim3(256), lds, st, (const u16*)x, wT, sc, sh, out, Tn,
+             C, act, out_f32);
+  return SFM_OK;
+}
+
 template <class T, int KS>
 static int launch_dwconv_reg(const void* x, const float* wT, const float* sc, const float* sh, void* out, int B, int Tn,
                              int C, int act, int out_f32, hipStream_t st) {
@@ -484,6 +592,9 @@ extern "C" int sfm_dwconv_folded(const void* x, const float* wT, const float* sc
   if (B <= 0 || T <= 0 || C % 8 != 0 || C > 512 || (256 % (C / 2)) != 0 || (DW_TT / (256 / (C / 2))) % 4 != 0)
     return SFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  // fp16: the dot-product form (SFM_DWCONV_DOT=0 keeps the multiply-add kernel: the A/B knob)
+  static const int dot_on = getenv("SFM_DWCONV_DOT") ? atoi(getenv("SFM_DWCONV_DOT")) : 1;
+  if (KS == 31 && dtype == SFM_DT_F16 && dot_on) return launch_dwconv_dot<31>(x, wT, sc, sh, out, B, T, C, act, out_f32, st);
   if (KS == 31) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 31>(x, wT, sc, sh, out, B, T, C, act, out_f32, st)
                                            : launch_dwconv_reg<BF16, 31>(x, wT, sc, sh, out, B, T, C, act, out_f32, st);
   if (KS == 7) return dtype == SFM_DT_F16 ? launch_dwconv_reg<F16, 7>(x, wT, sc, sh, out, B, T, C, act, out_f32, st)
