@@ -410,7 +410,8 @@ int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const floa
      glu != 0: out[M, NW / 2] = GLU(A W^T + b), W rows in 64-row groups of 32 values | 32 gates
                                                                          (models/conformer.py:92-96, pointwise_conv1 + GLU)
    A rows have stride lda >= 256 (16-bit elements, multiple of 8), W is [NW, 256] row-major, NW % 64 == 0 (% 128 with glu),
-   bias [NW] fp32 or NULL; out_dtype may be the other 16-bit format (one rounding of the fp32 accumulators).  The same contract as
+   bias [NW] fp32 or NULL; out_dtype may be the other 16-bit format (one rounding of the fp32 accumulators) or, with glu == 0,
+   2 = fp32 (ldo a multiple of 4; the BiLSTM input projections of agents/cpea.py:43-50).  The same contract as
    sfm_gemm16 on these shapes, and the same bits (same MFMA, same k order, same epilogue expressions). */
 int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M, int NW, int lda, int ldo, int glu, int dtype,
                int out_dtype, void* stream);

@@ -42,7 +42,8 @@ __device__ __forceinline__ void l2_barrier() {
 }
 
 // GLU: 0 = plain (64 output columns per chunk), 1 = GLU (a chunk's 64 W rows = 32 values | 32 gates -> 32 output columns)
-// OTHER: the result is written in the other 16-bit format (a run-time flag here is a branch per convert inside the MFMA stream)
+// OTHER: 1 = the result is written in the other 16-bit format (a run-time flag here is a branch per convert inside the MFMA
+// stream); 2 = fp32 result, stored straight from the accumulator quads (16 bytes per lane, no LDS image)
 template <class T, int GLU, int OTHER>
 __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, const u16* __restrict__ W,
                                                      const float* __restrict__ bias, u16* __restrict__ out, int M, int NW,
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
   };
   // result of chunk c, register quad q -> 8 bytes of the image of group c / CPG (row r1; 16-byte chunk j at j ^ ((row >> 1) & 7))
-  constexpr bool other = OTHER != 0;
+  constexpr bool other = OTHER == 1;
+  static_assert(!(GLU && OTHER == 2), "fp32 result: plain epilogue only");
   auto epi_quad = [&](const f32x16& s, int c, int q) {
     float y[4];
     int col;                                                        // first of 4 consecutive columns inside the 64-column image
@@ -127,6 +129,13 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = s[4 * q + e] + bv[e];
       col = half * 32 + 8 * q + 4 * hl;
+    }
+    if constexpr (OTHER == 2) {
+      // always issued (the counted waits depend on it): rows beyond M get an out-of-range offset
+      const int m = m0 + r1;
+      const int voff = m < M ? (m * ldo + c * 64 + col) * 4 : o_bytes;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{y[0], y[1], y[2], y[3]}), o_rs, voff, 0, 0);
+      return;
     }
     u32x2 pk;
     pk[0] = pack2_out<T>(y[0], y[1], other);
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
   int stored = 0;                                                   // groups already written to HBM
   for (int c = 0; c + 1 < nch; ++c) {
     bool did_store = false;
-    if (SFM_L2_ABL != 1 && c >= CPG && (c % CPG) == 0) {            // group c / CPG - 1 was completed in X(c - 1)
+    if (SFM_L2_ABL != 1 && OTHER != 2 && c >= CPG && (c % CPG) == 0) {   // group c / CPG - 1 was completed in X(c - 1)
       store_group(stored);
       ++stored;
       did_store = true;
@@ -202,7 +211,8 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
     }
     s1 = s1n;
     // W(c + 2) has landed: behind it in this wave's queue are the 4 pieces of W(c + 3) and this period's row stores
-    if (did_store) l2_wait_vmcnt<6>();
+    if (OTHER == 2) l2_wait_vmcnt<8>();                             // (fp32: the 4 quad stores of this period instead)
+    else if (did_store) l2_wait_vmcnt<6>();
     else l2_wait_vmcnt<4>();
     l2_barrier();                                                   // image of chunk c complete; W(c + 1) read by everyone
     stage_free = stage_next;
@@ -214,35 +224,39 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
   l2_wait_vmcnt<0>();                                               // (the zero refills past the last chunk have landed)
   l2_barrier();
   const int ngroups = (nch + CPG - 1) / CPG;
-  for (; stored < ngroups; ++stored) store_group(stored);
+  if (OTHER != 2)
+    for (; stored < ngroups; ++stored) store_group(stored);
 }
 
 // A [M, lda] 16-bit rows with 256 valid columns, W [NW, 256] 16-bit row-major (nn.Linear layout; glu != 0: the rows in the
 // order of ops.pack_linear(glu=True)), bias [NW] fp32 or NULL, out [M, ldo] 16-bit: NW columns (glu: NW / 2) in the operands'
-// format or, when out_dtype differs from dtype, in the other 16-bit format.
+// format or, when out_dtype differs from dtype, in the other 16-bit format; out_dtype 2 (SFM_DT_F32, plain epilogue only): fp32.
 extern "C" int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M, int NW, int lda, int ldo, int glu,
                           int dtype, int out_dtype, void* stream) {
   if (!A || !W || !out) return SFM_ERR_ARG;
-  if ((dtype != SFM_DT_BF16 && dtype != SFM_DT_F16) || (out_dtype != SFM_DT_BF16 && out_dtype != SFM_DT_F16)) return SFM_ERR_ARG;
-  if (M <= 0 || NW <= 0 || (NW % 64) != 0 || NW > 2048 || (glu && (NW % 128) != 0) || lda < L2_K || (lda % 8) != 0 || (ldo % 8) != 0 ||
-      ldo < (glu ? NW / 2 : NW))
+  if ((dtype != SFM_DT_BF16 && dtype != SFM_DT_F16) || (out_dtype != SFM_DT_BF16 && out_dtype != SFM_DT_F16 && out_dtype != 2))
+    return SFM_ERR_ARG;
+  const bool f32o = out_dtype == 2;
+  if (M <= 0 || NW <= 0 || (NW % 64) != 0 || NW > 2048 || (glu && ((NW % 128) != 0 || f32o)) || lda < L2_K || (lda % 8) != 0 ||
+      (ldo % (f32o ? 4 : 8)) != 0 || ldo < (glu ? NW / 2 : NW))
     return SFM_ERR_SHAPE;
   const long long a_bytes = (long long)(M - 1) * lda * 2 + L2_K * 2;
-  const long long o_bytes = (long long)(M - 1) * ldo * 2 + (glu ? NW / 2 : NW) * 2;
+  const long long o_bytes = ((long long)(M - 1) * ldo + (glu ? NW / 2 : NW)) * (f32o ? 4 : 2);
   if (a_bytes >= (1LL << 31) || o_bytes >= (1LL << 31)) return SFM_ERR_SHAPE;   // 32-bit buffer offsets
   const int lds = L2_NSTAGE * L2_STAGE + 2 * L2_IMG + NW * 4;
   const int w_bytes = NW * L2_K * 2;
-  const int other = out_dtype != dtype ? 1 : 0;
+  const int other = f32o ? 2 : (out_dtype != dtype ? 1 : 0);
   dim3 grid((M + L2_BM - 1) / L2_BM), block(512);
   hipStream_t st = (hipStream_t)stream;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
-  static bool attr_set[64][8] = {{false}};
-  const int ki = (dtype == SFM_DT_F16 ? 4 : 0) + (glu ? 2 : 0) + other;
+  static bool attr_set[64][12] = {{false}};
+  const int ki = (dtype == SFM_DT_F16 ? 6 : 0) + (glu ? 3 : 0) + other;
 #define L2_FN(TT, G, O) (const void*)lin256_kernel<TT, G, O>
-  const void* fns[8] = {L2_FN(BF16, 0, 0), L2_FN(BF16, 0, 1), L2_FN(BF16, 1, 0), L2_FN(BF16, 1, 1),
-                        L2_FN(F16, 0, 0),  L2_FN(F16, 0, 1),  L2_FN(F16, 1, 0),  L2_FN(F16, 1, 1)};
+  const void* fns[12] = {L2_FN(BF16, 0, 0), L2_FN(BF16, 0, 1), L2_FN(BF16, 0, 2), L2_FN(BF16, 1, 0), L2_FN(BF16, 1, 1), nullptr,
+                         L2_FN(F16, 0, 0),  L2_FN(F16, 0, 1),  L2_FN(F16, 0, 2),  L2_FN(F16, 1, 0),  L2_FN(F16, 1, 1),  nullptr};
 #undef L2_FN
+  if (!fns[ki]) return SFM_ERR_SHAPE;
   if (!attr_set[dev][ki]) {
     if (hipFuncSetAttribute(fns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFM_ERR_LAUNCH;
     attr_set[dev][ki] = true;
@@ -252,11 +266,13 @@ extern "C" int sfm_lin256(const void* A, const void* W, const float* bias, void*
   switch (ki) {
     case 0: L2_GO(BF16, 0, 0); break;
     case 1: L2_GO(BF16, 0, 1); break;
-    case 2: L2_GO(BF16, 1, 0); break;
-    case 3: L2_GO(BF16, 1, 1); break;
-    case 4: L2_GO(F16, 0, 0); break;
-    case 5: L2_GO(F16, 0, 1); break;
-    case 6: L2_GO(F16, 1, 0); break;
+    case 2: L2_GO(BF16, 0, 2); break;
+    case 3: L2_GO(BF16, 1, 0); break;
+    case 4: L2_GO(BF16, 1, 1); break;
+    case 6: L2_GO(F16, 0, 0); break;
+    case 7: L2_GO(F16, 0, 1); break;
+    case 8: L2_GO(F16, 0, 2); break;
+    case 9: L2_GO(F16, 1, 0); break;
     default: L2_GO(F16, 1, 1); break;
   }
 #undef L2_GO

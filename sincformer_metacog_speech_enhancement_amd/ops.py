@@ -443,9 +443,28 @@ def _lin256_ok(x16, pw, epi, out, resid, nsplit, p_drop):
     return (_LIN256["on"] and _state["gemm_variant"] == 0 and epi in (EPI_NONE, EPI_GLU) and (epi == EPI_GLU) == bool(pw.glu) and
             pw.K == 256 and pw.Kpad == 256 and pw.ksize == 1 and pw.Npad % (128 if pw.glu else 64) == 0 and
             (pw.Npad == (2 * pw.N if pw.glu else pw.N)) and pw.Npad <= 2048 and
-            resid is None and nsplit == 0 and p_drop == 0.0 and out.dtype in (torch.float16, torch.bfloat16) and
-            x16.shape[0] >= 4096 and x16.stride(1) == 1 and out.stride(1) == 1 and x16.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and
+            resid is None and nsplit == 0 and p_drop == 0.0 and
+            # (the kernel's fp32 result - ops.lin256 - is NOT routed here: its 16-byte-per-lane stores measured 286 against 219 us
+            #  on the BiLSTM input projections, M 131 072 x N 1024: tools/lin256_bench.py)
+            out.dtype in (torch.float16, torch.bfloat16) and
+            x16.shape[0] >= 4096 and x16.stride(1) == 1 and out.stride(1) == 1 and x16.stride(0) % 8 == 0 and
+            (out.stride(0) % 8 == 0 or out.dtype == torch.float32) and
             x16.dtype == _state["dtype"] and pw.w.dtype == _state["dtype"])
+
+
+def lin256(x16, pw, out):
+    """sfm_lin256 (csrc/lin256.hip): out = x16[:, :256] @ W^T + b, or its GLU when pw was packed with glu=True; out 16-bit (either
+    format) or, plain epilogue only, fp32.  linear16 routes the shapes of the path here (see _lin256_ok)."""
+    _need_dev(x16, out)
+    L = _lib.load()
+    M, ld = x16.shape[0], x16.stride(0)
+    odt_id = 2 if out.dtype == torch.float32 else (1 if out.dtype == torch.float16 else 0)
+    osz = 4.0 if out.dtype == torch.float32 else 2.0
+    _call("gemm16", L.sfm_lin256, (_p(x16), _p(pw.w), _p(pw.bias), _p(out), M, pw.Npad, ld, out.stride(0), 1 if pw.glu else 0,
+                                   _dt(), odt_id, _stream()),
+          2.0 * M * pw.Npad * 256, M * 256 * 2.0 + pw.Npad * 512.0 + M * pw.N * osz,
+          tag="M%d N%d K256 lin256%s o%d" % (M, pw.Npad, " glu" if pw.glu else "", int(osz)))
+    return out
 
 
 def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=None, nsplit=0, p_drop=0.0, seed=0):
@@ -455,14 +474,7 @@ def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=N
         odt = out_dtype or (torch.float32 if epi == EPI_RESID else _state["dtype"])
         out = torch.empty(M, pw.N, device=x16.device, dtype=odt)
     if _lin256_ok(x16, pw, epi, out, resid, nsplit, p_drop):
-        _need_dev(x16, out)
-        L = _lib.load()
-        odt_id = 1 if out.dtype == torch.float16 else 0
-        _call("gemm16", L.sfm_lin256, (_p(x16), _p(pw.w), _p(pw.bias), _p(out), M, pw.Npad, ld, out.stride(0), 1 if pw.glu else 0,
-                                       _dt(), odt_id, _stream()),
-              2.0 * M * pw.Npad * 256, M * 256 * 2.0 + pw.Npad * 512.0 + M * pw.N * 2.0,
-              tag="M%d N%d K256 lin256%s" % (M, pw.Npad, " glu" if pw.glu else ""))
-        return out
+        return lin256(x16, pw, out)
     gemm16(x16, pw, out, B=1, Lout=M, Lin=M, a_batch_stride=0, lda=ld, ldo=out.stride(0), o_batch_stride=0, epi=epi,
            resid=resid, ldr=(resid.stride(0) if resid is not None else 0), alpha=alpha, nsplit=nsplit, p_drop=p_drop,
            seed=seed)

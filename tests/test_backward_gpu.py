@@ -461,6 +461,8 @@ def test_ordered_reductions_repeat_bitwise_and_match_the_atomic_form(ops):
                 scale = float(v.double().abs().max()) + 1e-30
                 err = float((u.double() - v.double()).abs().max()) / scale
                 print("%-22s output %d: ordered vs atomics max|diff| / max|value| = %.2e" % (name, i, err))
-                assert err < 2e-5, (name, i, err)
+                # (a 16-bit output may differ by one rounding step where the two fp32 sums straddle a rounding boundary - the atomic
+                #  order changes from run to run, so this did show up once in many runs: 7e-5 of the tensor's maximum)
+                assert err < (2e-5 if v.dtype in (torch.float32, torch.float64) else 1e-3), (name, i, err)
     finally:
         ops.set_deterministic(True)

@@ -123,6 +123,12 @@ def test_lin256_resident_operand_kernel(ops, dt, M, N, glu):
         report("lin256 %s -> %s M%d N%d glu%d" % (dt, odt, M, N, glu), out.float().cpu(), ref.to(odt).float(), tol)
         assert torch.equal(out, old), "lin256 and sfm_gemm16 differ in bits"   # same MFMA, k order and epilogue expressions
         assert float(buf[:, :8].float().min()) == 7.0 and float(buf[:, 8 + ncol:].float().max()) == 7.0
+    if not glu:                                                                    # fp32 result, stored from the accumulator quads
+        out32 = torch.full((M, N + 4), 7.0, device="cuda", dtype=torch.float32)
+        ops.lin256(xd, pw, out32[:, :N])                                           # (linear16 keeps sfm_gemm16 for fp32 results)
+        old32 = ops.linear16(xd, pw, out_dtype=torch.float32)
+        report("lin256 fp32 out", out32[:, :N].cpu(), ref, 2e-4 * max(1.0, float(ref.abs().max())))
+        assert torch.equal(out32[:, :N], old32) and float(out32[:, N:].min()) == 7.0
     # the kernel is the one that ran: below its row threshold linear16 keeps sfm_gemm16, and the results agree to rounding
     small = ops.linear16(xd[:100], pw, epi=epi)
     report("small-M path", small.float().cpu(), ref[:100].to(dt).float(), 4 * EPS[dt] * float(ref.abs().max()))
