@@ -415,6 +415,12 @@ int sfm_attention_bwd(const void* qkv, const void* O, const void* dO, const floa
    sfm_gemm16 on these shapes, and the same bits (same MFMA, same k order, same epilogue expressions). */
 int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M, int NW, int lda, int ldo, int glu, int dtype,
                int out_dtype, void* stream);
+/* The same with LayerNorm(X32[m, :256]; lnw, lnb, eps) as the operand rows (models/conformer.py:88 conv.layer_norm -> :92 pointwise_conv1):
+   the workgroup that owns 128 rows for all output columns normalises them once, in its prologue, from the fp32 residual stream
+   [M, ldx] - the arithmetic of sfm_layernorm on D = 256, bit for bit -, so sfm_layernorm + sfm_lin256 in one launch and without the
+   16-bit normalised tensor in HBM.  16-bit results only. */
+int sfm_ln_lin256(const float* X32, int ldx, const float* lnw, const float* lnb, float eps, const void* W, const float* bias,
+                  void* out, int M, int NW, int ldo, int glu, int dtype, int out_dtype, void* stream);
 
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);

@@ -44,10 +44,20 @@ __device__ __forceinline__ void l2_barrier() {
 // GLU: 0 = plain (64 output columns per chunk), 1 = GLU (a chunk's 64 W rows = 32 values | 32 gates -> 32 output columns)
 // OTHER: 1 = the result is written in the other 16-bit format (a run-time flag here is a branch per convert inside the MFMA
 // stream); 2 = fp32 result, stored straight from the accumulator quads (16 bytes per lane, no LDS image)
-template <class T, int GLU, int OTHER>
+// LN: the operand rows are LayerNorm(X32[m, :256]) (models/conformer.py:88, conv.layer_norm in front of pointwise_conv1): one
+// workgroup owns whole rows for all N columns, so the rows are normalised ONCE, in the prologue, from the fp32 residual stream
+// (the expressions of layernorm256_kernel, pointwise.hip, bit for bit) and the 16-bit normalised tensor never exists in HBM.
+struct L2Ln {
+  const float* x;                         // [M, ldx] fp32 (NULL: A is the 16-bit operand)
+  const float* w;
+  const float* b;
+  int ldx;
+  float eps;
+};
+template <class T, int GLU, int OTHER, int LN>
 __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, const u16* __restrict__ W,
                                                      const float* __restrict__ bias, u16* __restrict__ out, int M, int NW,
-                                                     int lda, int ldo, int a_bytes, int w_bytes, int o_bytes) {
+                                                     int lda, int ldo, int a_bytes, int w_bytes, int o_bytes, L2Ln ln) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS map: W ring 3 x 32 KB (the first 64 KB hold the A tile [128][512 B] during the prologue), two result images, bias
   unsigned char* img0 = smem + L2_NSTAGE * L2_STAGE;
@@ -65,14 +75,43 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
 
   // ---- prologue: the A tile by LDS-DMA (an instruction = 2 rows x 512 B; 16-byte chunk p of row r holds logical chunk
   //      p ^ (r & 15); rows >= M are outside the descriptor's range and arrive as zeros), the bias vector ----
+  if constexpr (LN) {
+    // wave w normalises rows 16w .. 16w + 15, a lane 4 consecutive columns; all 16 row loads are issued before the first use
+    const f32x4 gw = *reinterpret_cast<const f32x4*>(ln.w + 4 * lane), gb = *reinterpret_cast<const f32x4*>(ln.b + 4 * lane);
+    f32x4 xv[16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int inst = wave * 8 + i;
-    const int row = inst * 2 + (lane >> 5);
-    const int lc = (lane & 31) ^ (row & 15);
-    const long long voff = ((long long)(m0 + row) * lda + lc * 8) * 2;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (l2_lds_ptr_t)(smem + inst * 1024), 16,
-                                             voff < a_bytes ? (int)voff : a_bytes, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+      int m = m0 + wave * 16 + r;
+      m = m < M ? m : M - 1;                                        // clamped: computed, never stored
+      xv[r] = *reinterpret_cast<const f32x4*>(ln.x + (long long)m * ln.ldx + 4 * lane);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 16 + r;
+      const f32x4 v = xv[r];
+      const float mean = wave_sum_dpp((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+      float d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = v[j] - mean;
+      const float rstd = rsqrtf(wave_sum_dpp((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f) + ln.eps);
+      float y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = d[j] * rstd * gw[j] + gb[j];
+      u32x2 pk;
+      pk[0] = pack2<T>(y[0], y[1]);
+      pk[1] = pack2<T>(y[2], y[3]);
+      *reinterpret_cast<u32x2*>(smem + row * 512 + (((lane >> 1) ^ (row & 15)) << 4) + (lane & 1) * 8) = pk;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int inst = wave * 8 + i;
+      const int row = inst * 2 + (lane >> 5);
+      const int lc = (lane & 31) ^ (row & 15);
+      const long long voff = ((long long)(m0 + row) * lda + lc * 8) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (l2_lds_ptr_t)(smem + inst * 1024), 16,
+                                               voff < a_bytes ? (int)voff : a_bytes, 0, 0, 0);
+    }
   }
   for (int i = tid; i < NW; i += 512) bs[i] = bias ? bias[i] : 0.f;
   l2_wait_vmcnt<0>();
@@ -231,16 +270,21 @@ __global__ __launch_bounds__(512) void lin256_kernel(const u16* __restrict__ A, 
 // A [M, lda] 16-bit rows with 256 valid columns, W [NW, 256] 16-bit row-major (nn.Linear layout; glu != 0: the rows in the
 // order of ops.pack_linear(glu=True)), bias [NW] fp32 or NULL, out [M, ldo] 16-bit: NW columns (glu: NW / 2) in the operands'
 // format or, when out_dtype differs from dtype, in the other 16-bit format; out_dtype 2 (SFM_DT_F32, plain epilogue only): fp32.
-extern "C" int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M, int NW, int lda, int ldo, int glu,
-                          int dtype, int out_dtype, void* stream) {
-  if (!A || !W || !out) return SFM_ERR_ARG;
+static int lin256_launch(const void* A, const float* X32, int ldx, const float* lnw, const float* lnb, float eps, const void* W,
+                         const float* bias, void* out, int M, int NW, int lda, int ldo, int glu, int dtype, int out_dtype,
+                         void* stream) {
+  const bool has_ln = X32 != nullptr;
+  if ((!A && !has_ln) || !W || !out || (has_ln && (!lnw || !lnb))) return SFM_ERR_ARG;
   if ((dtype != SFM_DT_BF16 && dtype != SFM_DT_F16) || (out_dtype != SFM_DT_BF16 && out_dtype != SFM_DT_F16 && out_dtype != 2))
     return SFM_ERR_ARG;
   const bool f32o = out_dtype == 2;
-  if (M <= 0 || NW <= 0 || (NW % 64) != 0 || NW > 2048 || (glu && ((NW % 128) != 0 || f32o)) || lda < L2_K || (lda % 8) != 0 ||
-      (ldo % (f32o ? 4 : 8)) != 0 || ldo < (glu ? NW / 2 : NW))
+  if (M <= 0 || NW <= 0 || (NW % 64) != 0 || NW > 2048 || (glu && ((NW % 128) != 0 || f32o)) || (ldo % (f32o ? 4 : 8)) != 0 ||
+      ldo < (glu ? NW / 2 : NW))
     return SFM_ERR_SHAPE;
-  const long long a_bytes = (long long)(M - 1) * lda * 2 + L2_K * 2;
+  if (has_ln ? (ldx < L2_K || (ldx % 4) != 0 || f32o || (((uintptr_t)X32 | (uintptr_t)lnw | (uintptr_t)lnb) % 16) != 0)
+             : (lda < L2_K || (lda % 8) != 0))
+    return SFM_ERR_SHAPE;
+  const long long a_bytes = has_ln ? 0 : (long long)(M - 1) * lda * 2 + L2_K * 2;
   const long long o_bytes = ((long long)(M - 1) * ldo + (glu ? NW / 2 : NW)) * (f32o ? 4 : 2);
   if (a_bytes >= (1LL << 31) || o_bytes >= (1LL << 31)) return SFM_ERR_SHAPE;   // 32-bit buffer offsets
   const int lds = L2_NSTAGE * L2_STAGE + 2 * L2_IMG + NW * 4;
@@ -250,31 +294,54 @@ extern "C" int sfm_lin256(const void* A, const void* W, const float* bias, void*
   hipStream_t st = (hipStream_t)stream;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SFM_ERR_LAUNCH;
-  static bool attr_set[64][12] = {{false}};
-  const int ki = (dtype == SFM_DT_F16 ? 6 : 0) + (glu ? 3 : 0) + other;
-#define L2_FN(TT, G, O) (const void*)lin256_kernel<TT, G, O>
-  const void* fns[12] = {L2_FN(BF16, 0, 0), L2_FN(BF16, 0, 1), L2_FN(BF16, 0, 2), L2_FN(BF16, 1, 0), L2_FN(BF16, 1, 1), nullptr,
-                         L2_FN(F16, 0, 0),  L2_FN(F16, 0, 1),  L2_FN(F16, 0, 2),  L2_FN(F16, 1, 0),  L2_FN(F16, 1, 1),  nullptr};
+  static bool attr_set[64][24] = {{false}};
+  const int ki = (has_ln ? 12 : 0) + (dtype == SFM_DT_F16 ? 6 : 0) + (glu ? 3 : 0) + other;
+#define L2_FN(TT, G, O, N) (const void*)lin256_kernel<TT, G, O, N>
+  const void* fns[24] = {L2_FN(BF16, 0, 0, 0), L2_FN(BF16, 0, 1, 0), L2_FN(BF16, 0, 2, 0), L2_FN(BF16, 1, 0, 0), L2_FN(BF16, 1, 1, 0), nullptr,
+                         L2_FN(F16, 0, 0, 0),  L2_FN(F16, 0, 1, 0),  L2_FN(F16, 0, 2, 0),  L2_FN(F16, 1, 0, 0),  L2_FN(F16, 1, 1, 0),  nullptr,
+                         L2_FN(BF16, 0, 0, 1), L2_FN(BF16, 0, 1, 1), nullptr, L2_FN(BF16, 1, 0, 1), L2_FN(BF16, 1, 1, 1), nullptr,
+                         L2_FN(F16, 0, 0, 1),  L2_FN(F16, 0, 1, 1),  nullptr, L2_FN(F16, 1, 0, 1),  L2_FN(F16, 1, 1, 1),  nullptr};
 #undef L2_FN
   if (!fns[ki]) return SFM_ERR_SHAPE;
   if (!attr_set[dev][ki]) {
     if (hipFuncSetAttribute(fns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFM_ERR_LAUNCH;
     attr_set[dev][ki] = true;
   }
-#define L2_GO(TT, G, O) SFM_LAUNCH((lin256_kernel<TT, G, O>), grid, block, lds, st, (const u16*)A, (const u16*)W, bias, (u16*)out, M, \
-                                   NW, lda, ldo, (int)a_bytes, w_bytes, (int)o_bytes)
+  const L2Ln ln = {X32, lnw, lnb, ldx, eps};
+#define L2_GO(TT, G, O, N) SFM_LAUNCH((lin256_kernel<TT, G, O, N>), grid, block, lds, st, (const u16*)A, (const u16*)W, bias, (u16*)out, \
+                                      M, NW, lda, ldo, (int)a_bytes, w_bytes, (int)o_bytes, ln)
   switch (ki) {
-    case 0: L2_GO(BF16, 0, 0); break;
-    case 1: L2_GO(BF16, 0, 1); break;
-    case 2: L2_GO(BF16, 0, 2); break;
-    case 3: L2_GO(BF16, 1, 0); break;
-    case 4: L2_GO(BF16, 1, 1); break;
-    case 6: L2_GO(F16, 0, 0); break;
-    case 7: L2_GO(F16, 0, 1); break;
-    case 8: L2_GO(F16, 0, 2); break;
-    case 9: L2_GO(F16, 1, 0); break;
-    default: L2_GO(F16, 1, 1); break;
+    case 0: L2_GO(BF16, 0, 0, 0); break;
+    case 1: L2_GO(BF16, 0, 1, 0); break;
+    case 2: L2_GO(BF16, 0, 2, 0); break;
+    case 3: L2_GO(BF16, 1, 0, 0); break;
+    case 4: L2_GO(BF16, 1, 1, 0); break;
+    case 6: L2_GO(F16, 0, 0, 0); break;
+    case 7: L2_GO(F16, 0, 1, 0); break;
+    case 8: L2_GO(F16, 0, 2, 0); break;
+    case 9: L2_GO(F16, 1, 0, 0); break;
+    case 10: L2_GO(F16, 1, 1, 0); break;
+    case 12: L2_GO(BF16, 0, 0, 1); break;
+    case 13: L2_GO(BF16, 0, 1, 1); break;
+    case 15: L2_GO(BF16, 1, 0, 1); break;
+    case 16: L2_GO(BF16, 1, 1, 1); break;
+    case 18: L2_GO(F16, 0, 0, 1); break;
+    case 19: L2_GO(F16, 0, 1, 1); break;
+    case 21: L2_GO(F16, 1, 0, 1); break;
+    default: L2_GO(F16, 1, 1, 1); break;
   }
 #undef L2_GO
   return SFM_OK;
+}
+
+extern "C" int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M, int NW, int lda, int ldo, int glu,
+                          int dtype, int out_dtype, void* stream) {
+  return lin256_launch(A, nullptr, 0, nullptr, nullptr, 0.f, W, bias, out, M, NW, lda, ldo, glu, dtype, out_dtype, stream);
+}
+
+// the same with LayerNorm(X32[m, :256]; lnw, lnb, eps) as the operand rows (16-bit results only)
+extern "C" int sfm_ln_lin256(const float* X32, int ldx, const float* lnw, const float* lnb, float eps, const void* W,
+                             const float* bias, void* out, int M, int NW, int ldo, int glu, int dtype, int out_dtype, void* stream) {
+  if (!X32) return SFM_ERR_ARG;
+  return lin256_launch(nullptr, X32, ldx, lnw, lnb, eps, W, bias, out, M, NW, 0, ldo, glu, dtype, out_dtype, stream);
 }

@@ -239,13 +239,14 @@ def mhsa_forward(x32, pk, B, T, H, h=None, index=None):
     The projections run in the caller's ("block") operand format, the Q | K | V buffer and the attention core in the
     "attn" stage's format: the in-projection's epilogue writes that format, the attention epilogue writes the block's."""
     D = x32.shape[1]
-    if h is None:
-        h = _ln16(x32, pk["ln_w"], pk["ln_b"])
     bdt = ops.compute_dtype()
     adt = ops.stage_dtype("attn", index) if D // H == 64 else bdt      # the small-shape attention kernel keeps one format
     if pk["heads"] != H:
         raise RuntimeError("packed attention weights were scaled for %d heads, got %d" % (pk["heads"], H))
-    qkv = ops.linear16(h, pk["win"], out_dtype=adt)
+    if h is None:
+        qkv = ops.ln_linear16(x32, pk["ln_w"], pk["ln_b"], pk["win"], out_dtype=adt)
+    else:
+        qkv = ops.linear16(h, pk["win"], out_dtype=adt)
     if adt is bdt:
         o = ops.attention(qkv, B, T, H, D // H, prescaled=True)
     else:
@@ -256,8 +257,7 @@ def mhsa_forward(x32, pk, B, T, H, h=None, index=None):
 
 def convmod_forward(x32, pk, B, T):
     D = x32.shape[1]
-    h = _ln16(x32, pk["ln_w"], pk["ln_b"])
-    g = ops.linear16(h, pk["pw1"], epi=ops.EPI_GLU)
+    g = ops.ln_linear16(x32, pk["ln_w"], pk["ln_b"], pk["pw1"], epi=ops.EPI_GLU)      # LayerNorm = the GEMM kernel's prologue
     if pk["dw_folded"] is not None:
         d = ops.dwconv_folded(g, pk["dw_folded"][0], pk["dw_folded"][1], pk["dw_folded"][2], B, T, D)
     else:

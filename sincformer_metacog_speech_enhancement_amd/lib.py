@@ -122,6 +122,7 @@ SIGNATURES = {
     "sfm_attention_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                           ctypes.c_uint, c_i, c_vp],
     "sfm_lin256": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_ln_lin256": [c_vp, c_i, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_ex": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_train": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],

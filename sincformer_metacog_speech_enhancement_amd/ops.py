@@ -467,6 +467,31 @@ def lin256(x16, pw, out):
     return out
 
 
+def ln_linear16(x32, ln_w, ln_b, pw, epi=EPI_NONE, out_dtype=None, eps=1e-5):
+    """linear16(LayerNorm(x32[:, :256]), pw, epi) with a 16-bit result.  On the shapes sfm_lin256 takes (K = 256, plain or GLU epilogue,
+    M >= 4096) the LayerNorm is the GEMM kernel's prologue (sfm_ln_lin256): one launch, the normalised 16-bit rows never reach HBM;
+    otherwise sfm_layernorm + linear16.  The two routes give the same bits."""
+    M = x32.shape[0]
+    out = torch.empty(M, pw.N, device=x32.device, dtype=out_dtype or _state["dtype"])
+    fused = (_LIN256["on"] and _state["gemm_variant"] == 0 and epi in (EPI_NONE, EPI_GLU) and (epi == EPI_GLU) == bool(pw.glu) and
+             pw.K == 256 and pw.Kpad == 256 and pw.ksize == 1 and pw.Npad % (128 if pw.glu else 64) == 0 and
+             pw.Npad == (2 * pw.N if pw.glu else pw.N) and pw.Npad <= 2048 and out.dtype in (torch.float16, torch.bfloat16) and
+             M >= 4096 and x32.dtype == torch.float32 and x32.stride(1) == 1 and x32.stride(0) % 4 == 0 and
+             x32.data_ptr() % 16 == 0 and ln_w.numel() == 256 and pw.w.dtype == _state["dtype"])
+    if fused:
+        _need_dev(x32, out)
+        L = _lib.load()
+        lw, lb = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        _call("gemm16", L.sfm_ln_lin256, (_p(x32), x32.stride(0), _p(lw), _p(lb), float(eps), _p(pw.w), _p(pw.bias), _p(out), M, pw.Npad,
+                                          out.stride(0), 1 if pw.glu else 0, _dt(), 1 if out.dtype == torch.float16 else 0, _stream()),
+              2.0 * M * pw.Npad * 256, M * 256 * 4.0 + pw.Npad * 512.0 + M * pw.N * 2.0,
+              tag="M%d N%d K256 ln+lin256%s" % (M, pw.Npad, " glu" if pw.glu else ""))
+        return out
+    h16 = torch.empty(M, 256, device=x32.device, dtype=_state["dtype"])
+    layernorm(x32, ln_w, ln_b, out16=h16, eps=eps)
+    return linear16(h16, pw, epi=epi, out=out)
+
+
 def linear16(x16, pw, epi=EPI_NONE, out_dtype=None, resid=None, alpha=1.0, out=None, nsplit=0, p_drop=0.0, seed=0):
     """x16 [M, K(>=pw.K)] 16-bit contiguous rows -> [M, N]."""
     M, ld = x16.shape[0], x16.stride(0)

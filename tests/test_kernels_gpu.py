@@ -134,6 +134,35 @@ def test_lin256_resident_operand_kernel(ops, dt, M, N, glu):
     report("small-M path", small.float().cpu(), ref[:100].to(dt).float(), 4 * EPS[dt] * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,glu", [(4096, 512, True), (4133, 768, False), (300, 512, True)])
+def test_ln_linear16_layernorm_as_the_gemm_prologue(ops, dt, M, N, glu):
+    """LayerNorm -> Linear (conv.layer_norm -> pointwise_conv1 + GLU; mhsa.layer_norm -> Q | K | V) with the LayerNorm in the
+    prologue of csrc/lin256.hip: the same bits as sfm_layernorm + sfm_lin256 / sfm_gemm16, against the fp32 reference, ragged last
+    tile, and the unfused route below the row threshold"""
+    ops.set_compute_dtype(dt)
+    x = arr("lnx", (M, 256), 31) * 1.7 + 0.3
+    lw, lb = arr("lnw", (256,), 32) * 0.2 + 1.0, arr("lnb", (256,), 33) * 0.1
+    w, b = arr("l2w", (N, 256), 22) / 16.0, arr("l2b", (N,), 23)
+    pw = ops.pack_linear(dev(w), dev(b), glu=glu)
+    epi = ops.EPI_GLU if glu else ops.EPI_NONE
+    xd = dev(x)
+    other = torch.bfloat16 if dt == torch.float16 else torch.float16
+    hn = torch.nn.functional.layer_norm(x, (256,), lw, lb, 1e-5)
+    h = q16(hn, dt) @ q16(w, dt).t() + b
+    ref = h[:, :N // 2] * torch.sigmoid(h[:, N // 2:]) if glu else h
+    for odt in (dt, other):
+        ops.set_lin256(True)
+        out = ops.ln_linear16(xd, dev(lw), dev(lb), pw, epi=epi, out_dtype=odt)
+        ops.set_lin256(False)
+        old = ops.ln_linear16(xd, dev(lw), dev(lb), pw, epi=epi, out_dtype=odt)      # sfm_layernorm + sfm_gemm16
+        ops.set_lin256(True)
+        assert out.dtype == odt and torch.equal(out, old), "the fused prologue and sfm_layernorm + sfm_gemm16 differ in bits"
+        # (the reference rounds LN(x) once more than the kernels see it differently: a rounding step of the operand format)
+        report("ln + lin256 %s -> %s M%d N%d glu%d" % (dt, odt, M, N, glu), out.float().cpu(), ref.to(odt).float(),
+               (6 * EPS[odt] + 16 * EPS[dt]) * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_gemm16_strided_operand_views(ops, variant):
     """A is a column slice of a wider buffer (lda > K), output goes into a column slice (ldo > N)"""
