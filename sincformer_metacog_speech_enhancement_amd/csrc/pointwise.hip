@@ -990,40 +990,41 @@ extern "C" int sfm_sum_time(const float* src, float* dst, float* scratch, int B,
 
 // log1p-magnitude normalisation of the noisy STFT (agents/msa.py:134-137) written as
 // 16-bit into the fusion operand: cols [0,F) real, [F,2F) imag, [2F, 2F+zpad) zero.
+// One wave per row, a lane per frequency bin: the magnitude and its log1p are computed ONCE per bin for both parts (the per-output-element
+// form of rounds 1-3 - 2 square roots, 2 log1pf and a 64-bit division per bin - was bound by those ~200 instructions per bin:
+// 1 TB/s).  sqrt / rcp / log by the hardware instructions (1 ulp); below mag = 2^-5, where log(1 + mag) loses its leading
+// digits, the series 1 - mag/2 + mag^2/3 - mag^3/4 (next term < 2e-7); the result is rounded to 16 bits.
 template <class T>
-__global__ __launch_bounds__(256) void stft_lognorm_pack_kernel(const float* __restrict__ re, const float* __restrict__ im,
-                                                                u16* __restrict__ dst, long long M, int F, int zpad,
-                                                                long long ld_dst) {
-  const int W = 2 * F + zpad;
-  long long total = M * W;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    long long m = e / W;
-    int c = (int)(e - m * W);
-    float v = 0.f;
-    if (c < 2 * F) {
-      int f = (c < F) ? c : c - F;
-      float r = re[m * F + f], i = im[m * F + f];
-      float mag = sqrtf(r * r + i * i + 1e-8f);
-      float nf = log1pf(mag) / mag;
-      v = ((c < F) ? r : i) * nf;
-    }
-    dst[m * ld_dst + c] = T::from_f32(v);
+__global__ __launch_bounds__(256) void stft_lognorm_pack_rows_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                                     u16* __restrict__ dst, long long M, int F, int zpad,
+                                                                     long long ld_dst) {
+  const int lane = threadIdx.x & 63;
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* rr = re + m * F;
+  const float* ii = im + m * F;
+  u16* d = dst + m * ld_dst;
+  for (int f = lane; f < F; f += 64) {
+    const float r = rr[f], i = ii[f];
+    const float mag = __builtin_amdgcn_sqrtf(r * r + i * i + 1e-8f);
+    const float nf = mag < 0.03125f ? 1.0f - mag * (0.5f - mag * (0.33333333f - mag * 0.25f))
+                                    : __logf(1.0f + mag) * __builtin_amdgcn_rcpf(mag);
+    d[f] = T::from_f32(r * nf);
+    d[F + f] = T::from_f32(i * nf);
   }
+  for (int c = 2 * F + lane; c < 2 * F + zpad; c += 64) d[c] = 0;
 }
 
 extern "C" int sfm_stft_lognorm_pack(const float* re, const float* im, void* dst, long long M, int F, int zpad,
                                      long long ld_dst, int dtype, void* stream) {
   if (!re || !im || !dst) return SFM_ERR_ARG;
   if (M <= 0 || F <= 0 || zpad < 0) return SFM_ERR_SHAPE;
-  long long nb = (M * (2 * F + zpad) + 255) / 256;
-  if (nb > 16384) nb = 16384;
+  if (M > 4LL * 2147483647LL) return SFM_ERR_SHAPE;
+  const unsigned nbr = (unsigned)((M + 3) / 4);
   if (dtype == SFM_DT_F16)
-    SFM_LAUNCH((stft_lognorm_pack_kernel<F16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
-                       (u16*)dst, M, F, zpad, ld_dst);
+    SFM_LAUNCH((stft_lognorm_pack_rows_kernel<F16>), dim3(nbr), dim3(256), 0, (hipStream_t)stream, re, im, (u16*)dst, M, F, zpad, ld_dst);
   else
-    SFM_LAUNCH((stft_lognorm_pack_kernel<BF16>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, re, im,
-                       (u16*)dst, M, F, zpad, ld_dst);
-  SFM_CHECK_LAUNCH();
+    SFM_LAUNCH((stft_lognorm_pack_rows_kernel<BF16>), dim3(nbr), dim3(256), 0, (hipStream_t)stream, re, im, (u16*)dst, M, F, zpad, ld_dst);
   return SFM_OK;
 }
 
