@@ -777,33 +777,34 @@ __global__ __launch_bounds__(256) void pool_time_vec_kernel(const void* __restri
   const long long s = ((long long)i * Tin) / Tout;
   const long long e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  // window rows in groups of 8 with ALL of a group's loads issued before the first add (a rolled `for t` loop waits out one
-  // memory round trip per row; the windows of the path are 5-6 rows)
-  for (long long t0 = s; t0 < e; t0 += 8) {
+  // window rows in groups of PG = 6 with ALL of a group's loads issued before the first add (a rolled `for t` loop waits out one
+  // memory round trip per row; the windows of the path are 5-6 rows: groups of 8 issued 2-3 clamped loads per window for nothing)
+  constexpr int PG = 6;
+  for (long long t0 = s; t0 < e; t0 += PG) {
     if (SRC == 0) {
-      f32x4 a0[8], a1[8];
+      f32x4 a0[PG], a1[PG];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < PG; ++k) {
         const long long t = t0 + k < e ? t0 + k : e - 1;     // clamped: loaded, not added
         const long long o = ((long long)b * Tin + t) * ld_src + c;
         a0[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o);
         a1[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src_) + o + 4);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < PG; ++k)
         if (t0 + k < e) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { acc[j] += a0[k][j]; acc[4 + j] += a1[k][j]; }
         }
     } else {
-      u32x4 a[8];
+      u32x4 a[PG];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < PG; ++k) {
         const long long t = t0 + k < e ? t0 + k : e - 1;
         a[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(src_) + ((long long)b * Tin + t) * ld_src + c);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < PG; ++k)
         if (t0 + k < e) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

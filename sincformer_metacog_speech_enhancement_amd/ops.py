@@ -444,9 +444,7 @@ def _lin256_ok(x16, pw, epi, out, resid, nsplit, p_drop):
             pw.K == 256 and pw.Kpad == 256 and pw.ksize == 1 and pw.Npad % (128 if pw.glu else 64) == 0 and
             (pw.Npad == (2 * pw.N if pw.glu else pw.N)) and pw.Npad <= 2048 and
             resid is None and nsplit == 0 and p_drop == 0.0 and
-            # (the kernel's fp32 result - ops.lin256 - is NOT routed here: its 16-byte-per-lane stores measured 286 against 219 us
-            #  on the BiLSTM input projections, M 131 072 x N 1024: tools/lin256_bench.py)
-            out.dtype in (torch.float16, torch.bfloat16) and
+            (out.dtype in (torch.float16, torch.bfloat16) or (out.dtype == torch.float32 and not pw.glu and out.stride(0) % 4 == 0)) and
             x16.shape[0] >= 4096 and x16.stride(1) == 1 and out.stride(1) == 1 and x16.stride(0) % 8 == 0 and
             (out.stride(0) % 8 == 0 or out.dtype == torch.float32) and
             x16.dtype == _state["dtype"] and pw.w.dtype == _state["dtype"])
