@@ -660,6 +660,19 @@ def test_bilstm_layer(ops, B, T):
     assert not torch.equal(out16, out)                     # the other kernel did run
 
 
+def test_bilstm_layer_fp16_recurrence_other_sizes(ops):
+    """sfm_bilstm_layer_ex: hidden 64 takes the fp16-operand kernel too, hidden 32 silently keeps the fp32 one (its 4-float slices
+    are too short for the 16-byte reads); a batch larger than the CU count (two chains per CU)"""
+    g = torch.Generator().manual_seed(5)
+    for H, B, T in ((64, 3, 40), (32, 2, 17), (128, 300, 9)):
+        xg = torch.randn(B, T, 2, 4 * H, generator=g)
+        whh = torch.randn(2, 4 * H, H, generator=g) / H ** 0.5
+        ref = ops.bilstm_layer(dev(xg), dev(whh), B, T, H).cpu()
+        out = ops.bilstm_layer(dev(xg), dev(whh), B, T, H, w16=True).cpu()
+        report("bilstm fp16 recurrence H%d B%d" % (H, B), out, ref, 2e-3)
+        assert torch.equal(out, ref) == (H == 32)
+
+
 def test_memory(ops):
     from sincformer_metacog_speech_enhancement_amd.functional import pack_memory_params
     sd = synth_sd("EpisodicMemory", 71)
