@@ -29,8 +29,8 @@ for B, T in ((64, 801), (256, 512), (256, 801)):
 print(json.dumps(r))
 ''' % ROOT
 for rnd in range(2):
-    for dot in ("0", "1"):
+    for dot, name in (("0", "fma"), ("1", "dot")):
         env = dict(os.environ, SFM_DWCONV_DOT=dot)
         o = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         line = [l for l in o.stdout.splitlines() if l.startswith("{")]
-        print("dot" if dot == "1" else "fma", line[-1] if line else o.stderr[-400:])
+        print(name, line[-1] if line else o.stderr[-400:])
