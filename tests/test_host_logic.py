@@ -223,3 +223,36 @@ def test_shard_range_is_a_balanced_partition():
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
         sizes = [e - s for s, e in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_lin256_routing_rule():
+    """which linears linear16 hands to the resident-operand kernel (ops._lin256_ok): K = 256, plain or GLU epilogue matching the
+    pack, no residual / dropout / column split, M >= 4096, operands in the stage's format, unit-stride rows; everything else stays
+    on sfm_gemm16.  (Host logic only: no launch.)"""
+    ops.set_compute_dtype(torch.float16)
+    try:
+        w, b = torch.randn(768, 256), torch.randn(768)
+        pw = ops.pack_linear(w, b)
+        pg = ops.pack_linear(torch.randn(512, 256), torch.randn(512), glu=True)
+        p1024 = ops.pack_linear(torch.randn(256, 1024), torch.randn(256))
+        x = torch.empty(8192, 256, dtype=torch.float16)
+        o16, obf, o32 = (torch.empty(8192, 768, dtype=d) for d in (torch.float16, torch.bfloat16, torch.float32))
+        og = torch.empty(8192, 256, dtype=torch.float16)
+        ok = ops._lin256_ok
+        assert ok(x, pw, ops.EPI_NONE, o16, None, 0, 0.0) and ok(x, pw, ops.EPI_NONE, obf, None, 0, 0.0)
+        assert ok(x, pw, ops.EPI_NONE, o32, None, 0, 0.0)                    # fp32 result: through the LDS images
+        assert ok(x, pg, ops.EPI_GLU, og, None, 0, 0.0)
+        assert not ok(x, pg, ops.EPI_NONE, og, None, 0, 0.0)                 # a GLU pack needs the GLU epilogue
+        assert not ok(x, pw, ops.EPI_GLU, o16, None, 0, 0.0)
+        assert not ok(x, pg, ops.EPI_GLU, torch.empty(8192, 256), None, 0, 0.0)   # GLU with an fp32 result: sfm_gemm16
+        assert not ok(x[:100], pw, ops.EPI_NONE, o16[:100], None, 0, 0.0)    # small M
+        assert not ok(x, pw, ops.EPI_RESID, o32, torch.empty(8192, 768), 0, 0.0)
+        assert not ok(x, pw, ops.EPI_NONE, o16, None, 0, 0.1)                # dropout in the epilogue
+        assert not ok(x, pw, ops.EPI_NONE, o16, None, 384, 0.0)              # column split (two activations)
+        assert not ok(torch.empty(8192, 1024, dtype=torch.float16), p1024, ops.EPI_NONE, og, None, 0, 0.0)   # K = 1024
+        assert not ok(x.to(torch.bfloat16), pw, ops.EPI_NONE, o16, None, 0, 0.0)   # operands not in the stage's format
+        ops.set_lin256(False)
+        assert not ok(x, pw, ops.EPI_NONE, o16, None, 0, 0.0)
+    finally:
+        ops.set_lin256(True)
+        ops.reset_precision() if hasattr(ops, "reset_precision") else None
