@@ -421,6 +421,15 @@ int sfm_lin256(const void* A, const void* W, const float* bias, void* out, int M
    16-bit normalised tensor in HBM.  16-bit results only. */
 int sfm_ln_lin256(const float* X32, int ldx, const float* lnw, const float* lnb, float eps, const void* W, const float* bias,
                   void* out, int M, int NW, int ldo, int glu, int dtype, int out_dtype, void* stream);
+/* PerceptionAgent latent heads (agents/perception.py:183-199, real_proj | imag_proj 1x1 convs stacked: NW = 2 * latent_dim rows of W) with
+   the time pooling of the fused path (glue G1) in the same launch: pooled[b, i, :] = mean over the adaptive-average window of frame i
+   of xd[b, t, :256] W^T + bias (16-bit, RAW: the GroupNorm that follows has no activation, is affine per (utterance, channel) and is
+   applied to `pooled` afterwards - sfm_pool_time_affine16 with Tin == Tout), and the GroupNorm statistics of the FULL-RATE outputs:
+   gn_partial [B, P, NW / gcols, 2] (sum, sum of squares per row tile; P = ceil(Tout / sfm_headpool_frames_per_tile(Tin, Tout)); reduce
+   with sfm_gn_finalize(rows = Tin)).  The full-rate head outputs are never written.  gcols = 16; Tin >= Tout. */
+int sfm_headpool_frames_per_tile(int Tin, int Tout);
+int sfm_headpool(const void* xd, const void* W, const float* bias, void* pooled, float* gn_partial, int B, int Tin, int Tout, int NW,
+                 int lda, int ldp, int gcols, int dtype, void* stream);
 
 /* one direction-pair of an nn.LSTM layer (agents/cpea.py:43-50,99), see lstm.hip */
 int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype, void* stream);

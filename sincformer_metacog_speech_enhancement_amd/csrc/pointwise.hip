@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void pool_time_kernel(const void* __restrict__
 
 // 8 channels per thread (16-byte loads of a 16-bit source, 2 x 16 bytes of an fp32 one): a 256-thread workgroup covers (256 / (C / 8)) output frames of one utterance; needs C % 8 == 0, C / 8 a divisor of 256 and
 // 16-byte aligned rows.  The scalar kernel above moved 2 or 4 bytes per lane and was bound by its load count, not by HBM.
-template <class T, int SRC>
+template <class T, int SRC, int PG>
 __global__ __launch_bounds__(256) void pool_time_vec_kernel(const void* __restrict__ src_, u16* dst16, float* dst32, int Tin, int Tout,
                                                             int C, long long ld_src, long long ld_dst,
                                                             const float* __restrict__ scale, const float* __restrict__ shift) {
@@ -774,12 +774,21 @@ __global__ __launch_bounds__(256) void pool_time_vec_kernel(const void* __restri
   const int i = blockIdx.x * fpb + threadIdx.x / tpf;
   const int c = (threadIdx.x % tpf) * 8;
   if (i >= Tout) return;
-  const long long s = ((long long)i * Tin) / Tout;
-  const long long e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
+  // (window bounds in 32-bit arithmetic when the products fit: two emulated 64-bit divisions per thread were a third of this
+  //  kernel's instructions; PG == 1: the window is the row itself)
+  long long s, e;
+  if (PG == 1) { s = i; e = i + 1; }
+  else if ((long long)Tin * (Tout + 1) < 2147483647LL) {
+    s = (unsigned)(i * Tin) / (unsigned)Tout;
+    e = (unsigned)((i + 1) * Tin + Tout - 1) / (unsigned)Tout;
+  } else {
+    s = ((long long)i * Tin) / Tout;
+    e = (((long long)(i + 1)) * Tin + Tout - 1) / Tout;
+  }
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  // window rows in groups of PG = 6 with ALL of a group's loads issued before the first add (a rolled `for t` loop waits out one
-  // memory round trip per row; the windows of the path are 5-6 rows: groups of 8 issued 2-3 clamped loads per window for nothing)
-  constexpr int PG = 6;
+  // window rows in groups of PG (6; 1 when Tin == Tout: the per-(utterance, channel) affine + convert of already pooled rows) with
+  // ALL of a group's loads issued before the first add (a rolled `for t` loop waits out one memory round trip per row; the windows
+  // of the path are 5-6 rows: groups of 8 issued 2-3 clamped loads per window for nothing)
   for (long long t0 = s; t0 < e; t0 += PG) {
     if (SRC == 0) {
       f32x4 a0[PG], a1[PG];
@@ -817,9 +826,16 @@ __global__ __launch_bounds__(256) void pool_time_vec_kernel(const void* __restri
   }
   const float inv = 1.0f / (float)(e - s);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    acc[j] *= inv;
-    if (scale) acc[j] = acc[j] * scale[(long long)b * C + c + j] + shift[(long long)b * C + c + j];   // affine commutes with the average
+  for (int j = 0; j < 8; ++j) acc[j] *= inv;
+  if (scale) {                                             // affine commutes with the average (16-byte loads: C % 8 == 0, c % 8 == 0)
+    const f32x4* sp = reinterpret_cast<const f32x4*>(scale + (long long)b * C + c);
+    const f32x4* hp = reinterpret_cast<const f32x4*>(shift + (long long)b * C + c);
+    const f32x4 s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = acc[j] * s0[j] + h0[j];
+      acc[4 + j] = acc[4 + j] * s1[j] + h1[j];
+    }
   }
   const long long o = ((long long)b * Tout + i) * ld_dst + c;
   if (dst16) {
@@ -842,11 +858,13 @@ static int pool_time_go(const void* src, int srcfmt, const float* scale, const f
   const int esz = srcfmt == 0 ? 4 : 2;
   const bool vec = (C % 8 == 0) && C <= 2048 && (256 % (C / 8) == 0) && ((ld_src * esz) % 16 == 0) && (((uintptr_t)src) % 16 == 0) &&
                    (!dst16 || ((ld_dst * 2) % 16 == 0 && ((uintptr_t)dst16) % 16 == 0)) &&
-                   (!dst32 || ((ld_dst * 4) % 16 == 0 && ((uintptr_t)dst32) % 16 == 0));
+                   (!dst32 || ((ld_dst * 4) % 16 == 0 && ((uintptr_t)dst32) % 16 == 0)) &&
+                   (!scale || ((((uintptr_t)scale) | ((uintptr_t)shift)) % 16 == 0));
   if (vec) {
     const int fpb = 256 / (C / 8);
     dim3 grid((Tout + fpb - 1) / fpb, B), block(256);
-#define POOL_GO(TT, S) SFM_LAUNCH((pool_time_vec_kernel<TT, S>), grid, block, 0, st, src, (u16*)dst16, dst32, Tin, Tout, C, ld_src, ld_dst, scale, shift)
+#define POOL_GO(TT, S) do { if (Tin == Tout) SFM_LAUNCH((pool_time_vec_kernel<TT, S, 1>), grid, block, 0, st, src, (u16*)dst16, dst32, Tin, Tout, C, ld_src, ld_dst, scale, shift); \
+                            else SFM_LAUNCH((pool_time_vec_kernel<TT, S, 6>), grid, block, 0, st, src, (u16*)dst16, dst32, Tin, Tout, C, ld_src, ld_dst, scale, shift); } while (0)
 #define POOL_SRC(TT) { if (srcfmt == 0) POOL_GO(TT, 0); else if (srcfmt == 1) POOL_GO(TT, 1); else POOL_GO(TT, 2); }
     if (dtype == SFM_DT_F16) POOL_SRC(F16) else POOL_SRC(BF16)
 #undef POOL_SRC

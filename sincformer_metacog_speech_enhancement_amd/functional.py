@@ -378,10 +378,13 @@ def _conv_gn(x16, pw, B, Lin, stride, pad, groups, raw_dtype):
     return raw, part, P, Lout
 
 
-def perception_forward(wave, pk, keep_sinc=False, latents=True):
-    """wave [B, L] fp32 -> zcat [B, T_pa, 2D] fp32 (z_real | z_imag, channels-last), sigma [B, T_pa] fp32."""
+def perception_forward(wave, pk, keep_sinc=False, latents=True, pool_to=None):
+    """wave [B, L] fp32 -> zcat [B, T_pa, 2D] fp32 (z_real | z_imag, channels-last), sigma [B, T_pa] fp32.
+    latents=False: zcat = (raw head outputs [B, T_pa, 2D] 16-bit, scale, shift [B, 2D]) - the caller only pools the latents, and the
+    GroupNorm behind the heads is affine per (utterance, channel); with pool_to = T (the STFT frame count) the heads and the pooling
+    are one launch (ops.headpool) and the first element is already the POOLED raw output [B, T, 2D]."""
     with ops.stage("pa"):
-        return _perception_forward(wave, pk, keep_sinc, latents)
+        return _perception_forward(wave, pk, keep_sinc, latents, pool_to)
 
 
 PATCH_CONV = True     # False: one gn_apply pass + implicit-GEMM convs (sfm_gemm16) per layer, as in round 1
@@ -422,7 +425,7 @@ def _patch_conv_ok(pk):
     return ops.conv16p_supported(cin, pk["D"], 5, 2, 2, True, False)
 
 
-def _perception_forward(wave, pk, keep_sinc, latents):
+def _perception_forward(wave, pk, keep_sinc, latents, pool_to=None):
     dt = ops.compute_dtype()
     wave = wave.contiguous()
     B, L = wave.shape
@@ -484,7 +487,17 @@ def _perception_forward(wave, pk, keep_sinc, latents):
     # complex latent heads: one GEMM for (real | imag), GroupNorm(16) per half = 32 groups over 2D channels
     # (raw output fp32 when the full-rate latents are returned; otherwise in the operands' format: it is only pooled, and the
     #  GroupNorm statistics come from the fp32 accumulators either way)
-    rz, pz, Pz, _ = _conv_gn(xd, pk["zproj"], B, Tpa, 1, 0, 32, torch.float32 if latents else dt)
+    tiles = None
+    if not latents and pool_to is not None and D == 256 and pk["zproj"].Npad == 2 * D and pk["zproj"].ksize == 1:
+        tiles = ops.headpool_tiles(Tpa, pool_to)
+    if tiles is not None:
+        # heads + time pooling in one launch: the full-rate raw latents are never written (their GroupNorm statistics are)
+        rz = torch.empty(B, pool_to, 2 * D, device=dev, dtype=dt)
+        pz = torch.empty(B, tiles[1], 32, 2, device=dev, dtype=torch.float32)
+        ops.headpool(xd, pk["zproj"], rz, pz, B, Tpa, pool_to, gcols=(2 * D) // 32)
+        Pz = tiles[1]
+    else:
+        rz, pz, Pz, _ = _conv_gn(xd, pk["zproj"], B, Tpa, 1, 0, 32, torch.float32 if latents else dt)
     sz, hz = ops.gn_finalize(pz, pk["z_w"], pk["z_b"], B, Pz, 32, 2 * D, Tpa)
     if latents:
         zcat = torch.empty(B, Tpa, 2 * D, device=dev, dtype=torch.float32)
@@ -653,9 +666,9 @@ def enhance_path(wave, packs, H=4, use_memory=False, want=("mask", "wave")):
     pa = packs["pa"]
     D = pa["D"]
     want_lat = "latents" in want
-    zcat, sigma = perception_forward(wave, pa, latents=want_lat)       # [B, Tpa, 2D] fp32 (or raw + GroupNorm affine)
+    zcat, sigma = perception_forward(wave, pa, latents=want_lat, pool_to=T)   # [B, Tpa, 2D] fp32 (or raw / pooled raw + GroupNorm affine)
     zsrc, zsc, zsh = (zcat, None, None) if want_lat else zcat
-    Tpa = zsrc.shape[1]
+    Tpa = zsrc.shape[1]                                                # (= T when the heads kernel pooled already: identity windows below)
     fused = torch.empty(M, FUSE_LD, device=dev, dtype=dt)
     with ops.stage("front"):
         ops.pool_time(zsrc, fused, None, B, Tpa, T, 2 * D, 2 * D, FUSE_LD, scale=zsc, shift=zsh)   # G1 -> fused[:, :2D]

@@ -122,6 +122,8 @@ SIGNATURES = {
     "sfm_attention_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                           ctypes.c_uint, c_i, c_vp],
     "sfm_lin256": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_headpool_frames_per_tile": [c_i, c_i],
+    "sfm_headpool": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_ln_lin256": [c_vp, c_i, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_ex": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],

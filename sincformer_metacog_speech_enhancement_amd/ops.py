@@ -465,6 +465,35 @@ def lin256(x16, pw, out):
     return out
 
 
+_HEADPOOL = {"on": _os.environ.get("SFM_HEADPOOL", "1") != "0"}
+
+
+def set_headpool(flag):
+    """latent heads + time pooling in one launch (sfm_headpool) in the fused path; False / SFM_HEADPOOL=0 = heads GEMM, then pool_time"""
+    _HEADPOOL["on"] = bool(flag)
+
+
+def headpool_tiles(Tin, Tout):
+    """(frames per tile, tiles per utterance) of sfm_headpool, or None when the pair is not supported / the fusion is switched off"""
+    if not _HEADPOOL["on"] or _state["gemm_variant"] != 0:
+        return None
+    fpt = int(_lib.load().sfm_headpool_frames_per_tile(int(Tin), int(Tout)))
+    return (fpt, (Tout + fpt - 1) // fpt) if fpt > 0 else None
+
+
+def headpool(xd16, pw, pooled16, part, B, Tin, Tout, gcols=16):
+    """xd16 [B, Tin, 256] -> pooled16 [B, Tout, N] = time-pooled RAW head outputs, part [B, P, N / gcols, 2] = GroupNorm partial sums of
+    the full-rate outputs (see include/sincformer_hip.h)."""
+    _need_dev(xd16, pooled16, part)
+    L = _lib.load()
+    if xd16.dtype != _state["dtype"] or pw.w.dtype != _state["dtype"] or pooled16.dtype != _state["dtype"]:
+        raise RuntimeError("headpool: operands must be in the stage's format")
+    _call("gemm16", L.sfm_headpool, (_p(xd16), _p(pw.w), _p(pw.bias), _p(pooled16), _p(part), B, Tin, Tout, pw.Npad, xd16.stride(1),
+                                     pooled16.stride(1), gcols, _dt(), _stream()),
+          2.0 * B * Tin * pw.Npad * 256, B * Tin * 512.0 + pw.Npad * 512.0 + B * Tout * pw.Npad * 2.0,
+          tag="M%d N%d K256 headpool->T%d" % (B * Tin, pw.Npad, Tout))
+
+
 def ln_linear16(x32, ln_w, ln_b, pw, epi=EPI_NONE, out_dtype=None, eps=1e-5):
     """linear16(LayerNorm(x32[:, :256]), pw, epi) with a 16-bit result.  On the shapes sfm_lin256 takes (K = 256, plain or GLU epilogue,
     M >= 4096) the LayerNorm is the GEMM kernel's prologue (sfm_ln_lin256): one launch, the normalised 16-bit rows never reach HBM;

@@ -163,6 +163,34 @@ def test_ln_linear16_layernorm_as_the_gemm_prologue(ops, dt, M, N, glu):
                (6 * EPS[odt] + 16 * EPS[dt]) * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,Tin,Tout", [(3, 2555, 512), (2, 4000, 801), (2, 640, 129), (1, 300, 300)])
+def test_headpool_heads_and_time_pooling_in_one_launch(ops, dt, B, Tin, Tout):
+    """sfm_headpool: the PerceptionAgent's stacked latent heads (1x1 conv, 256 -> 512) + adaptive average pooling to the STFT frame
+    count + GroupNorm partial sums of the full-rate outputs, against the fp32 reference on the rounded operands; ragged last tile,
+    windows of 5 / 6 and of 1 frame, a row shared by two tiles counted once"""
+    ops.set_compute_dtype(dt)
+    tiles = ops.headpool_tiles(Tin, Tout)
+    assert tiles is not None and tiles[0] >= 1
+    x = arr("hpx", (B, Tin, 256), 41)
+    w, b = arr("hpw", (512, 256), 42) / 16.0, arr("hpb", (512,), 43)
+    pw = ops.pack_linear(dev(w), dev(b))
+    raw = q16(x, dt) @ q16(w, dt).t() + b                                            # [B, Tin, 512] fp32
+    ref = torch.stack([raw[:, (i * Tin) // Tout: -((-(i + 1) * Tin) // Tout)].mean(1) for i in range(Tout)], dim=1)
+    pooled = torch.full((B, Tout, 520), 5.0, device="cuda", dtype=dt)                # ldp > N
+    part = torch.full((B, tiles[1], 32, 2), float("nan"), device="cuda")
+    ops.headpool(dev(x).to(dt).contiguous(), pw, pooled[:, :, :512], part, B, Tin, Tout)
+    report("headpool pooled %s T%d->%d" % (dt, Tin, Tout), pooled[:, :, :512].float().cpu(), ref, 3 * EPS[dt] * float(ref.abs().max()))
+    assert float(pooled[:, :, 512:].float().min()) == 5.0
+    sums = part.double().sum(1).cpu()                                                # [B, 32, 2]
+    rg = raw.double().reshape(B, Tin, 32, 16)
+    report("headpool sum", sums[..., 0].float(), rg.sum((1, 3)).float(), 2e-5 * float(rg.abs().sum((1, 3)).max()))
+    report("headpool sum of squares", sums[..., 1].float(), (rg ** 2).sum((1, 3)).float(), 2e-5 * float((rg ** 2).sum((1, 3)).max()))
+    again = torch.empty_like(part)
+    ops.headpool(dev(x).to(dt).contiguous(), pw, torch.empty(B, Tout, 512, device="cuda", dtype=dt), again, B, Tin, Tout)
+    assert torch.equal(again, part)                                                  # fixed summation order
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_gemm16_strided_operand_views(ops, variant):
     """A is a column slice of a wider buffer (lda > K), output goes into a column slice (ldo > N)"""
