@@ -170,6 +170,7 @@ def test_headpool_heads_and_time_pooling_in_one_launch(ops, dt, B, Tin, Tout):
     count + GroupNorm partial sums of the full-rate outputs, against the fp32 reference on the rounded operands; ragged last tile,
     windows of 5 / 6 and of 1 frame, a row shared by two tiles counted once"""
     ops.set_compute_dtype(dt)
+    ops.set_headpool(True)                                                           # (whatever SFM_HEADPOOL says)
     tiles = ops.headpool_tiles(Tin, Tout)
     assert tiles is not None and tiles[0] >= 1
     x = arr("hpx", (B, Tin, 256), 41)
