@@ -62,7 +62,8 @@ def test_bench_default_line_is_on_the_metrics_shape_and_carries_configs1_and_tra
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     a = d["headline"]["attention"]
     assert a["operands"] == "bf16" and a["tflops"] > 300 and abs(a["frac_bf16_mfma_peak"] - a["tflops"] / 2500.0) < 1e-9
-    assert len(a["window_avg_ms"]) == 5
+    assert len(a["window_avg_ms"]) == 5 and a["sustained_launches"] >= 2000 and 0 < a["frac_windows_median"] < 1
+    assert abs(a["tflops"] - 4.0 * 256 * 4 * 512 * 512 * 64 / a["avg_ms"] / 1e9) < 1e-6 * a["tflops"]
     c = d["configs1"]
     assert "B64 x 4 s" in c["workload"] and c["frames_per_s"] > 1e6 and c["roofline"]["frac"] > 0
     assert "T801" in c["attention"]["shape"] and c["attention"]["tflops"] > 100

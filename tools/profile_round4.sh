@@ -23,8 +23,10 @@ for w in c3p c2; do
   rocprofv3 --pmc WRITE_SIZE -d $O/prof/write_$w -o write --output-format csv -- python3 $R/bench.py --workload $w $FW --streams 1 --steps 3 --warmup 1 --no-sustained > /dev/null 2> $O/prof/write_$w.log
   python3 $R/tools/pmc_summary.py $(find $O/prof/fetch_$w -name "*counter_collection.csv") $(find $O/prof/write_$w -name "*counter_collection.csv") $O/pmc_traffic_$w.json > $O/prof/pmc_traffic_$w.txt
 done
-step "attention trace"
+step "attention trace (50 launches from idle)"
 rocprofv3 --kernel-trace --stats -d $O/prof/attn -o attn --output-format csv -- python3 $R/tools/attn_bench.py --iters 50 > $O/attn_bench_b256_t512.json 2> $O/prof/attn.log
+step "attention trace (20 000 launches: steady state)"
+rocprofv3 --kernel-trace --stats -d $O/prof/attns -o attns --output-format csv -- python3 $R/tools/attn_bench.py --iters 20000 > $O/attn_bench_b256_t512_sustained.json 2> $O/prof/attns.log
 step "attention pmc"
 bash $R/tools/pmc_attn_run.sh attention_pipe_t512 --iters 20 > $O/prof/pmc_attn.txt 2>&1
 cp $O/pmc_attention_pipe_t512/summary.json $O/pmc_attention_pipe_t512.json 2>/dev/null
@@ -36,7 +38,7 @@ bash $R/tools/pmc_run.sh gemm16v2 gemm16v2_kernel tools/gemm_k256_bench.py > $O/
 cp $O/pmc_gemm16v2/summary.json $O/pmc_gemm16v2.json 2>/dev/null
 step "trace c3t"
 rocprofv3 --kernel-trace --stats -d $O/prof/c3t -o c3t --output-format csv -- python3 $R/bench.py --workload c3t --no-cpu-baseline --steps 4 --warmup 2 > $O/prof/bench_c3t_profiled.json 2> $O/prof/c3t.log
-for t in c3p c3ps1 c2s1 attn c3t; do
+for t in c3p c3ps1 c2s1 attn attns c3t; do
   f=$(find $O/prof/$t -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats_$t.csv && echo "== $t" && head -8 $f | cut -c1-170
 done
