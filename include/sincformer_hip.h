@@ -437,6 +437,9 @@ int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T
    cell state / output fp32): half the registers, so two chains share a CU - 1.6 x at batch 256; H 32 keeps the fp32 kernel.
    (agents/cpea.py:43-50,99: the same nn.LSTM recurrence) */
 int sfm_bilstm_layer_ex(const float* xg, const float* whh, float* out, int B, int T, int H, int w16, void* stream);
+/* sfm_bilstm_layer_train with the same fp16-operand recurrent product (the reference's LSTM runs under fp16 autocast in training:
+   training/conformer_pipeline.py:504); `save` and the BPTT (sfm_bilstm_layer_bwd) stay fp32 */
+int sfm_bilstm_layer_train_ex(const float* xg, const float* whh, float* out, float* save, int B, int T, int H, int w16, void* stream);
 /* training: as sfm_bilstm_layer, also saving the activated gates and cell states [B, T, 2, 5, H] fp32; and the BPTT of
  * the layer: dout [B, T, 2H] -> dxg [B, T, 2, 4H] = gradient w.r.t. the input projection (dW_ih, dW_hh, biases and dx
  * are GEMMs / column sums of dxg afterwards). */

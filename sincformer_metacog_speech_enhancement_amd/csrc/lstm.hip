@@ -119,11 +119,11 @@ __global__ __launch_bounds__(LPU * H) void bilstm_layer_kernel(const float* __re
 // the kernel fits 4 waves per SIMD, so TWO chains share a CU - at batch 256 there are 512 chains for 256 CUs and the fp32 form runs
 // them in two rounds), h published in LDS as fp16 (half the LDS bytes of a step), `v_dot2_f32_f16` with fp32 accumulation (half the
 // multiply-add instructions).  c, the gates and the h written to `out` stay fp32; what is rounded is the recurrent operand pair, to
-// the format every MFMA operand of the 16-bit path already has.  No `save`: training keeps the fp32 kernel above.
+// the format every MFMA operand of the 16-bit path already has.  SAVE: the training forward (gates and cell states for the BPTT).
 typedef _Float16 lstm_h2 __attribute__((ext_vector_type(2)));
-template <int H, int LPU>
+template <int H, int LPU, bool SAVE>
 __global__ __launch_bounds__(LPU * H, 4) void bilstm_layer16_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
-                                                                    float* __restrict__ out, int T) {
+                                                                    float* __restrict__ out, int T, float* __restrict__ save) {
   constexpr int KS = H / LPU;                                // h values per lane
   constexpr int KW = KS / 2;                                 // = dwords (half pairs) per slice
   constexpr int SLW = KW + 4;                                // dword stride of a slice
@@ -197,6 +197,11 @@ __global__ __launch_bounds__(LPU * H, 4) void bilstm_layer16_kernel(const float*
       const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)h);
       asm volatile("ds_write_b16 %0, %1" ::"v"(hslot + (uint32_t)(((s + 1) & 1) * LPU * SLW * 4)), "v"(hb) : "memory");
       ob[(long long)t * (2 * H)] = h;
+    }
+    if (SAVE) {                                              // training: activated gates and cell state for the BPTT (fp32)
+      float* sv = save + ((((long long)b * T + t) * 2 + dir) * 5) * H + j;
+      if (ks < 4) sv[mygate * H] = act;
+      if (ks == LPU - 4) sv[4 * H] = c;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
@@ -293,8 +298,9 @@ template <int H>
 static int bilstm_fwd_go(const float* xg, const float* whh, float* out, float* save, int B, int T, hipStream_t st, bool w16 = false) {
   constexpr int LPU = H >= 64 ? SFM_LSTM_LPU : 8;           // H 32: 4 x H / 4 = 8-float slices, too short for the float4 reads
   if constexpr (H >= 64 && (H / LPU) % 8 == 0) {
-    if (w16 && !save) {
-      SFM_LAUNCH((bilstm_layer16_kernel<H, LPU>), dim3(2, B), dim3(LPU * H), 0, st, xg, whh, out, T);
+    if (w16) {
+      if (save) SFM_LAUNCH((bilstm_layer16_kernel<H, LPU, true>), dim3(2, B), dim3(LPU * H), 0, st, xg, whh, out, T, save);
+      else SFM_LAUNCH((bilstm_layer16_kernel<H, LPU, false>), dim3(2, B), dim3(LPU * H), 0, st, xg, whh, out, T, save);
       return SFM_OK;
     }
   }
@@ -318,6 +324,19 @@ extern "C" int sfm_bilstm_layer_train(const float* xg, const float* whh, float* 
 extern "C" int sfm_bilstm_layer(const float* xg, const float* whh, float* out, int B, int T, int H, int dtype,
                                 void* stream) {
   return sfm_bilstm_layer_train(xg, whh, out, nullptr, B, T, H, dtype, stream);
+}
+
+// training forward with the recurrent product on fp16 operands when w16 != 0 (the reference trains its nn.LSTM under fp16 autocast:
+// training/conformer_pipeline.py:504); the saved gates / cell states and the BPTT stay fp32
+extern "C" int sfm_bilstm_layer_train_ex(const float* xg, const float* whh, float* out, float* save, int B, int T, int H, int w16,
+                                         void* stream) {
+  if (!xg || !whh || !out || !save) return SFM_ERR_ARG;
+  if (B <= 0 || T <= 0) return SFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 128) return bilstm_fwd_go<128>(xg, whh, out, save, B, T, st, w16 != 0);
+  if (H == 64) return bilstm_fwd_go<64>(xg, whh, out, save, B, T, st, w16 != 0);
+  if (H == 32) return bilstm_fwd_go<32>(xg, whh, out, save, B, T, st, false);
+  return SFM_ERR_SHAPE;
 }
 
 // inference, recurrent product on fp16 operands when w16 != 0 (bilstm_layer16_kernel; H 32 keeps the fp32 kernel)

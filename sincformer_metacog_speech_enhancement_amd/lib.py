@@ -128,6 +128,7 @@ SIGNATURES = {
     "sfm_bilstm_layer": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_ex": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_train": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "sfm_bilstm_layer_train_ex": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "sfm_bilstm_layer_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "sfm_memory_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp],
     "sfm_memory_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_vp],

@@ -1276,12 +1276,19 @@ def bilstm_layer(xg, whh, B, T, H, w16=False):
     return out
 
 
-def bilstm_layer_train(xg, whh, B, T, H):
-    """forward of one BiLSTM layer that also saves the activated gates / cell states [B, T, 2, 5, H] for the BPTT"""
+def bilstm_layer_train(xg, whh, B, T, H, w16=None):
+    """forward of one BiLSTM layer that also saves the activated gates / cell states [B, T, 2, 5, H] for the BPTT.
+    w16 (default: lstm_w16() when the training format is fp16): the recurrent product on fp16 operands, as under the reference's
+    fp16 autocast; the saved state and the backward stay fp32"""
     L = _lib.load()
     out = torch.empty(B, T, 2 * H, device=xg.device, dtype=torch.float32)
     save = torch.empty(B, T, 2, 5, H, device=xg.device, dtype=torch.float32)
-    _call("bilstm_layer", L.sfm_bilstm_layer_train, (_p(xg), _p(whh), _p(out), _p(save), B, T, H, _dt(), _stream()))
+    if w16 is None:
+        w16 = _LSTM["w16"] and _state["dtype"] == torch.float16
+    if w16:
+        _call("bilstm_layer", L.sfm_bilstm_layer_train_ex, (_p(xg), _p(whh), _p(out), _p(save), B, T, H, 1, _stream()))
+    else:
+        _call("bilstm_layer", L.sfm_bilstm_layer_train, (_p(xg), _p(whh), _p(out), _p(save), B, T, H, _dt(), _stream()))
     return out, save
 
 

@@ -689,6 +689,23 @@ def test_bilstm_layer(ops, B, T):
     assert not torch.equal(out16, out)                     # the other kernel did run
 
 
+def test_bilstm_layer_train_fp16_recurrence_saves_consistent_state(ops):
+    """training forward on the fp16-operand recurrence (sfm_bilstm_layer_train_ex): output, saved gates and cell states against the
+    fp32 kernel's; the saved state is what the BPTT consumes, so it must describe THIS forward (out = o * tanh(c) exactly)"""
+    g = torch.Generator().manual_seed(6)
+    H, B, T = 128, 3, 25
+    xg = torch.randn(B, T, 2, 4 * H, generator=g)
+    whh = torch.randn(2, 4 * H, H, generator=g) / H ** 0.5
+    o32, s32 = ops.bilstm_layer_train(dev(xg), dev(whh), B, T, H, w16=False)
+    o16, s16 = ops.bilstm_layer_train(dev(xg), dev(whh), B, T, H, w16=True)
+    report("bilstm train fp16 recurrence: out", o16.cpu(), o32.cpu(), 2e-3)
+    report("bilstm train fp16 recurrence: saved gates / cell", s16.cpu(), s32.cpu(), 4e-3)
+    for d in range(2):
+        h = s16[:, :, d, 3] * torch.tanh(s16[:, :, d, 4])
+        report("saved state reproduces the output, dir %d" % d, h.cpu(), o16[:, :, d * H:(d + 1) * H].cpu(), 2e-6)
+    assert not torch.equal(o16, o32)
+
+
 def test_bilstm_layer_fp16_recurrence_other_sizes(ops):
     """sfm_bilstm_layer_ex: hidden 64 takes the fp16-operand kernel too, hidden 32 silently keeps the fp32 one (its 4-float slices
     are too short for the 16-byte reads); a batch larger than the CU count (two chains per CU)"""
